@@ -1,0 +1,167 @@
+/*
+ * scn_hip.h -- C ABI of libscn_hip.so: the MI355X (gfx950) sparse-convolution
+ * hot path behind the reference's `sparseconvnet.SCN` extension boundary.
+ *
+ * Every entry point replaces one (or the device half of one) function the
+ * reference binds in sparseconvnet/SCN/pybind.cpp and dispatches in
+ * sparseconvnet/SCN/sparseconvnet_cuda.cpp.  Paths below are relative to the
+ * reference tree.  Conventions:
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - features are contiguous fp32 [rows, planes]; indices are int32 (`Int`,
+ *     sparseconvnet/SCN/Metadata/32bits.h:11);
+ *   - `stream` is a hipStream_t passed as void*; nothing runs on another stream;
+ *   - the only entry points that synchronise the stream are the two whose
+ *     result size is data dependent (scn_grid_build, scn_input_rules_max_active);
+ *   - no entry point allocates device memory: callers pass workspaces whose
+ *     sizes are given by the *_bytes query functions;
+ *   - return value 0 = ok, otherwise an error code; scn_last_error() holds text.
+ *
+ * Rulebook layout ("rules"): int32 [K][stride][2]; list k holds counts[k] pairs
+ * (col0, col1) exactly as the reference's RuleBook rules[k] = {in0,out0,in1,out1,..}
+ * (sparseconvnet/SCN/Metadata/Metadata.h:73), bit for bit, but device resident.
+ */
+#ifndef SCN_HIP_H
+#define SCN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCN_ABI_VERSION 1
+#define SCN_TILE_GRANULE 32 /* output-row granule of the tile-base tables */
+
+int scn_abi_version(void);
+const char *scn_last_error(void);
+
+/* ---------------------------------------------------------------- grids ---
+ * Voxel grid of one scale = the reference's GPU_SparseGrids + Multival_Point_Hashtable
+ * (sparseconvnet/SCN/Metadata/Metadata.h:114-120, sparseconvnet/SCN/CUDA/CUDPPWrapper.hpp:731-999).
+ */
+
+/* workspace bytes needed by scn_grid_build for P input rows */
+size_t scn_grid_build_temp_bytes(int64_t P);
+
+/* Number the active sites.  Replaces HashInputPointClouds + InsertAndCompactPointCloud
+ * (sparseconvnet/SCN/CUDA/CUDPPWrapper.hpp:663-681,:767-793; key :CUDPPWrapper.cu:80-83; rank
+ * semantics extra/cudpp/src/cudpp_hash/hash_multivalue.cpp:45-93) for the input
+ * layer (coords int64 [P,ncols], ncols 3|4, shift 0) and the `insert` of the
+ * coarse grid in Convolution_InputSgToRulesAndOutputSg_FastDownSampleMode
+ * (sparseconvnet/SCN/Metadata/ConvolutionRules.h:370-372; coords = fine site coords int32 [P,4], shift 1).
+ *   keys_sorted [P] u64   (b<<31 | key31) ascending
+ *   order       [P] i32   original row of each sorted position (stable)
+ *   site_of_row [P] i32   global site id of each input row  (`_d_hash_idx`)
+ *   site_start  [P+1] i32 first sorted position of each site; site_start[N] = P
+ *   n_sites_host          N, written after ONE stream synchronisation
+ * error if a coordinate lies outside 0<=x<1024, 0<=y<2048, 0<=z<1024 (the
+ * reference silently aliases there, sparseconvnet/SCN/CUDA/CUDPPWrapper.cu:80-81). */
+int scn_grid_build(const void *coords, int coords_are_i64, int ncols, int shift, int64_t P,
+                   void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
+                   int32_t *site_of_row, int32_t *site_start, int32_t *n_sites_host,
+                   void *stream);
+
+/* site_coords [N,4] i32 = (x,y,z,b) of the first duplicate of each site
+ * (sparseconvnet/SCN/CUDA/CUDPPWrapper.cu:224-226), site_keys [N] u64. */
+int scn_grid_finalize(const void *coords, int coords_are_i64, int ncols, int shift, int64_t P,
+                      int64_t N, const uint64_t *keys_sorted, const int32_t *order,
+                      const int32_t *site_start, int32_t *site_coords, uint64_t *site_keys,
+                      void *stream);
+
+/* open-addressing voxel hash map key -> site id; capacity (power of two >= 2N) */
+int64_t scn_hash_capacity(int64_t N);
+int scn_hash_build(const uint64_t *site_keys, int64_t N, uint64_t *table_keys,
+                   int32_t *table_vals, int64_t capacity, void *stream);
+
+/* padded input rule table [N, 1+maxActive] in the reference's host format
+ * (sparseconvnet/SCN/CUDA/CUDPPWrapper.cu:53-64; sparseconvnet/SCN/Metadata/IOLayersRules.h:181-199).
+ * Not used by the hot path (which reads order/site_start directly). */
+int scn_input_rules_max_active(const int32_t *site_start, int64_t N, int32_t *scratch_dev,
+                               int32_t *max_active_host, void *stream);
+int scn_input_rules_table(const int32_t *order, const int32_t *site_start, int64_t N,
+                          int32_t max_active, int32_t *table, void *stream);
+
+/* ------------------------------------------------------------ rulebooks --- */
+
+/* 3x3x3 submanifold rulebook.  Replaces SubmanifoldBuildObject::{generateQueryList,
+ * global_hash_query, generate_rulebook} (sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cpp:97-202;
+ * kernels sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:45-114) and the 27 CUDPP compactions.
+ *   nbr    [27][N] i32   neighbour site per offset or -1
+ *   rules  [27][N][2] i32, counts [27] i32 (device)
+ *   temp   scn_rules_temp_bytes(N, 27) bytes */
+size_t scn_rules_temp_bytes(int64_t N, int K);
+int scn_submanifold_rules(const int32_t *site_coords, int64_t N, const uint64_t *table_keys,
+                          const int32_t *table_vals, int64_t capacity, int32_t *nbr,
+                          int32_t *rules, int32_t *counts, void *temp, size_t temp_bytes,
+                          void *stream);
+
+/* size 2 / stride 2 rulebook: pairs (fine, coarse), 8 lists, ascending fine.
+ * Replaces d_Convolution_GenerateOutputRules
+ * (sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:534-628).  rules [8][N][2]. */
+int scn_strided_rules(const int32_t *fine_coords, int64_t N, const int32_t *coarse_of_fine,
+                      int32_t *rules, int32_t *counts, void *temp, size_t temp_bytes,
+                      void *stream);
+
+/* bases [K][n_granules+1]: index of the first pair of list k whose column
+ * `out_col` is >= g*SCN_TILE_GRANULE (lists are sorted on that column);
+ * n_granules = ceil(n_out / SCN_TILE_GRANULE). */
+int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
+                   int out_col, int64_t n_out, int32_t *bases, void *stream);
+
+/* ------------------------------------------------------- gather-mm-scatter ---
+ * out[o,:] = (bias) + sum_k sum_{pairs of list k} in[pair.in_col,:] . W[k]
+ * Replaces cuda_SubmanifoldConvolution_updateOutput / cuda_Convolution_updateOutput /
+ * cuda_Deconvolution_updateOutput (sparseconvnet/SCN/CUDA/Convolution.cpp:36-66,:105-162;
+ * sparseconvnet/SCN/CUDA/Deconvolution.cpp:20-49) and, with transposed weights, the dInput half
+ * of the matching *_backward.  W is [K][Ci][Co] row major.  `out` is fully overwritten.
+ * in_col/out_col: 0/1 for conv + submanifold, 1/0 for deconvolution
+ * (sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49). */
+int scn_conv_forward(const float *in, float *out, const float *W, const float *bias,
+                     const int32_t *rules, const int32_t *bases, int K, int64_t stride,
+                     int in_col, int out_col, int64_t n_out, int Ci, int Co, void *stream);
+
+/* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller,
+ * as the reference's callers do: sparseconvnet/submanifoldConvolution.py:114-115).
+ * Replaces dConvolution_KMxKN_backward_dW_* (sparseconvnet/SCN/CUDA/Convolution.cu:265-442,:695-753). */
+int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
+                     const int32_t *counts, int K, int64_t stride, int in_col, int out_col,
+                     int Ci, int Co, void *stream);
+
+/* Wt[k][co][ci] = W[reverse ? K-1-k : k][ci][co] */
+int scn_weight_transpose(const float *W, float *Wt, int K, int Ci, int Co, int reverse,
+                         void *stream);
+
+/* column sums: d_bias[c] = sum_rows dOut[r][c] (sparseconvnet/SCN/CUDA/Convolution.cu:52-75) */
+int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream);
+
+/* ----------------------------------------------------------- batch norm ---
+ * Replaces cuda_BatchNormalization_updateOutput / _backward
+ * (sparseconvnet/SCN/CUDA/BatchNormalization.cpp:21-76, kernels sparseconvnet/SCN/CUDA/BatchNormalization.cu:14-199);
+ * arithmetic of sparseconvnet/SCN/CPU/BatchNormalization.cpp:12-107.  weight/bias/d_weight/d_bias may be NULL.
+ * temp: scn_bn_temp_bytes(C) bytes.  Backward rewrites d_out in place (BatchNormalization.cu:151-153). */
+size_t scn_bn_temp_bytes(int C);
+int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invstd,
+                   float *running_mean, float *running_var, const float *weight,
+                   const float *bias, double eps, double momentum, int train, double leakiness,
+                   int64_t N, int C, void *temp, void *stream);
+int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
+                    const float *save_mean, const float *save_invstd, const float *weight,
+                    float *d_weight, float *d_bias, double leakiness, int64_t N, int C,
+                    void *temp, void *stream);
+
+/* ------------------------------------------------------ input / output ---
+ * Replaces InputLayer_fp/bp (sparseconvnet/SCN/CUDA/IOLayers.cu:17-76) and the four wrappers of
+ * sparseconvnet/SCN/CUDA/IOLayers.cpp:17-154.  average != 0 for mode 4. */
+int scn_input_forward(const float *feats, float *out, const int32_t *order,
+                      const int32_t *site_start, int64_t N, int C, int average, void *stream);
+int scn_input_backward(float *d_feats, const float *d_out, const int32_t *site_of_row,
+                       const int32_t *site_start, int64_t P, int C, int average, void *stream);
+int scn_output_forward(const float *in, float *out, const int32_t *site_of_row, int64_t P,
+                       int C, void *stream);
+int scn_output_backward(float *d_in, const float *d_out, const int32_t *order,
+                        const int32_t *site_start, int64_t N, int C, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCN_HIP_H */

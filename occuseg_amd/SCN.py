@@ -1,0 +1,477 @@
+"""Drop-in for the reference's pybind11 module ``sparseconvnet.SCN``
+(sparseconvnet/SCN/pybind.cpp:11-239, declarations sparseconvnet/SCN/sparseconvnet.h), D = 3,
+hot-path functions only.  Same names, argument order and ownership rules as the
+reference: callers pass empty outputs which are ``resize_``d and filled here;
+``d_weight`` / ``d_bias`` arrive zeroed and are accumulated into; batch-norm
+backward rewrites ``d_output_features`` in place.
+
+Everything here is host-side plumbing (torch owns device memory and streams);
+all arithmetic and all rulebook construction happens in libscn_hip.so through
+the C ABI of include/scn_hip.h.  CPU tensors are refused: there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+GRANULE = 32  # SCN_TILE_GRANULE
+
+
+def _lib_():
+    return _lib.load()
+
+
+def _size_key(t):
+    return tuple(int(v) for v in t.tolist()) if torch.is_tensor(t) else tuple(int(v) for v in t)
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "occuseg_amd.SCN.%s: features must live on the GPU -- this backend has no CPU path "
+            "(the CPU restatement lives in oracle/ and is test infrastructure only)" % what)
+    if t.dtype != torch.float32:
+        raise RuntimeError("occuseg_amd.SCN.%s: only float32 features are supported" % what)
+
+
+class _Grid(object):
+    """Active sites of one scale (device resident)."""
+    __slots__ = ("n", "coords", "keys", "hash_keys", "hash_vals", "hash_cap")
+
+    def __init__(self, n, coords, keys):
+        self.n = n
+        self.coords = coords  # int32 [N,4]  (x,y,z,b) in global site order
+        self.keys = keys      # int64 [N]    (b<<31 | key31), ascending
+        self.hash_keys = None
+        self.hash_vals = None
+        self.hash_cap = 0
+
+
+class _RuleBook(object):
+    """Device rulebook: rules int32 [K, stride, 2], counts int32 [K] (device),
+    tile-base tables per output column."""
+    __slots__ = ("K", "stride", "rules", "counts", "bases", "n_rows", "total_pairs", "nbr")
+
+    def __init__(self, K, stride, rules, counts):
+        self.K = K
+        self.stride = stride
+        self.rules = rules
+        self.counts = counts
+        self.bases = {}      # out_col -> int32 [K, n_gran+1]
+        self.n_rows = {}     # out_col -> number of output rows
+        self.total_pairs = None
+        self.nbr = None
+
+    def host_lists(self):
+        """reference-format host rulebook: list of K int32 arrays [R_k, 2]"""
+        counts = self.counts.cpu().tolist()
+        r = self.rules.cpu().numpy()
+        return [r[k, :counts[k]].copy() for k in range(self.K)]
+
+
+class Metadata_3(object):
+    """Mirror of ``Metadata<3>`` (sparseconvnet/SCN/Metadata/Metadata.h:218-364): per-scale grids,
+    rulebook caches keyed like the reference (sparseconvnet/SCN/Metadata/32bits.h:17-76)."""
+
+    def __init__(self):
+        self.normal_guide_scale = 10240
+        self.clear()
+
+    def clear(self):
+        self.grids = {}
+        self.nActive = {}
+        self.submanifoldRuleBooks = {}
+        self.ruleBooks = {}
+        self.device = None
+        self.inputSpatialSize = None
+        self.input_mode = None
+        self.input_P = 0
+        self.input_order = None
+        self.input_site_of_row = None
+        self.input_site_start = None
+
+    def setNormalGuideScale(self, s):
+        self.normal_guide_scale = int(s)
+
+    # -- grids ---------------------------------------------------------------
+    def _build_grid(self, coords_dev, is_i64, ncols, shift, P):
+        lib = _lib_()
+        dev = coords_dev.device
+        tb = lib.scn_grid_build_temp_bytes(P)
+        temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        keys_sorted = torch.empty(P, dtype=torch.int64, device=dev)
+        order = torch.empty(P, dtype=torch.int32, device=dev)
+        site_of_row = torch.empty(P, dtype=torch.int32, device=dev)
+        site_start = torch.empty(P + 1, dtype=torch.int32, device=dev)
+        n = ctypes.c_int32(0)
+        check(lib.scn_grid_build(ptr(coords_dev), int(is_i64), ncols, shift, P, ptr(temp), tb,
+                                 ptr(keys_sorted), ptr(order), ptr(site_of_row), ptr(site_start),
+                                 ctypes.byref(n), stream()))
+        N = int(n.value)
+        site_coords = torch.empty((N, 4), dtype=torch.int32, device=dev)
+        site_keys = torch.empty(N, dtype=torch.int64, device=dev)
+        check(lib.scn_grid_finalize(ptr(coords_dev), int(is_i64), ncols, shift, P, N, ptr(keys_sorted),
+                                    ptr(order), ptr(site_start), ptr(site_coords), ptr(site_keys),
+                                    stream()))
+        return _Grid(N, site_coords, site_keys), order, site_of_row, site_start[:N + 1]
+
+    def _hash(self, g):
+        if g.hash_keys is None:
+            lib = _lib_()
+            cap = lib.scn_hash_capacity(g.n)
+            g.hash_keys = torch.empty(cap, dtype=torch.int64, device=g.coords.device)
+            g.hash_vals = torch.empty(cap, dtype=torch.int32, device=g.coords.device)
+            g.hash_cap = cap
+            check(lib.scn_hash_build(ptr(g.keys), g.n, ptr(g.hash_keys), ptr(g.hash_vals), cap, stream()))
+        return g
+
+    def inputLayer(self, spatialSize, coords, batchSize, mode, device):
+        """Metadata::inputLayer (sparseconvnet/SCN/Metadata/Metadata.cpp:424-446) ->
+        inputLayerRulesSimple (sparseconvnet/SCN/Metadata/IOLayersRules.h:135-202)."""
+        if mode not in (3, 4):
+            raise NotImplementedError("InputLayer: the reference GPU path supports mode 3 and 4 only "
+                                      "(sparseconvnet/SCN/Metadata/IOLayersRules.h:141)")
+        assert coords.dim() == 2 and coords.size(1) in (3, 4)
+        assert coords.dtype == torch.int64
+        self.clear()
+        self.device = device
+        key = _size_key(spatialSize)
+        self.inputSpatialSize = key
+        c = coords.to(device, non_blocking=True).contiguous()
+        P = c.size(0)
+        g, order, site_of_row, site_start = self._build_grid(c, True, c.size(1), 0, P)
+        self.grids[key] = g
+        self.nActive[key] = g.n
+        self.input_mode = int(mode)
+        self.input_P = P
+        self.input_order, self.input_site_of_row, self.input_site_start = order, site_of_row, site_start
+
+    def getNActive(self, spatialSize):
+        return self.nActive[_size_key(spatialSize)]
+
+    def getSpatialLocations(self, spatialSize):
+        """LongTensor [N,4] = (x,y,z,batch) in site order (sparseconvnet/SCN/Metadata/Metadata.cpp:722-749)."""
+        return self.grids[_size_key(spatialSize)].coords.cpu().to(torch.int64)
+
+    # -- rulebooks -----------------------------------------------------------
+    def _tile_bases(self, rb, out_col, n_out):
+        lib = _lib_()
+        n_gran = (n_out + GRANULE - 1) // GRANULE
+        bases = torch.empty((rb.K, n_gran + 1), dtype=torch.int32, device=rb.rules.device)
+        check(lib.scn_tile_bases(ptr(rb.rules), ptr(rb.counts), rb.K, rb.stride, out_col, n_out,
+                                 ptr(bases), stream()))
+        rb.bases[out_col] = bases
+        rb.n_rows[out_col] = n_out
+
+    def getSubmanifoldRuleBook(self, spatialSize, filterSize, dilated_rate=1):
+        """cache key (spatialSize, filterSize) as sparseconvnet/SCN/Metadata/Metadata.cpp:504-529"""
+        fs = _size_key(filterSize)
+        if fs != (3, 3, 3):
+            raise NotImplementedError("SubmanifoldConvolution: the reference GPU rule builder aborts unless "
+                                      "filter_size == 3 (sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cpp:40-44)")
+        if int(dilated_rate) != 1:
+            raise NotImplementedError("SubmanifoldConvolution: dilated_rate must be 1 (the reference GPU "
+                                      "builder ignores it, SubmanifoldConvolutionRules.h:248-275)")
+        key = _size_key(spatialSize) + fs
+        rb = self.submanifoldRuleBooks.get(key)
+        if rb is None:
+            lib = _lib_()
+            g = self._hash(self.grids[_size_key(spatialSize)])
+            dev = g.coords.device
+            N = g.n
+            nbr = torch.empty((27, N), dtype=torch.int32, device=dev)
+            rules = torch.empty((27, N, 2), dtype=torch.int32, device=dev)
+            counts = torch.empty(27, dtype=torch.int32, device=dev)
+            tb = lib.scn_rules_temp_bytes(N, 27)
+            temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+            check(lib.scn_submanifold_rules(ptr(g.coords), N, ptr(g.hash_keys), ptr(g.hash_vals), g.hash_cap,
+                                            ptr(nbr), ptr(rules), ptr(counts), ptr(temp), tb, stream()))
+            rb = _RuleBook(27, N, rules, counts)
+            rb.nbr = nbr
+            self._tile_bases(rb, 1, N)
+            rb.total_pairs = int(counts.sum().item())
+            self.submanifoldRuleBooks[key] = rb
+        return rb
+
+    def getRuleBook(self, inputSpatialSize, outputSpatialSize, size, stride):
+        """Metadata::getRuleBook (sparseconvnet/SCN/Metadata/Metadata.cpp:598-625): builds the coarse
+        grid as a side effect and sets nActive[outputSpatialSize]."""
+        fs, st = _size_key(size), _size_key(stride)
+        if fs != (2, 2, 2) or st != (2, 2, 2):
+            raise NotImplementedError("Convolution/Deconvolution: the reference GPU path asserts size == stride == 2 "
+                                      "(sparseconvnet/SCN/Metadata/ConvolutionRules.h:353-358)")
+        iS, oS = _size_key(inputSpatialSize), _size_key(outputSpatialSize)
+        key = iS + fs + st
+        rb = self.ruleBooks.get(key)
+        if rb is None:
+            lib = _lib_()
+            fine = self.grids[iS]
+            dev = fine.coords.device
+            Nf = fine.n
+            coarse, _order, coarse_of_fine, _start = self._build_grid(fine.coords, False, 4, 1, Nf)
+            self.grids[oS] = coarse
+            self.nActive[oS] = coarse.n
+            rules = torch.empty((8, Nf, 2), dtype=torch.int32, device=dev)
+            counts = torch.empty(8, dtype=torch.int32, device=dev)
+            tb = lib.scn_rules_temp_bytes(Nf, 8)
+            temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+            check(lib.scn_strided_rules(ptr(fine.coords), Nf, ptr(coarse_of_fine), ptr(rules), ptr(counts),
+                                        ptr(temp), tb, stream()))
+            rb = _RuleBook(8, Nf, rules, counts)
+            self._tile_bases(rb, 1, coarse.n)  # lists are also ascending in the coarse id
+            self._tile_bases(rb, 0, Nf)
+            rb.total_pairs = Nf  # every fine site appears in exactly one list
+            self.ruleBooks[key] = rb
+        return rb
+
+    # -- host views for tests / tooling ---------------------------------------
+    def getInputRulesHost(self):
+        """reference-format input rulebook: (header [mode,maxActive,P,N], table [N,1+maxActive])"""
+        lib = _lib_()
+        N = self.nActive[self.inputSpatialSize]
+        scratch = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ma = ctypes.c_int32(0)
+        check(lib.scn_input_rules_max_active(ptr(self.input_site_start), N, ptr(scratch), ctypes.byref(ma), stream()))
+        table = torch.empty((N, 1 + ma.value), dtype=torch.int32, device=self.device)
+        check(lib.scn_input_rules_table(ptr(self.input_order), ptr(self.input_site_start), N, ma.value,
+                                        ptr(table), stream()))
+        header = np.array([self.input_mode, ma.value, self.input_P, N], np.int32)
+        return header, table.cpu().numpy()
+
+
+# ----------------------------------------------------------------- helpers ---
+def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out):
+    lib = _lib_()
+    K, Ci, Co = weight.shape
+    assert K == rb.K, (K, rb.K)
+    assert inp.is_contiguous() and weight.is_contiguous()
+    out.resize_(n_out, Co)
+    check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), ptr(bias) if bias is not None and bias.numel() else None,
+                               ptr(rb.rules), ptr(rb.bases[out_col]), K, rb.stride, in_col, out_col, n_out,
+                               Ci, Co, stream()))
+
+
+def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse):
+    """d_in = conv(d_out, W^T) with the two columns swapped; dW; d_bias."""
+    lib = _lib_()
+    K, Ci, Co = weight.shape
+    d_out = d_out.contiguous()
+    if d_in is not None:
+        wt = torch.empty((K, Co, Ci), dtype=weight.dtype, device=weight.device)
+        check(lib.scn_weight_transpose(ptr(weight), ptr(wt), K, Ci, Co, int(reverse), stream()))
+        if reverse:
+            # submanifold: dIn[i] = sum_k' dOut[nbr(i,k')] . W[26-k']^T over the SAME lists (rules are
+            # symmetric: (i,o) in list k <=> (o,i) in list 26-k), so columns keep their roles
+            _conv(d_out, d_in, wt, None, rb, in_col, out_col, n_in)
+        else:
+            _conv(d_out, d_in, wt, None, rb, out_col, in_col, n_in)
+    if d_weight is not None and d_weight.numel():
+        check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts), K,
+                                   rb.stride, in_col, out_col, Ci, Co, stream()))
+    if d_bias is not None and d_bias.numel():
+        check(lib.scn_column_sum(ptr(d_out), ptr(d_bias), d_out.size(0), Co, stream()))
+
+
+# ---------------------------------------------------- boundary functions ---
+def n_rulebook_bits():
+    return 32
+
+
+def InputLayer_updateOutput(m, spatialSize, input_coords, input_features, output_features, batchSize, mode,
+                            input_normal=None):
+    """sparseconvnet/SCN/pybind.cpp:158-162 -> sparseconvnet/SCN/CUDA/IOLayers.cpp:17-80"""
+    _need_cuda(input_features, "InputLayer_updateOutput")
+    m.inputLayer(spatialSize, input_coords, batchSize, mode, input_features.device)
+    if input_normal is not None and torch.is_tensor(input_normal) and input_normal.dim() == 2 \
+            and input_normal.size(0) == input_features.size(0):
+        raise NotImplementedError("normal-guided filters (use_normal) are out of scope (SURVEY.md section 2 row 30)")
+    N = m.nActive[m.inputSpatialSize]
+    C = input_features.size(1)
+    output_features.resize_(N, C)
+    check(_lib_().scn_input_forward(ptr(input_features.contiguous()), ptr(output_features), ptr(m.input_order),
+                                    ptr(m.input_site_start), N, C, int(mode == 4), stream()))
+
+
+def InputLayer_updateGradInput(m, d_input_features, d_output_features):
+    """sparseconvnet/SCN/CUDA/IOLayers.cpp:81-106"""
+    _need_cuda(d_output_features, "InputLayer_updateGradInput")
+    C = d_output_features.size(1)
+    d_input_features.resize_(m.input_P, C)
+    check(_lib_().scn_input_backward(ptr(d_input_features), ptr(d_output_features.contiguous()),
+                                     ptr(m.input_site_of_row), ptr(m.input_site_start), m.input_P, C,
+                                     int(m.input_mode == 4), stream()))
+
+
+def OutputLayer_updateOutput(m, input_features, output_features):
+    """sparseconvnet/SCN/CUDA/IOLayers.cpp:108-129: every original point gets its site's row"""
+    _need_cuda(input_features, "OutputLayer_updateOutput")
+    C = input_features.size(1)
+    output_features.resize_(m.input_P, C)
+    check(_lib_().scn_output_forward(ptr(input_features.contiguous()), ptr(output_features),
+                                     ptr(m.input_site_of_row), m.input_P, C, stream()))
+
+
+def OutputLayer_updateGradInput(m, d_input_features, d_output_features):
+    """sparseconvnet/SCN/CUDA/IOLayers.cpp:131-154"""
+    _need_cuda(d_output_features, "OutputLayer_updateGradInput")
+    C = d_output_features.size(1)
+    N = m.nActive[m.inputSpatialSize]
+    d_input_features.resize_(N, C)
+    check(_lib_().scn_output_backward(ptr(d_input_features), ptr(d_output_features.contiguous()),
+                                      ptr(m.input_order), ptr(m.input_site_start), N, C, stream()))
+
+
+def SubmanifoldConvolution_updateOutput(spatialSize, filterSize, m, input_features, output_features, weight,
+                                        bias, dilated_rate=1):
+    """sparseconvnet/SCN/pybind.cpp:138-142 -> sparseconvnet/SCN/CUDA/Convolution.cpp:105-162.
+    Returns the multiply-add count sum_k R_k*Ci*Co (the reference returns 0 on
+    its chunk path, sparseconvnet/SCN/CUDA/Convolution.cu:1286,1374 -- treated as a bug)."""
+    _need_cuda(input_features, "SubmanifoldConvolution_updateOutput")
+    rb = m.getSubmanifoldRuleBook(spatialSize, filterSize, dilated_rate)
+    n = m.getNActive(spatialSize)
+    _conv(input_features.contiguous(), output_features, weight, bias, rb, 0, 1, n)
+    return float(rb.total_pairs) * weight.size(1) * weight.size(2)
+
+
+def SubmanifoldConvolution_backward(spatialSize, filterSize, m, input_features, d_input_features,
+                                    d_output_features, weight, d_weight, d_bias, dilated_rate=1):
+    """sparseconvnet/SCN/pybind.cpp:143-147 -> sparseconvnet/SCN/CUDA/Convolution.cpp:165-210.
+    d_input_features may be None to skip the dInput half."""
+    _need_cuda(d_output_features, "SubmanifoldConvolution_backward")
+    rb = m.getSubmanifoldRuleBook(spatialSize, filterSize, dilated_rate)
+    n = m.getNActive(spatialSize)
+    _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight, d_weight, d_bias,
+                   rb, 0, 1, n, reverse=True)
+
+
+def Convolution_updateOutput(inputSize, outputSize, filterSize, filterStride, m, input_features,
+                             output_features, weight, bias):
+    """sparseconvnet/SCN/pybind.cpp:58-63 -> sparseconvnet/SCN/CUDA/Convolution.cpp:36-66"""
+    _need_cuda(input_features, "Convolution_updateOutput")
+    rb = m.getRuleBook(inputSize, outputSize, filterSize, filterStride)
+    n_out = m.getNActive(outputSize)
+    _conv(input_features.contiguous(), output_features, weight, bias, rb, 0, 1, n_out)
+    return float(rb.total_pairs) * weight.size(1) * weight.size(2)
+
+
+def Convolution_backward(inputSize, outputSize, filterSize, filterStride, m, input_features, d_input_features,
+                         d_output_features, weight, d_weight, d_bias):
+    """sparseconvnet/SCN/pybind.cpp:64-69 -> sparseconvnet/SCN/CUDA/Convolution.cpp:69-102"""
+    _need_cuda(d_output_features, "Convolution_backward")
+    rb = m.getRuleBook(inputSize, outputSize, filterSize, filterStride)
+    n_in = m.getNActive(inputSize)
+    _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight, d_weight, d_bias,
+                   rb, 0, 1, n_in, reverse=False)
+
+
+def Deconvolution_updateOutput(inputSize, outputSize, filterSize, filterStride, m, input_features,
+                               output_features, weight, bias):
+    """sparseconvnet/SCN/pybind.cpp:82-87 -> sparseconvnet/SCN/CUDA/Deconvolution.cpp:20-49: the conv rulebook
+    of (outputSize -> inputSize) with the columns swapped."""
+    _need_cuda(input_features, "Deconvolution_updateOutput")
+    rb = m.getRuleBook(outputSize, inputSize, filterSize, filterStride)
+    n_out = m.getNActive(outputSize)
+    _conv(input_features.contiguous(), output_features, weight, bias, rb, 1, 0, n_out)
+    return float(rb.total_pairs) * weight.size(1) * weight.size(2)
+
+
+def Deconvolution_backward(inputSize, outputSize, filterSize, filterStride, m, input_features,
+                           d_input_features, d_output_features, weight, d_weight, d_bias):
+    """sparseconvnet/SCN/pybind.cpp:88-93 -> sparseconvnet/SCN/CUDA/Deconvolution.cpp:52-84"""
+    _need_cuda(d_output_features, "Deconvolution_backward")
+    rb = m.getRuleBook(outputSize, inputSize, filterSize, filterStride)
+    n_in = m.getNActive(inputSize)
+    _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight, d_weight, d_bias,
+                   rb, 1, 0, n_in, reverse=False)
+
+
+def _bn_temp(C, device):
+    tb = _lib_().scn_bn_temp_bytes(C)
+    return torch.empty(tb, dtype=torch.uint8, device=device)
+
+
+def BatchNormalization_updateOutput(input_features, output_features, saveMean, saveInvStd, runningMean,
+                                    runningVar, weight, bias, eps, momentum, train, leakiness):
+    """sparseconvnet/SCN/sparseconvnet.h:21-26 -> sparseconvnet/SCN/CUDA/BatchNormalization.cpp:21-42"""
+    _need_cuda(input_features, "BatchNormalization_updateOutput")
+    x = input_features.contiguous()
+    N, C = x.shape
+    output_features.resize_(N, C)
+    saveMean.resize_(C)
+    saveInvStd.resize_(C)
+    temp = _bn_temp(C, x.device)
+    check(_lib_().scn_bn_forward(ptr(x), ptr(output_features), ptr(saveMean), ptr(saveInvStd), ptr(runningMean),
+                                 ptr(runningVar), ptr(weight), ptr(bias), float(eps), float(momentum), int(train),
+                                 float(leakiness), N, C, ptr(temp), stream()))
+
+
+def BatchNormalization_backward(input_features, d_input_features, output_features, d_output_features, saveMean,
+                                saveInvStd, runningMean, runningVar, weight, bias, d_weight, d_bias, leakiness):
+    """sparseconvnet/SCN/sparseconvnet.h:27-32 -> sparseconvnet/SCN/CUDA/BatchNormalization.cpp:45-76.
+    d_output_features must be contiguous: it is rewritten in place
+    (sparseconvnet/SCN/CUDA/BatchNormalization.cu:151-153)."""
+    _need_cuda(d_output_features, "BatchNormalization_backward")
+    assert d_output_features.is_contiguous()
+    x = input_features.contiguous()
+    N, C = x.shape
+    d_input_features.resize_(N, C)
+    temp = _bn_temp(C, x.device)
+    check(_lib_().scn_bn_backward(ptr(x), ptr(d_input_features), ptr(output_features), ptr(d_output_features),
+                                  ptr(saveMean), ptr(saveInvStd), ptr(weight), ptr(d_weight), ptr(d_bias),
+                                  float(leakiness), N, C, ptr(temp), stream()))
+
+
+def NetworkInNetwork_updateOutput(input_features, output_features, weight, bias):
+    """sparseconvnet/SCN/CUDA/NetworkInNetwork.cpp:9-25: a plain library GEMM (rocBLAS through torch),
+    exactly as the reference calls cuBLAS through ATen."""
+    n = input_features.size(0)
+    output_features.resize_(n, weight.size(1))
+    if bias is not None and bias.numel():
+        output_features.copy_(bias.expand_as(output_features))
+        if n:
+            output_features.addmm_(input_features, weight)
+    elif n:
+        torch.mm(input_features, weight, out=output_features)
+    return float(n) * weight.size(0) * weight.size(1)
+
+
+def NetworkInNetwork_updateGradInput(d_input_features, d_output_features, weight):
+    """sparseconvnet/SCN/CUDA/NetworkInNetwork.cpp:27-37"""
+    n = d_output_features.size(0)
+    d_input_features.resize_(n, weight.size(0))
+    if n:
+        torch.mm(d_output_features, weight.t(), out=d_input_features)
+
+
+def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weight, d_bias):
+    """sparseconvnet/SCN/CUDA/NetworkInNetwork.cpp:39-50"""
+    n = input_features.size(0)
+    if n and d_bias is not None and d_bias.numel():
+        torch.sum(d_output_features, 0, out=d_bias)
+    if n:
+        torch.mm(input_features.t(), d_output_features, out=d_weight)
+
+
+def _not_in_scope(name):
+    def f(*a, **k):
+        raise NotImplementedError("sparseconvnet.SCN.%s is outside the hot path this backend provides "
+                                  "(SURVEY.md section 8)" % name)
+    f.__name__ = name
+    return f
+
+
+for _n in ("ResolutionBasedScattering", "ActivePooling_updateOutput", "ActivePooling_updateGradInput",
+           "AveragePooling_updateOutput", "AveragePooling_updateGradInput", "MaxPooling_updateOutput",
+           "MaxPooling_updateGradInput", "SparseToDense_updateOutput", "SparseToDense_updateGradInput",
+           "FullConvolution_updateOutput", "FullConvolution_backward", "RandomizedStrideConvolution_updateOutput",
+           "RandomizedStrideConvolution_backward", "RandomizedStrideMaxPooling_updateOutput",
+           "RandomizedStrideMaxPooling_updateGradInput", "PermutohedralSubmanifoldConvolution_updateOutput",
+           "PermutohedralSubmanifoldConvolution_backward", "BLInputLayer_updateOutput",
+           "BLInputLayer_updateGradInput", "BLOutputLayer_updateOutput", "BLOutputLayer_updateGradInput",
+           "UnPooling_updateOutput", "UnPooling_updateGradInput", "AffineReluTrivialConvolution_updateOutput",
+           "AffineReluTrivialConvolution_backward", "BatchwiseMultiplicativeDropout_updateOutput",
+           "BatchwiseMultiplicativeDropout_updateGradInput", "LeakyReLU_updateOutput", "LeakyReLU_updateGradInput"):
+    globals()[_n] = _not_in_scope(_n)

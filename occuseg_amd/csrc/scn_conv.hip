@@ -1,0 +1,332 @@
+// gather -> small GEMM -> scatter over a device rulebook (gfx950, fp32 MFMA).
+//
+// One output-stationary kernel serves submanifold conv, strided conv,
+// deconvolution and (with transposed weights) every dInput:
+//   * a workgroup owns M consecutive OUTPUT rows x COB output planes, kept in LDS;
+//   * because every rulebook list is sorted on its output column, the pairs of
+//     list k that land in the tile are one contiguous segment [bases[k][g0], bases[k][g1]);
+//   * per (k, Ci-chunk) the segment's input rows are gathered with 16-byte
+//     coalesced loads into an LDS tile, each wave multiplies 16-pair groups by its
+//     16-plane slice of W[k] with v_mfma_f32_16x16x4_f32 (weights live in registers
+//     as the B operand) and adds the 16x16 result into the LDS output tile;
+//   * each output element is owned by one wave and visited in (k, pair) order:
+//     no global atomics, results are bitwise reproducible; every output row is
+//     written to HBM exactly once.
+// The reference instead stages 16x16 tiles for CUDA-core FMAs and scatters with
+// global atomicAdd (sparseconvnet/SCN/CUDA/Convolution.cu:1059-1152).
+//
+// dW[k] = In^T . dOut over the pairs of list k: split-K over pair chunks, both
+// row sets staged in LDS, 16x16x4 MFMA with the pair index as the K dimension,
+// float atomics into dW (as the reference, sparseconvnet/SCN/CUDA/Convolution.cu:749).
+#include "scn_common.h"
+
+namespace scn {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int KMAX = 27;
+
+// ---------------------------------------------------------------- forward ---
+template <int NW, int COS, int M, int CK>
+__global__ void __launch_bounds__(64 * NW)
+    k_conv_tile(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
+                const float *__restrict__ bias, const int2 *__restrict__ rules,
+                const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                int64_t n_out, int n_gran, int Ci, int Co) {
+  constexpr int COB = NW * COS * 16;
+  constexpr int NT = 64 * NW;
+  constexpr int AS = CK + 4;   // a_tile row stride (floats): conflict-free ds_read_b128 across 16 rows
+  constexpr int OS = COB + 4;  // o_tile row stride
+  __shared__ __attribute__((aligned(16))) float a_tile[M * AS];
+  __shared__ __attribute__((aligned(16))) float o_tile[M * OS];
+  __shared__ int ol[M];
+  __shared__ int seg[KMAX + 1][2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int64_t o0 = (int64_t)blockIdx.x * M;
+  const int co0 = blockIdx.y * COB;
+  const int g0 = blockIdx.x * (M / SCN_TILE_GRANULE);
+  const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
+
+  for (int i = tid; i < M * COB; i += NT) {
+    const int r = i / COB, c = i % COB;
+    o_tile[r * OS + c] = bias ? bias[co0 + c] : 0.f;
+  }
+  if (tid < K) {
+    seg[tid][0] = bases[(int64_t)tid * (n_gran + 1) + g0];
+    seg[tid][1] = bases[(int64_t)tid * (n_gran + 1) + g1];
+  }
+  __syncthreads();
+
+  const int li = lane & 15;  // A row / B column / D column inside a 16x16 tile
+  const int lq = lane >> 4;  // k-quad of the A/B operands, row-quad of D
+
+  for (int k = 0; k < K; ++k) {
+    const int s = seg[k][0];
+    const int c = seg[k][1] - s;
+    if (c <= 0) continue;
+    const int2 *rk = rules + (int64_t)k * stride + s;
+    const int ngroups = (c + 15) >> 4;
+    for (int c0 = 0; c0 < Ci; c0 += CK) {
+      const int ck = min(CK, Ci - c0);  // multiple of 16
+      const int ch_per_row = ck >> 2;
+      __syncthreads();  // previous phase finished reading a_tile / ol
+      for (int idx = tid; idx < c * ch_per_row; idx += NT) {
+        const int row = idx / ch_per_row, ch = idx - row * ch_per_row;
+        const int2 p = rk[row];
+        const int src = in_col ? p.y : p.x;
+        const float4 v = *(const float4 *)(in + (int64_t)src * Ci + c0 + ch * 4);
+        *(float4 *)(a_tile + row * AS + ch * 4) = v;
+        if (c0 == 0 && ch == 0) ol[row] = (int)((in_col ? p.x : p.y) - o0);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < COS; ++q) {
+        const int cw = (w * COS + q) * 16;  // plane offset inside the block's COB
+        // B operand: lane holds W[k][c0 + 16 s' + 4 lq + e][co0 + cw + li]
+        float breg[CK / 4];
+        const float *wp = W + ((int64_t)k * Ci + c0 + 4 * lq) * Co + co0 + cw + li;
+#pragma unroll
+        for (int sp = 0; sp < CK / 16; ++sp)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            breg[sp * 4 + e] = (sp * 16 < ck) ? wp[(int64_t)(sp * 16 + e) * Co] : 0.f;
+        for (int g = 0; g < ngroups; ++g) {
+          floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+          const float *ap = a_tile + (g * 16 + li) * AS + 4 * lq;
+#pragma unroll
+          for (int sp = 0; sp < CK / 16; ++sp) {
+            if (sp * 16 < ck) {
+              const float4 a4 = *(const float4 *)(ap + sp * 16);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, breg[sp * 4 + 0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, breg[sp * 4 + 1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, breg[sp * 4 + 2], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, breg[sp * 4 + 3], acc, 0, 0, 0);
+            }
+          }
+          // D: lane holds rows (pairs) g*16 + 4 lq + r, column li
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = g * 16 + 4 * lq + r;
+            if (row < c) o_tile[ol[row] * OS + cw + li] += acc[r];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int rows = (int)min((int64_t)M, n_out - o0);
+  for (int i = tid; i < rows * (COB / 4); i += NT) {
+    const int r = i / (COB / 4), c4 = i % (COB / 4);
+    *(float4 *)(out + (o0 + r) * Co + co0 + c4 * 4) = *(const float4 *)(o_tile + r * OS + c4 * 4);
+  }
+}
+
+// generic fallback (any Ci, Co; scalar FMA): 32 output rows x 64 planes per block
+__global__ void __launch_bounds__(256)
+    k_conv_generic(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
+                   const float *__restrict__ bias, const int2 *__restrict__ rules,
+                   const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                   int64_t n_out, int n_gran, int Ci, int Co) {
+  constexpr int M = SCN_TILE_GRANULE;
+  __shared__ float o_tile[M][65];
+  const int tid = threadIdx.x;
+  const int64_t o0 = (int64_t)blockIdx.x * M;
+  const int co = blockIdx.y * 64 + (tid & 63);
+  const int pj = tid >> 6;  // 4 pairs in flight
+  for (int i = tid; i < M * 64; i += 256) o_tile[i >> 6][i & 63] = (bias && co < Co) ? bias[co] : 0.f;
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    const int s = bases[(int64_t)k * (n_gran + 1) + blockIdx.x];
+    const int e = bases[(int64_t)k * (n_gran + 1) + blockIdx.x + 1];
+    const int2 *rk = rules + (int64_t)k * stride;
+    if (co < Co)
+      for (int j = s + pj; j < e; j += 4) {
+        const int2 p = rk[j];
+        const int src = in_col ? p.y : p.x;
+        const int dst = (int)((in_col ? p.x : p.y) - o0);
+        const float *ip = in + (int64_t)src * Ci;
+        const float *wp = W + (int64_t)k * Ci * Co + co;
+        float acc = 0.f;
+        for (int ci = 0; ci < Ci; ++ci) acc += ip[ci] * wp[(int64_t)ci * Co];
+        o_tile[dst][tid & 63] += acc;  // one pair per output row inside a list: no race
+      }
+    __syncthreads();
+  }
+  const int rows = (int)min((int64_t)M, n_out - o0);
+  if (co < Co)
+    for (int r = pj; r < rows; r += 4) out[(o0 + r) * Co + co] = o_tile[r][tid & 63];
+}
+
+// ---------------------------------------------------------------- dWeight ---
+// block: 4 waves as 2x2; wave owns TI x TJ 16x16 tiles; block tile CIB x COB.
+template <int TI, int TJ>
+__global__ void __launch_bounds__(256)
+    k_dw_tile(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+              const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
+              int in_col, int Ci, int Co, int chunk) {
+  constexpr int CIB = 32 * TI, COB = 32 * TJ;
+  constexpr int IS = CIB + 16, DS = COB + 16;  // row strides: (stride % 32) == 16 -> ds_read_b32 conflict-free
+  constexpr int PS = 32;                       // pairs per staged step
+  __shared__ __attribute__((aligned(16))) float in_t[PS * IS];
+  __shared__ __attribute__((aligned(16))) float do_t[PS * DS];
+  const int k = blockIdx.y;
+  const int count = counts[k];
+  const int p0 = blockIdx.x * chunk;
+  if (p0 >= count) return;
+  const int p1 = min(count, p0 + chunk);
+  const int nci = Ci / CIB;
+  const int ci0 = (blockIdx.z % nci) * CIB, co0 = (blockIdx.z / nci) * COB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = w & 1, wj = w >> 1;
+  const int li = lane & 15, lq = lane >> 4;
+  const int2 *rk = rules + (int64_t)k * stride;
+
+  floatx4 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  for (int pb = p0; pb < p1; pb += PS) {
+    __syncthreads();
+    // stage 32 pairs: in rows [32 x CIB], dout rows [32 x COB]; zero rows past the end
+    for (int idx = tid; idx < PS * (CIB / 4); idx += 256) {
+      const int row = idx / (CIB / 4), ch = idx % (CIB / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pb + row < p1) {
+        const int2 p = rk[pb + row];
+        v = *(const float4 *)(in + (int64_t)(in_col ? p.y : p.x) * Ci + ci0 + ch * 4);
+      }
+      *(float4 *)(in_t + row * IS + ch * 4) = v;
+    }
+    for (int idx = tid; idx < PS * (COB / 4); idx += 256) {
+      const int row = idx / (COB / 4), ch = idx % (COB / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pb + row < p1) {
+        const int2 p = rk[pb + row];
+        v = *(const float4 *)(dout + (int64_t)(in_col ? p.x : p.y) * Co + co0 + ch * 4);
+      }
+      *(float4 *)(do_t + row * DS + ch * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PS / 4; ++ps) {
+      float a[TI], b[TJ];
+      // A[i = ci][k = pair]: lane (li, lq) <- in_t[4 ps + lq][ci]; B[k = pair][j = co] <- do_t[4 ps + lq][co]
+#pragma unroll
+      for (int t = 0; t < TI; ++t) a[t] = in_t[(4 * ps + lq) * IS + (wi * TI + t) * 16 + li];
+#pragma unroll
+      for (int t = 0; t < TJ; ++t) b[t] = do_t[(4 * ps + lq) * DS + (wj * TJ + t) * 16 + li];
+#pragma unroll
+      for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TJ; ++tb)
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+  }
+  // D[row = ci][col = co]: lane holds rows 4 lq + r, column li
+#pragma unroll
+  for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < TJ; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + (wi * TI + ta) * 16 + 4 * lq + r;
+        const int co = co0 + (wj * TJ + tb) * 16 + li;
+        unsafeAtomicAdd(dW + ((int64_t)k * Ci + ci) * Co + co, acc[ta][tb][r]);
+      }
+}
+
+// generic dW (any Ci, Co): block = (pair chunk, k); threads stride over (ci, co)
+__global__ void __launch_bounds__(256)
+    k_dw_generic(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+                 const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
+                 int in_col, int Ci, int Co, int chunk) {
+  const int k = blockIdx.y;
+  const int count = counts[k];
+  const int p0 = blockIdx.x * chunk;
+  if (p0 >= count) return;
+  const int p1 = min(count, p0 + chunk);
+  const int2 *rk = rules + (int64_t)k * stride;
+  for (int e = threadIdx.x; e < Ci * Co; e += 256) {
+    const int ci = e / Co, co = e % Co;
+    float acc = 0.f;
+    for (int p = p0; p < p1; ++p) {
+      const int2 pr = rk[p];
+      acc += in[(int64_t)(in_col ? pr.y : pr.x) * Ci + ci] * dout[(int64_t)(in_col ? pr.x : pr.y) * Co + co];
+    }
+    unsafeAtomicAdd(dW + ((int64_t)k * Ci + ci) * Co + co, acc);
+  }
+}
+
+}  // namespace scn
+using namespace scn;
+
+template <int NW, int COS, int M, int CK>
+static int launch_tile(const float *in, float *out, const float *W, const float *bias,
+                       const int32_t *rules, const int32_t *bases, int K, int64_t stride,
+                       int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
+  const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+  dim3 grid((unsigned)((n_out + M - 1) / M), (unsigned)(Co / (NW * COS * 16)));
+  k_conv_tile<NW, COS, M, CK><<<grid, 64 * NW, 0, stream>>>(in, out, W, bias, (const int2 *)rules, bases,
+                                                          K, stride, in_col, n_out, n_gran, Ci, Co);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" {
+
+int scn_conv_forward(const float *in, float *out, const float *W, const float *bias,
+                     const int32_t *rules, const int32_t *bases, int K, int64_t stride,
+                     int in_col, int out_col, int64_t n_out, int Ci, int Co, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_forward: filter volume must be 1..27");
+  SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_forward: in_col/out_col must be 0/1 or 1/0");
+  SCN_REQUIRE(Ci > 0 && Co > 0, "scn_conv_forward: bad plane counts");
+  if (n_out <= 0) return 0;
+  if (Ci % 16 == 0 && Co % 16 == 0) {
+    const int s16 = Co / 16;
+    if (s16 % 4 == 0) return launch_tile<4, 1, 64, 64>(in, out, W, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    if (s16 % 3 == 0) return launch_tile<3, 1, 64, 64>(in, out, W, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    if (s16 % 2 == 0) return launch_tile<2, 1, 64, 64>(in, out, W, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    return launch_tile<1, 1, 64, 64>(in, out, W, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+  }
+  const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+  dim3 grid((unsigned)n_gran, (unsigned)((Co + 63) / 64));
+  k_conv_generic<<<grid, 256, 0, stream>>>(in, out, W, bias, (const int2 *)rules, bases, K, stride, in_col,
+                                          n_out, n_gran, Ci, Co);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
+                     const int32_t *counts, int K, int64_t stride, int in_col, int out_col,
+                     int Ci, int Co, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_dweight: filter volume must be 1..27");
+  SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_dweight: in_col/out_col must be 0/1 or 1/0");
+  if (stride <= 0) return 0;
+  if (Ci % 32 == 0 && Co % 32 == 0) {
+    const int chunk = 1024;
+    const unsigned gx = (unsigned)((stride + chunk - 1) / chunk);
+    if (Ci % 64 == 0 && Co % 64 == 0) {
+      dim3 grid(gx, K, (Ci / 64) * (Co / 64));
+      k_dw_tile<2, 2><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+    } else {
+      dim3 grid(gx, K, (Ci / 32) * (Co / 32));
+      k_dw_tile<1, 1><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+    }
+    SCN_CHECK_LAUNCH();
+    return 0;
+  }
+  const int chunk = 256;
+  dim3 grid((unsigned)((stride + chunk - 1) / chunk), K);
+  k_dw_generic<<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+// Dense [rows, planes] kernels of the hot path: batch norm over active sites,
+// input/output layers, column sums, weight transposition (gfx950).
+//
+// All of these are HBM-bound streaming passes: rows are walked with 16-byte
+// loads along the plane dimension (coalesced), reductions over rows are
+// per-thread registers -> LDS -> per-block partial -> fp64 finalize, so every
+// CU takes part (the reference's BN kernels run on at most 16 blocks,
+// sparseconvnet/SCN/CUDA/BatchNormalization.cu:110-114).
+#include "scn_common.h"
+
+namespace scn {
+
+constexpr int BN_MAX_BLOCKS = 1024;
+
+// Reduce column sums of two per-row quantities over a block's row range.
+// Thread (cg, slot): column group cg (VEC planes), row slot; rows strided by nslots.
+template <int VEC, class F>
+__device__ __forceinline__ void bn_reduce_rows(int64_t N, int C, float *partial, F &&load2) {
+  // partial layout: [gridDim.x][2][C]
+  __shared__ float red[2][256 * 4];
+  const int cg_total = C / VEC;
+  const int cgb = min(cg_total, 256);
+  const int nslots = 256 / cgb;
+  const int cg = blockIdx.y * cgb + (threadIdx.x % cgb);
+  const int slot = threadIdx.x / cgb;
+  const bool active = slot < nslots && cg < cg_total;
+  float a[VEC], b[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) a[v] = b[v] = 0.f;
+  const int64_t rows_per_blk = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = min(N, r0 + rows_per_blk);
+  if (active)
+    for (int64_t r = r0 + slot; r < r1; r += nslots) load2(r, cg * VEC, a, b);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    red[0][threadIdx.x * VEC + v] = a[v];
+    red[1][threadIdx.x * VEC + v] = b[v];
+  }
+  __syncthreads();
+  if (slot == 0 && cg < cg_total) {
+    for (int s = 1; s < nslots; ++s)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        a[v] += red[0][(s * cgb + threadIdx.x) * VEC + v];
+        b[v] += red[1][(s * cgb + threadIdx.x) * VEC + v];
+      }
+    float *p = partial + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      p[cg * VEC + v] = a[v];
+      p[C + cg * VEC + v] = b[v];
+    }
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_bn_stats(const float *x, int64_t N, int C, float *partial) {
+  bn_reduce_rows<VEC>(N, C, partial, [&](int64_t r, int c, float *a, float *b) {
+    const float *px = x + r * C + c;
+    float v[VEC];
+    if (VEC == 4) {
+      const float4 t = *(const float4 *)px;
+      v[0] = t.x; v[1 % VEC] = t.y; v[2 % VEC] = t.z; v[3 % VEC] = t.w;
+    } else {
+      v[0] = px[0];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      a[i] += v[i];
+      b[i] += v[i] * v[i];
+    }
+  });
+}
+
+// arithmetic of sparseconvnet/SCN/CPU/BatchNormalization.cpp:19-52 with the row sums finished in fp64
+__global__ void k_bn_finalize(const float *partial, int nblk, int64_t N, int C, float *save_mean,
+                              float *save_invstd, float *running_mean, float *running_var,
+                              const float *weight, const float *bias, float eps, float momentum,
+                              int train, float *wb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, invstd;
+  if (train) {
+    double s = 0, ss = 0;
+    for (int b = 0; b < nblk; ++b) {
+      s += (double)partial[(int64_t)b * 2 * C + c];
+      ss += (double)partial[(int64_t)b * 2 * C + C + c];
+    }
+    const double m = s / (double)N;
+    const double var_n = ss - m * m * (double)N;  // "saveInvStd" before the rsqrt: sum of squared deviations
+    mean = (float)m;
+    running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * mean;
+    running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)(var_n / (double)(N - 1));
+    invstd = (float)(1.0 / sqrt(var_n / (double)N + (double)eps));
+  } else {
+    mean = running_mean[c];
+    invstd = powf(running_var[c] + eps, -0.5f);
+  }
+  save_mean[c] = mean;
+  save_invstd[c] = invstd;
+  const float w = invstd * (weight ? weight[c] : 1.f);
+  wb[c] = w;
+  wb[C + c] = -mean * w + (bias ? bias[c] : 0.f);
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    k_bn_apply(const float *x, float *y, int64_t total_vec, int C, const float *wb, float leak) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i * VEC) % C);
+    if (VEC == 4) {
+      const float4 v = ((const float4 *)x)[i];
+      const float4 w = *(const float4 *)(wb + c);
+      const float4 b = *(const float4 *)(wb + C + c);
+      float4 o;
+      o.x = v.x * w.x + b.x; o.y = v.y * w.y + b.y; o.z = v.z * w.z + b.z; o.w = v.w * w.w + b.w;
+      o.x = o.x > 0 ? o.x : o.x * leak; o.y = o.y > 0 ? o.y : o.y * leak;
+      o.z = o.z > 0 ? o.z : o.z * leak; o.w = o.w > 0 ? o.w : o.w * leak;
+      ((float4 *)y)[i] = o;
+    } else {
+      float o = x[i] * wb[c] + wb[C + c];
+      y[i] = o > 0 ? o : o * leak;
+    }
+  }
+}
+
+// backward pass 1: mask d_out in place, reduce sum(d) and sum((x-mean) d)
+// (sparseconvnet/SCN/CPU/BatchNormalization.cpp:75-87)
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    k_bn_bwd_stats(const float *x, const float *y, float *d_out, const float *save_mean, int64_t N,
+                   int C, float leak, float *partial) {
+  bn_reduce_rows<VEC>(N, C, partial, [&](int64_t r, int c, float *a, float *b) {
+    const int64_t o = r * C + c;
+    if (VEC == 4) {
+      const float4 xv = *(const float4 *)(x + o);
+      const float4 yv = *(const float4 *)(y + o);
+      float4 d = *(const float4 *)(d_out + o);
+      const float4 m = *(const float4 *)(save_mean + c);
+      d.x *= yv.x > 0 ? 1.f : leak; d.y *= yv.y > 0 ? 1.f : leak;
+      d.z *= yv.z > 0 ? 1.f : leak; d.w *= yv.w > 0 ? 1.f : leak;
+      *(float4 *)(d_out + o) = d;
+      a[0] += d.x; a[1 % VEC] += d.y; a[2 % VEC] += d.z; a[3 % VEC] += d.w;
+      b[0] += (xv.x - m.x) * d.x; b[1 % VEC] += (xv.y - m.y) * d.y;
+      b[2 % VEC] += (xv.z - m.z) * d.z; b[3 % VEC] += (xv.w - m.w) * d.w;
+    } else {
+      float d = d_out[o] * (y[o] > 0 ? 1.f : leak);
+      d_out[o] = d;
+      a[0] += d;
+      b[0] += (x[o] - save_mean[c]) * d;
+    }
+  });
+}
+
+// (sparseconvnet/SCN/CPU/BatchNormalization.cpp:88-93,:103-106); coef = [gradMean | k | invstd*gamma]
+__global__ void k_bn_bwd_finalize(const float *partial, int nblk, int64_t N, int C,
+                                  const float *save_invstd, const float *weight, float *d_weight,
+                                  float *d_bias, float *coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, dp = 0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)partial[(int64_t)b * 2 * C + c];
+    dp += (double)partial[(int64_t)b * 2 * C + C + c];
+  }
+  const float invstd = save_invstd[c];
+  if (d_bias) d_bias[c] = (float)s;
+  if (d_weight) d_weight[c] = (float)(dp * (double)invstd);
+  coef[c] = (float)(s / (double)N);
+  coef[C + c] = (float)(dp * (double)invstd * (double)invstd / (double)N);
+  coef[2 * C + c] = invstd * (weight ? weight[c] : 1.f);
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    k_bn_bwd_apply(const float *x, const float *d_out, float *d_x, const float *save_mean,
+                   int64_t total_vec, int C, const float *coef) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i * VEC) % C);
+    if (VEC == 4) {
+      const float4 xv = ((const float4 *)x)[i];
+      const float4 d = ((const float4 *)d_out)[i];
+      const float4 m = *(const float4 *)(save_mean + c);
+      const float4 gm = *(const float4 *)(coef + c);
+      const float4 kk = *(const float4 *)(coef + C + c);
+      const float4 sc = *(const float4 *)(coef + 2 * C + c);
+      float4 o;
+      o.x = (d.x - gm.x - (xv.x - m.x) * kk.x) * sc.x;
+      o.y = (d.y - gm.y - (xv.y - m.y) * kk.y) * sc.y;
+      o.z = (d.z - gm.z - (xv.z - m.z) * kk.z) * sc.z;
+      o.w = (d.w - gm.w - (xv.w - m.w) * kk.w) * sc.w;
+      ((float4 *)d_x)[i] = o;
+    } else {
+      d_x[i] = (d_out[i] - coef[c] - (x[i] - save_mean[c]) * coef[C + c]) * coef[2 * C + c];
+    }
+  }
+}
+
+// ------------------------------------------------------ input / output ---
+// out[s] = sum_j mult * in[order[q0+j]]  (sparseconvnet/SCN/CUDA/IOLayers.cu:17-31)
+__global__ void k_input_fwd(const float *feats, float *out, const int32_t *order,
+                            const int32_t *site_start, int64_t N, int C, int average) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * C;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = t / C;
+    const int c = (int)(t % C);
+    const int q0 = site_start[s], cnt = site_start[s + 1] - q0;
+    const float mult = (average && cnt > 0) ? 1.f / (float)cnt : 1.f;
+    float acc = 0.f;
+    for (int j = 0; j < cnt; ++j) acc += mult * feats[(int64_t)order[q0 + j] * C + c];
+    out[t] = acc;
+  }
+}
+// d_in[p] = mult(site) * d_out[site(p)]  (sparseconvnet/SCN/CUDA/IOLayers.cu:46-60, without atomics:
+// every input row belongs to exactly one site)
+__global__ void k_input_bwd(float *d_feats, const float *d_out, const int32_t *site_of_row,
+                            const int32_t *site_start, int64_t P, int C, int average) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < P * C;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / C;
+    const int c = (int)(t % C);
+    const int s = site_of_row[p];
+    float mult = 1.f;
+    if (average) {
+      const int cnt = site_start[s + 1] - site_start[s];
+      mult = cnt > 0 ? 1.f / (float)cnt : 1.f;
+    }
+    d_feats[t] = mult * d_out[(int64_t)s * C + c];
+  }
+}
+// out[p] = in[site(p)]  (sparseconvnet/SCN/CUDA/IOLayers.cpp:108-129)
+template <int VEC>
+__global__ void k_output_fwd(const float *in, float *out, const int32_t *site_of_row, int64_t P, int C) {
+  const int cv = C / VEC;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < P * cv;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / cv;
+    const int c = (int)(t % cv) * VEC;
+    const int64_t s = site_of_row[p];
+    if (VEC == 4) *(float4 *)(out + p * C + c) = *(const float4 *)(in + s * C + c);
+    else out[p * C + c] = in[s * C + c];
+  }
+}
+// d_in[s] = sum_j d_out[order[q0+j]]  (sparseconvnet/SCN/CUDA/IOLayers.cpp:131-154)
+template <int VEC>
+__global__ void k_output_bwd(float *d_in, const float *d_out, const int32_t *order,
+                             const int32_t *site_start, int64_t N, int C) {
+  const int cv = C / VEC;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * cv;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = t / cv;
+    const int c = (int)(t % cv) * VEC;
+    const int q0 = site_start[s], cnt = site_start[s + 1] - q0;
+    if (VEC == 4) {
+      float4 acc = make_float4(0, 0, 0, 0);
+      for (int j = 0; j < cnt; ++j) {
+        const float4 v = *(const float4 *)(d_out + (int64_t)order[q0 + j] * C + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *(float4 *)(d_in + s * C + c) = acc;
+    } else {
+      float acc = 0.f;
+      for (int j = 0; j < cnt; ++j) acc += d_out[(int64_t)order[q0 + j] * C + c];
+      d_in[s * C + c] = acc;
+    }
+  }
+}
+
+__global__ void k_column_sum(const float *x, float *out, int64_t rows, int C) {
+  // grid.x blocks over row chunks; thread handles column c = threadIdx.x + k*blockDim.x
+  const int64_t rows_per_blk = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc += x[r * C + c];
+    atomicAdd(out + c, acc);
+  }
+}
+
+// Wt[k][co][ci] = W[ks][ci][co] through a 32x33 LDS tile
+__global__ void __launch_bounds__(256)
+    k_weight_transpose(const float *W, float *Wt, int K, int Ci, int Co, int reverse) {
+  __shared__ float tile[32][33];
+  const int k = blockIdx.z;
+  const int ks = reverse ? K - 1 - k : k;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    tile[r][tx] = (ci < Ci && co < Co) ? W[((int64_t)ks * Ci + ci) * Co + co] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    if (co < Co && ci < Ci) Wt[((int64_t)k * Co + co) * Ci + ci] = tile[tx][r];
+  }
+}
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 4096) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+static inline int bn_blocks(int64_t N) {
+  int64_t b = (N + 63) / 64;  // >= 64 rows per block
+  if (b < 1) b = 1;
+  if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
+  return (int)b;
+}
+
+}  // namespace scn
+using namespace scn;
+
+extern "C" {
+
+size_t scn_bn_temp_bytes(int C) { return ((size_t)BN_MAX_BLOCKS * 2 * C + 3 * (size_t)C) * 4 + 256; }
+
+int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invstd,
+                   float *running_mean, float *running_var, const float *weight,
+                   const float *bias, double eps, double momentum, int train, double leakiness,
+                   int64_t N, int C, void *temp, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(C > 0 && N >= 0, "scn_bn_forward: bad shape");
+  float *partial = (float *)temp;
+  float *wb = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
+  const int nblk = bn_blocks(N);
+  const bool v4 = (C % 4) == 0;
+  if (train) {
+    SCN_REQUIRE(N > 0, "scn_bn_forward: training batch norm over zero active sites");
+    const int cg = v4 ? C / 4 : C;
+    dim3 grid(nblk, (cg + 255) / 256);
+    if (v4) k_bn_stats<4><<<grid, 256, 0, stream>>>(x, N, C, partial);
+    else k_bn_stats<1><<<grid, 256, 0, stream>>>(x, N, C, partial);
+    SCN_CHECK_LAUNCH();
+  }
+  k_bn_finalize<<<(C + 255) / 256, 256, 0, stream>>>(partial, nblk, N, C, save_mean, save_invstd,
+                                                    running_mean, running_var, weight, bias,
+                                                    (float)eps, (float)momentum, train, wb);
+  SCN_CHECK_LAUNCH();
+  if (N > 0) {
+    const int64_t total = N * C;
+    if (v4) k_bn_apply<4><<<grid_for(total / 4), 256, 0, stream>>>(x, y, total / 4, C, wb, (float)leakiness);
+    else k_bn_apply<1><<<grid_for(total), 256, 0, stream>>>(x, y, total, C, wb, (float)leakiness);
+    SCN_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
+                    const float *save_mean, const float *save_invstd, const float *weight,
+                    float *d_weight, float *d_bias, double leakiness, int64_t N, int C,
+                    void *temp, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(C > 0 && N > 0, "scn_bn_backward: bad shape");
+  float *partial = (float *)temp;
+  float *coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
+  const int nblk = bn_blocks(N);
+  const bool v4 = (C % 4) == 0;
+  const int cg = v4 ? C / 4 : C;
+  dim3 grid(nblk, (cg + 255) / 256);
+  if (v4) k_bn_bwd_stats<4><<<grid, 256, 0, stream>>>(x, y, d_out, save_mean, N, C, (float)leakiness, partial);
+  else k_bn_bwd_stats<1><<<grid, 256, 0, stream>>>(x, y, d_out, save_mean, N, C, (float)leakiness, partial);
+  SCN_CHECK_LAUNCH();
+  k_bn_bwd_finalize<<<(C + 255) / 256, 256, 0, stream>>>(partial, nblk, N, C, save_invstd, weight,
+                                                        d_weight, d_bias, coef);
+  SCN_CHECK_LAUNCH();
+  const int64_t total = N * C;
+  if (v4) k_bn_bwd_apply<4><<<grid_for(total / 4), 256, 0, stream>>>(x, d_out, d_x, save_mean, total / 4, C, coef);
+  else k_bn_bwd_apply<1><<<grid_for(total), 256, 0, stream>>>(x, d_out, d_x, save_mean, total, C, coef);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int scn_input_forward(const float *feats, float *out, const int32_t *order,
+                      const int32_t *site_start, int64_t N, int C, int average, void *stream_) {
+  if (N <= 0) return 0;
+  k_input_fwd<<<grid_for(N * C), 256, 0, as_stream(stream_)>>>(feats, out, order, site_start, N, C, average);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+int scn_input_backward(float *d_feats, const float *d_out, const int32_t *site_of_row,
+                       const int32_t *site_start, int64_t P, int C, int average, void *stream_) {
+  if (P <= 0) return 0;
+  k_input_bwd<<<grid_for(P * C), 256, 0, as_stream(stream_)>>>(d_feats, d_out, site_of_row, site_start, P, C, average);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+int scn_output_forward(const float *in, float *out, const int32_t *site_of_row, int64_t P, int C,
+                       void *stream_) {
+  if (P <= 0) return 0;
+  if (C % 4 == 0) k_output_fwd<4><<<grid_for(P * (C / 4)), 256, 0, as_stream(stream_)>>>(in, out, site_of_row, P, C);
+  else k_output_fwd<1><<<grid_for(P * C), 256, 0, as_stream(stream_)>>>(in, out, site_of_row, P, C);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+int scn_output_backward(float *d_in, const float *d_out, const int32_t *order,
+                        const int32_t *site_start, int64_t N, int C, void *stream_) {
+  if (N <= 0) return 0;
+  if (C % 4 == 0) k_output_bwd<4><<<grid_for(N * (C / 4)), 256, 0, as_stream(stream_)>>>(d_in, d_out, order, site_start, N, C);
+  else k_output_bwd<1><<<grid_for(N * C), 256, 0, as_stream(stream_)>>>(d_in, d_out, order, site_start, N, C);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)C * 4, stream));
+  if (rows <= 0) return 0;
+  int blocks = (int)((rows + 255) / 256);
+  if (blocks > 512) blocks = 512;
+  k_column_sum<<<blocks, 256, 0, stream>>>(x, out, rows, C);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int scn_weight_transpose(const float *W, float *Wt, int K, int Ci, int Co, int reverse,
+                         void *stream_) {
+  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, K);
+  k_weight_transpose<<<grid, 256, 0, as_stream(stream_)>>>(W, Wt, K, Ci, Co, reverse);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

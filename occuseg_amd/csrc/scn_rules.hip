@@ -1,0 +1,512 @@
+// Voxel grids, voxel hash map and rulebooks on the device (gfx950).
+//
+// What the reference does with CUDPP radix-sort / cuckoo hash / 27+8 stream
+// compactions and host round trips (sparseconvnet/SCN/CUDA/CUDPPWrapper.{hpp,cu},
+// sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.{cpp,cu}) is done here with one
+// global (sample,key) sort, an open-addressing hash map and order-preserving
+// compaction by wavefront ballot + popcount prefix sums.  Rulebooks never leave
+// the device.  Semantics: SURVEY.md Appendix A.
+#include "scn_common.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace scn {
+thread_local char g_err[512] = "";
+
+// ------------------------------------------------------------------ keys ---
+template <bool I64>
+__global__ void k_make_keys(const void *coords_, int ncols, int shift, int64_t P,
+                            uint64_t *keys, uint32_t *idx, int *err) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t x, y, z, b;
+    if (I64) {
+      const int64_t *c = (const int64_t *)coords_ + p * ncols;
+      x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
+    } else {
+      const int32_t *c = (const int32_t *)coords_ + p * ncols;
+      x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
+    }
+    x >>= shift; y >>= shift; z >>= shift;
+    if (x < 0 || x >= 1024 || y < 0 || y >= 2048 || z < 0 || z >= 1024 || b < 0 || b >= 65536) {
+      atomicOr(err, 1);
+      x = y = z = b = 0;
+    }
+    keys[p] = voxel_key((int)x, (int)y, (int)z, (int)b);
+    idx[p] = (uint32_t)p;
+  }
+}
+
+// first-of-run flags over the sorted keys; per-block counts
+__global__ void __launch_bounds__(256) k_mark_first(const uint64_t *keys, int64_t P, int *blk_cnt) {
+  __shared__ int wt[4];
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool flag = q < P && (q == 0 || keys[q] != keys[q - 1]);
+  int total;
+  block_rank256(flag, wt, total);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = total;
+}
+
+// exclusive scan of each row of data[rows][n] in place; totals[row] = row sum
+__global__ void __launch_bounds__(1024) k_excl_scan_rows(int *data, int n, int *totals) {
+  __shared__ int wsum[16];
+  int *d = data + (int64_t)blockIdx.x * n;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  int carry = 0;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? d[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int t = wsum[j];
+      wbase += j < w ? t : 0;
+      tot += t;
+    }
+    if (i < n) d[i] = carry + wbase + x - v;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+    k_assign_sites(const uint64_t *keys, const uint32_t *order, int64_t P, const int *blk_base,
+                   int32_t *site_of_row, int32_t *site_start) {
+  __shared__ int wt[4];
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool flag = q < P && (q == 0 || keys[q] != keys[q - 1]);
+  int total;
+  const int r = block_rank256(flag, wt, total);
+  if (q < P) {
+    const int site = blk_base[blockIdx.x] + r + (flag ? 1 : 0) - 1;
+    site_of_row[order[q]] = site;
+    if (flag) site_start[site] = (int32_t)q;
+    if (q == P - 1) site_start[site + 1] = (int32_t)P;
+  }
+}
+
+template <bool I64>
+__global__ void k_site_coords(const void *coords_, int ncols, int shift, int64_t N,
+                              const uint64_t *keys_sorted, const int32_t *order,
+                              const int32_t *site_start, int4 *site_coords, uint64_t *site_keys) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < N;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    const int q = site_start[s];
+    const int64_t p = order[q];
+    int64_t x, y, z, b;
+    if (I64) {
+      const int64_t *c = (const int64_t *)coords_ + p * ncols;
+      x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
+    } else {
+      const int32_t *c = (const int32_t *)coords_ + p * ncols;
+      x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
+    }
+    site_coords[s] = make_int4((int)(x >> shift), (int)(y >> shift), (int)(z >> shift), (int)b);
+    site_keys[s] = keys_sorted[q];
+  }
+}
+
+// ------------------------------------------------------------ hash map ---
+__global__ void k_hash_insert(const uint64_t *site_keys, int64_t N, uint64_t *tkeys,
+                              int32_t *tvals, uint32_t mask) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < N;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = site_keys[s];
+    uint32_t slot = hash_slot(key, mask);
+    while (true) {
+      const unsigned long long prev =
+          atomicCAS((unsigned long long *)&tkeys[slot], (unsigned long long)HASH_EMPTY,
+                    (unsigned long long)key);
+      if (prev == HASH_EMPTY) {
+        tvals[slot] = (int32_t)s;
+        break;
+      }
+      slot = (slot + 1) & mask;  // keys are unique: never equal to prev
+    }
+  }
+}
+
+__device__ __forceinline__ int hash_lookup(const uint64_t *tkeys, const int32_t *tvals,
+                                           uint32_t mask, uint64_t key) {
+  uint32_t slot = hash_slot(key, mask);
+  while (true) {
+    const uint64_t k = tkeys[slot];
+    if (k == key) return tvals[slot];
+    if (k == HASH_EMPTY) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ----------------------------------------------- submanifold 3x3x3 rules ---
+// pass 1: probe the 27 neighbours of each site, write nbr[k][o], count per block
+__global__ void __launch_bounds__(256)
+    k_sub_probe(const int4 *coords, int64_t N, const uint64_t *tkeys, const int32_t *tvals,
+                uint32_t mask, int32_t *nbr, int *blk_cnt, int nblk) {
+  __shared__ int wcnt[4][27];
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = o < N;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  int4 c = make_int4(0, 0, 0, 0);
+  if (valid) c = coords[o];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    // k = (dx+1)*9 + (dy+1)*3 + (dz+1): sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:61-74
+    const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
+    int i = -1;
+    if (valid) {
+      if (k == 13) {
+        i = (int)o;
+      } else {
+        const int x = c.x + dx, y = c.y + dy, z = c.z + dz;
+        if (in_key_box(x, y, z)) i = hash_lookup(tkeys, tvals, mask, voxel_key(x, y, z, c.w));
+      }
+      nbr[(int64_t)k * N + o] = i;
+    }
+    const unsigned long long m = __ballot(i >= 0);
+    if (lane == 0) wcnt[w][k] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int k = threadIdx.x;
+    blk_cnt[(int64_t)k * nblk + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+  }
+}
+
+// pass 2: order-preserving compaction of (in, out) pairs into rules[k]
+template <int K>
+__global__ void __launch_bounds__(256)
+    k_rules_fill(const int32_t *nbr, int64_t N, const int *blk_base, int nblk, int2 *rules) {
+  __shared__ int wcnt[4][K];
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = o < N;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int in_k[K];
+  int rk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    in_k[k] = valid ? nbr[(int64_t)k * N + o] : -1;
+    const unsigned long long m = __ballot(in_k[k] >= 0);
+    rk[k] = __popcll(m & lt);
+    if (lane == 0) wcnt[w][k] = __popcll(m);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (in_k[k] >= 0) {
+      int base = blk_base[(int64_t)k * nblk + blockIdx.x];
+      for (int j = 0; j < w; ++j) base += wcnt[j][k];
+      rules[(int64_t)k * N + base + rk[k]] = make_int2(in_k[k], (int)o);
+    }
+  }
+}
+
+// ---------------------------------------------------- strided 2/2 rules ---
+// k = ((x&1)*2 + (y&1))*2 + (z&1): sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:549-554
+__global__ void __launch_bounds__(256)
+    k_str_count(const int4 *coords, int64_t N, int *blk_cnt, int nblk) {
+  __shared__ int wcnt[4][8];
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  int koff = -1;
+  if (f < N) {
+    const int4 c = coords[f];
+    koff = ((c.x & 1) * 2 + (c.y & 1)) * 2 + (c.z & 1);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const unsigned long long m = __ballot(koff == k);
+    if (lane == 0) wcnt[w][k] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int k = threadIdx.x;
+    blk_cnt[(int64_t)k * nblk + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_str_fill(const int4 *coords, int64_t N, const int32_t *coarse_of_fine, const int *blk_base,
+               int nblk, int2 *rules) {
+  __shared__ int wcnt[4][8];
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int koff = -1, coarse = -1;
+  if (f < N) {
+    const int4 c = coords[f];
+    koff = ((c.x & 1) * 2 + (c.y & 1)) * 2 + (c.z & 1);
+    coarse = coarse_of_fine[f];
+  }
+  int my_rank = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const unsigned long long m = __ballot(koff == k);
+    if (koff == k) my_rank = __popcll(m & lt);
+    if (lane == 0) wcnt[w][k] = __popcll(m);
+  }
+  __syncthreads();
+  if (koff >= 0) {
+    int base = blk_base[(int64_t)koff * nblk + blockIdx.x];
+    for (int j = 0; j < w; ++j) base += wcnt[j][koff];
+    rules[(int64_t)koff * N + base + my_rank] = make_int2((int)f, coarse);
+  }
+}
+
+// ------------------------------------------------------------ tile bases ---
+__global__ void k_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
+                             int out_col, int n_gran, int32_t *bases) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * (n_gran + 1);
+  if (t >= total) return;
+  const int k = (int)(t / (n_gran + 1));
+  const int g = (int)(t % (n_gran + 1));
+  const int target = g * SCN_TILE_GRANULE;
+  const int32_t *col = rules + ((int64_t)k * stride) * 2 + out_col;
+  int lo = 0, hi = counts[k];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[(int64_t)mid * 2] < target) lo = mid + 1; else hi = mid;
+  }
+  bases[t] = lo;
+}
+
+// ------------------------------------------------------ input rule table ---
+__global__ void k_max_active(const int32_t *site_start, int64_t N, int32_t *out) {
+  int m = 0;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < N;
+       s += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, site_start[s + 1] - site_start[s]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off));
+  if (lane_id() == 0) atomicMax(out, m);
+}
+
+__global__ void k_input_table(const int32_t *order, const int32_t *site_start, int64_t N,
+                              int max_active, int32_t *table) {
+  const int wdt = 1 + max_active;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * wdt;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = t / wdt;
+    const int j = (int)(t % wdt);
+    const int q0 = site_start[s], cnt = site_start[s + 1] - q0;
+    int v;
+    if (j == 0) v = cnt;
+    else v = (j - 1 < cnt) ? order[q0 + j - 1] : 0;
+    table[t] = v;
+  }
+}
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+struct GridTemp {
+  size_t keys_in, idx_in, blk_cnt, info, sort, total, sort_bytes;
+};
+static int grid_temp_layout(int64_t P, GridTemp &t) {
+  const int64_t nblk = (P + 255) / 256;
+  size_t sort_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, uint64_t *, uint64_t *,
+                                           uint32_t *, uint32_t *>(
+      nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)P, 0, 47, 0, false);
+  if (e != hipSuccess) return 1;
+  size_t off = 0;
+  t.keys_in = off; off += align256((size_t)P * 8);
+  t.idx_in = off; off += align256((size_t)P * 4);
+  t.blk_cnt = off; off += align256((size_t)(nblk + 1) * 4);
+  t.info = off; off += 256;
+  t.sort = off; off += align256(sort_bytes);
+  t.total = off;
+  t.sort_bytes = sort_bytes;
+  return 0;
+}
+
+}  // namespace scn
+
+using namespace scn;
+
+extern "C" {
+
+int scn_abi_version(void) { return SCN_ABI_VERSION; }
+const char *scn_last_error(void) { return scn::g_err; }
+
+size_t scn_grid_build_temp_bytes(int64_t P) {
+  GridTemp t;
+  if (P <= 0 || grid_temp_layout(P, t)) return 0;
+  return t.total;
+}
+
+int scn_grid_build(const void *coords, int coords_are_i64, int ncols, int shift, int64_t P,
+                   void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
+                   int32_t *site_of_row, int32_t *site_start, int32_t *n_sites_host,
+                   void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(P > 0 && P < (int64_t)1 << 31, "scn_grid_build: P out of range");
+  SCN_REQUIRE(ncols == 3 || ncols == 4, "scn_grid_build: ncols must be 3 or 4");
+  GridTemp t;
+  SCN_REQUIRE(grid_temp_layout(P, t) == 0, "scn_grid_build: rocprim size query failed");
+  SCN_REQUIRE(temp_bytes >= t.total, "scn_grid_build: workspace too small");
+  char *base = (char *)temp;
+  uint64_t *keys_in = (uint64_t *)(base + t.keys_in);
+  uint32_t *idx_in = (uint32_t *)(base + t.idx_in);
+  int *blk_cnt = (int *)(base + t.blk_cnt);
+  int *info = (int *)(base + t.info);  // [0]=N [1]=error flag
+  const int nblk = (int)((P + 255) / 256);
+  SCN_CHECK_HIP(hipMemsetAsync(info, 0, 16, stream));
+  if (coords_are_i64)
+    k_make_keys<true><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
+  else
+    k_make_keys<false><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
+  SCN_CHECK_LAUNCH();
+  size_t sb = t.sort_bytes;
+  SCN_CHECK_HIP((rocprim::radix_sort_pairs(base + t.sort, sb, keys_in, keys_sorted, idx_in,
+                                           (uint32_t *)order, (size_t)P, 0, 47, stream, false)));
+  k_mark_first<<<nblk, 256, 0, stream>>>(keys_sorted, P, blk_cnt);
+  SCN_CHECK_LAUNCH();
+  k_excl_scan_rows<<<1, 1024, 0, stream>>>(blk_cnt, nblk, info);
+  SCN_CHECK_LAUNCH();
+  k_assign_sites<<<nblk, 256, 0, stream>>>(keys_sorted, (const uint32_t *)order, P, blk_cnt,
+                                          site_of_row, site_start);
+  SCN_CHECK_LAUNCH();
+  int host_info[2] = {0, 0};
+  SCN_CHECK_HIP(hipMemcpyAsync(host_info, info, 8, hipMemcpyDeviceToHost, stream));
+  SCN_CHECK_HIP(hipStreamSynchronize(stream));
+  if (host_info[1])
+    return fail(3, "scn_grid_build: coordinate outside the 31-bit key box (0<=x<1024, 0<=y<2048, 0<=z<1024) or bad sample index%s", "");
+  *n_sites_host = host_info[0];
+  return 0;
+}
+
+int scn_grid_finalize(const void *coords, int coords_are_i64, int ncols, int shift, int64_t P,
+                      int64_t N, const uint64_t *keys_sorted, const int32_t *order,
+                      const int32_t *site_start, int32_t *site_coords, uint64_t *site_keys,
+                      void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  (void)P;
+  if (N <= 0) return 0;
+  if (coords_are_i64)
+    k_site_coords<true><<<grid_for(N), 256, 0, stream>>>(coords, ncols, shift, N, keys_sorted, order,
+                                                         site_start, (int4 *)site_coords, site_keys);
+  else
+    k_site_coords<false><<<grid_for(N), 256, 0, stream>>>(coords, ncols, shift, N, keys_sorted, order,
+                                                          site_start, (int4 *)site_coords, site_keys);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int64_t scn_hash_capacity(int64_t N) {
+  int64_t cap = 1024;
+  while (cap < 2 * N) cap <<= 1;
+  return cap;
+}
+
+int scn_hash_build(const uint64_t *site_keys, int64_t N, uint64_t *table_keys,
+                   int32_t *table_vals, int64_t capacity, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(capacity >= 2 * N && (capacity & (capacity - 1)) == 0 && capacity <= ((int64_t)1 << 31),
+              "scn_hash_build: capacity must be a power of two >= 2N");
+  SCN_CHECK_HIP(hipMemsetAsync(table_keys, 0xFF, (size_t)capacity * 8, stream));
+  if (N > 0) {
+    k_hash_insert<<<grid_for(N), 256, 0, stream>>>(site_keys, N, table_keys, table_vals,
+                                                   (uint32_t)(capacity - 1));
+    SCN_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int scn_input_rules_max_active(const int32_t *site_start, int64_t N, int32_t *scratch_dev,
+                               int32_t *max_active_host, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_CHECK_HIP(hipMemsetAsync(scratch_dev, 0, 4, stream));
+  if (N > 0) {
+    k_max_active<<<grid_for(N, 256, 1024), 256, 0, stream>>>(site_start, N, scratch_dev);
+    SCN_CHECK_LAUNCH();
+  }
+  SCN_CHECK_HIP(hipMemcpyAsync(max_active_host, scratch_dev, 4, hipMemcpyDeviceToHost, stream));
+  SCN_CHECK_HIP(hipStreamSynchronize(stream));
+  return 0;
+}
+
+int scn_input_rules_table(const int32_t *order, const int32_t *site_start, int64_t N,
+                          int32_t max_active, int32_t *table, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  if (N <= 0) return 0;
+  k_input_table<<<grid_for(N * (1 + max_active)), 256, 0, stream>>>(order, site_start, N, max_active, table);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t scn_rules_temp_bytes(int64_t N, int K) {
+  const int64_t nblk = (N + 255) / 256;
+  return align256((size_t)K * (size_t)(nblk > 0 ? nblk : 1) * 4) + 256;
+}
+
+int scn_submanifold_rules(const int32_t *site_coords, int64_t N, const uint64_t *table_keys,
+                          const int32_t *table_vals, int64_t capacity, int32_t *nbr,
+                          int32_t *rules, int32_t *counts, void *temp, size_t temp_bytes,
+                          void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(temp_bytes >= scn_rules_temp_bytes(N, 27), "scn_submanifold_rules: workspace too small");
+  if (N <= 0) {
+    SCN_CHECK_HIP(hipMemsetAsync(counts, 0, 27 * 4, stream));
+    return 0;
+  }
+  const int nblk = (int)((N + 255) / 256);
+  int *blk_cnt = (int *)temp;
+  k_sub_probe<<<nblk, 256, 0, stream>>>((const int4 *)site_coords, N, table_keys, table_vals,
+                                       (uint32_t)(capacity - 1), nbr, blk_cnt, nblk);
+  SCN_CHECK_LAUNCH();
+  k_excl_scan_rows<<<27, 1024, 0, stream>>>(blk_cnt, nblk, counts);
+  SCN_CHECK_LAUNCH();
+  k_rules_fill<27><<<nblk, 256, 0, stream>>>(nbr, N, blk_cnt, nblk, (int2 *)rules);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int scn_strided_rules(const int32_t *fine_coords, int64_t N, const int32_t *coarse_of_fine,
+                      int32_t *rules, int32_t *counts, void *temp, size_t temp_bytes,
+                      void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(temp_bytes >= scn_rules_temp_bytes(N, 8), "scn_strided_rules: workspace too small");
+  if (N <= 0) {
+    SCN_CHECK_HIP(hipMemsetAsync(counts, 0, 8 * 4, stream));
+    return 0;
+  }
+  const int nblk = (int)((N + 255) / 256);
+  int *blk_cnt = (int *)temp;
+  k_str_count<<<nblk, 256, 0, stream>>>((const int4 *)fine_coords, N, blk_cnt, nblk);
+  SCN_CHECK_LAUNCH();
+  k_excl_scan_rows<<<8, 1024, 0, stream>>>(blk_cnt, nblk, counts);
+  SCN_CHECK_LAUNCH();
+  k_str_fill<<<nblk, 256, 0, stream>>>((const int4 *)fine_coords, N, coarse_of_fine, blk_cnt, nblk,
+                                      (int2 *)rules);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
+                   int out_col, int64_t n_out, int32_t *bases, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(out_col == 0 || out_col == 1, "scn_tile_bases: out_col must be 0 or 1");
+  const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+  const int64_t total = (int64_t)K * (n_gran + 1);
+  k_tile_bases<<<(int)((total + 255) / 256), 256, 0, stream>>>(rules, counts, K, stride, out_col,
+                                                               n_gran, bases);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""Graph glue: Sequential, ConcatTable, JoinTable, AddTable, Identity, NetworkInNetwork.
+
+Operator API of sparseconvnet/sequential.py:9-17, sparseconvnet/tables.py:13-55, sparseconvnet/identity.py,
+sparseconvnet/networkInNetwork.py:14-88.  Children are registered under '0','1',... so that
+state_dict keys equal the reference's.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import Module, Parameter
+
+from .. import SCN
+from . import counters
+from .tensor import SparseConvNetTensor, like_empty, optionalTensor
+
+
+class Sequential(torch.nn.Sequential):
+    def add(self, module):
+        self._modules[str(len(self._modules))] = module
+        return self
+
+    def input_spatial_size(self, out_size):
+        for name in reversed(self._modules):
+            out_size = self._modules[name].input_spatial_size(out_size)
+        return out_size
+
+
+class Identity(Module):
+    def forward(self, input):
+        return input
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+def _like(first, features):
+    return SparseConvNetTensor(features, first.metadata, first.spatial_size)
+
+
+class ConcatTable(Sequential):
+    """apply every child to the same input, return the list of results"""
+
+    def forward(self, input):
+        return [child(input) for child in self._modules.values()]
+
+    def input_spatial_size(self, out_size):
+        return self._modules["0"].input_spatial_size(out_size)
+
+
+class JoinTable(torch.nn.Sequential):
+    """concatenate feature planes of a list of tensors living on the same sites"""
+
+    def forward(self, input):
+        return _like(input[0], torch.cat([t.features for t in input], 1))
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class AddTable(torch.nn.Sequential):
+    def forward(self, input):
+        total = input[0].features
+        for t in input[1:]:
+            total = total + t.features
+        return _like(input[0], total)
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class _NiNFunction(Function):
+    @staticmethod
+    def forward(ctx, features, weight, bias):
+        out = like_empty(features)
+        macs = SCN.NetworkInNetwork_updateOutput(features, out, weight, bias)
+        counters.add(macs, out.nelement())
+        ctx.save_for_backward(features, weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        features, weight, bias = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_input = like_empty(grad_output)
+        grad_weight = torch.zeros_like(weight)
+        grad_bias = torch.zeros_like(bias)
+        SCN.NetworkInNetwork_updateGradInput(grad_input, grad_output, weight)
+        SCN.NetworkInNetwork_accGradParameters(features, grad_output, grad_weight, grad_bias)
+        return grad_input, grad_weight, (grad_bias if grad_bias.numel() else None)
+
+
+class NetworkInNetwork(Module):
+    """1x1 convolution: features @ weight (+ bias); weight [nIn, nOut] ~ N(0, sqrt(2/nIn))"""
+
+    def __init__(self, nIn, nOut, bias):
+        Module.__init__(self)
+        self.nIn, self.nOut = nIn, nOut
+        self.weight = Parameter(torch.empty(nIn, nOut).normal_(0, (2.0 / nIn) ** 0.5))
+        if bias:
+            self.bias = Parameter(torch.zeros(nOut))
+
+    def forward(self, input):
+        assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, input.features.shape)
+        return _like(input, _NiNFunction.apply(input.features, self.weight, optionalTensor(self, "bias")))
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+    def __repr__(self):
+        return "NetworkInNetwork%d->%d" % (self.nIn, self.nOut)

@@ -1,0 +1,152 @@
+"""SubmanifoldConvolution / Convolution / Deconvolution modules.
+
+Operator API of sparseconvnet/submanifoldConvolution.py:18-128, sparseconvnet/convolution.py:14-127,
+sparseconvnet/deconvolution.py:13-155: same constructor arguments, parameter names/shapes
+(`weight` [filter_volume, nIn, nOut] ~ N(0, sqrt(2/(nIn*volume))), optional `bias`),
+same forward contract on SparseConvNetTensor.  One autograd Function serves
+the three ops; it calls the SCN boundary functions with the reference's names.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import Module, Parameter
+
+from .. import SCN
+from . import counters
+from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTensorReturn, toLongTensor
+
+
+class _RuleConvFunction(Function):
+    """kind: 'submanifold' | 'conv' | 'deconv'"""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, kind, metadata, in_size, out_size, filter_size, filter_stride,
+                dilated_rate):
+        ctx.kind, ctx.metadata, ctx.dilated_rate = kind, metadata, dilated_rate
+        ctx.sizes = (in_size, out_size, filter_size, filter_stride)
+        out = like_empty(features)
+        if kind == "submanifold":
+            macs = SCN.SubmanifoldConvolution_updateOutput(in_size, filter_size, metadata, features, out, weight,
+                                                           bias, dilated_rate)
+        elif kind == "conv":
+            macs = SCN.Convolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, features,
+                                                out, weight, bias)
+        else:
+            macs = SCN.Deconvolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, features,
+                                                  out, weight, bias)
+        counters.add(macs, out.nelement())
+        ctx.save_for_backward(features, weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        features, weight, bias = ctx.saved_tensors
+        in_size, out_size, filter_size, filter_stride = ctx.sizes
+        grad_output = grad_output.contiguous()
+        # the reference always computes dInput; it is skipped here when autograd does not ask for it
+        grad_input = like_empty(grad_output) if ctx.needs_input_grad[0] else None
+        grad_weight = torch.zeros_like(weight)
+        grad_bias = torch.zeros_like(bias)
+        m = ctx.metadata
+        if ctx.kind == "submanifold":
+            SCN.SubmanifoldConvolution_backward(in_size, filter_size, m, features, grad_input, grad_output, weight,
+                                                grad_weight, grad_bias, ctx.dilated_rate)
+        elif ctx.kind == "conv":
+            SCN.Convolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
+                                     grad_output, weight, grad_weight, grad_bias)
+        else:
+            SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
+                                       grad_output, weight, grad_weight, grad_bias)
+        ctx.metadata = None
+        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7
+
+
+class _RuleConv(Module):
+    kind = None
+    label = None
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias, dilated_rate=1):
+        Module.__init__(self)
+        self.dimension = dimension
+        self.nIn, self.nOut = nIn, nOut
+        self.filter_size = toLongTensor(dimension, filter_size)
+        self.filter_volume = int(self.filter_size.prod().item())
+        self.filter_stride = None if filter_stride is None else toLongTensor(dimension, filter_stride)
+        self.dilated_rate = dilated_rate
+        std = (2.0 / nIn / self.filter_volume) ** 0.5
+        self.weight = Parameter(torch.empty(self.filter_volume, nIn, nOut).normal_(0, std))
+        if bias:
+            self.bias = Parameter(torch.zeros(nOut))
+
+    def output_spatial_size(self, in_size):
+        raise NotImplementedError
+
+    def forward(self, input):
+        assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, self.nOut, input)
+        out_size = self.output_spatial_size(input.spatial_size)
+        output = SparseConvNetTensor(metadata=input.metadata, spatial_size=out_size)
+        output.features = _RuleConvFunction.apply(
+            input.features, self.weight, optionalTensor(self, "bias"), self.kind, input.metadata,
+            input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate)
+        return output
+
+    def _fmt(self, t):
+        v = t.tolist()
+        return str(v[0]) if min(v) == max(v) else "(" + ",".join(str(i) for i in v) + ")"
+
+    def __repr__(self):
+        s = "%s %d->%d C%s" % (self.label, self.nIn, self.nOut, self._fmt(self.filter_size))
+        if self.filter_stride is not None:
+            s += "/" + self._fmt(self.filter_stride)
+        return s
+
+
+class SubmanifoldConvolution(_RuleConv):
+    """scn.SubmanifoldConvolution(dimension, nIn, nOut, filter_size, bias, dilated_rate=1)"""
+    kind, label = "submanifold", "SubmanifoldConvolution"
+
+    def __init__(self, dimension, nIn, nOut, filter_size, bias, dilated_rate=1):
+        _RuleConv.__init__(self, dimension, nIn, nOut, filter_size, None, bias, dilated_rate)
+
+    def output_spatial_size(self, in_size):
+        return in_size
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class ValidConvolution(SubmanifoldConvolution):
+    pass
+
+
+class Convolution(_RuleConv):
+    """scn.Convolution(dimension, nIn, nOut, filter_size, filter_stride, bias)"""
+    kind, label = "conv", "Convolution"
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias):
+        _RuleConv.__init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias)
+
+    def output_spatial_size(self, in_size):
+        # integer division: sparseconvnet/convolution.py:35-38 relied on LongTensor `/` flooring (torch 1.1)
+        out = (in_size - self.filter_size) // self.filter_stride + 1
+        assert ((out - 1) * self.filter_stride + self.filter_size == in_size).all(), \
+            (in_size, out, self.filter_size, self.filter_stride)
+        return out
+
+    def input_spatial_size(self, out_size):
+        return (out_size - 1) * self.filter_stride + self.filter_size
+
+
+class Deconvolution(_RuleConv):
+    """scn.Deconvolution(dimension, nIn, nOut, filter_size, filter_stride, bias)"""
+    kind, label = "deconv", "Deconvolution"
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias):
+        _RuleConv.__init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias)
+
+    def output_spatial_size(self, in_size):
+        return (in_size - 1) * self.filter_stride + self.filter_size
+
+    def input_spatial_size(self, out_size):
+        in_size = (out_size - self.filter_size) // self.filter_stride + 1
+        assert ((in_size - 1) * self.filter_stride + self.filter_size == out_size).all()
+        return in_size

@@ -1,0 +1,75 @@
+"""InputLayer / OutputLayer.
+
+Operator API of sparseconvnet/ioLayers.py:15-87,157-223 including the fork's input convention
+``[coords, features, normals, batch_size]`` (sparseconvnet/ioLayers.py:56-60).  coords: LongTensor
+[P,3] or [P,4] (x,y,z[,batch]); the GPU path of the reference supports mode 3
+(sum duplicates) and 4 (average), sparseconvnet/SCN/Metadata/IOLayersRules.h:141.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import Module
+
+from .. import SCN
+from .tensor import Metadata, SparseConvNetTensor, like_empty, toLongTensor
+
+
+class _InputLayerFunction(Function):
+    @staticmethod
+    def forward(ctx, features, metadata, spatial_size, coords, batch_size, mode, normals, normal_guide_scale):
+        ctx.metadata = metadata
+        out = like_empty(features)
+        metadata.setNormalGuideScale(normal_guide_scale)
+        SCN.InputLayer_updateOutput(metadata, spatial_size, coords, features.contiguous(), out, batch_size, mode,
+                                    normals)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        grad_input = like_empty(grad_output)
+        SCN.InputLayer_updateGradInput(ctx.metadata, grad_input, grad_output.contiguous())
+        ctx.metadata = None
+        return (grad_input,) + (None,) * 7
+
+
+class _OutputLayerFunction(Function):
+    @staticmethod
+    def forward(ctx, features, metadata):
+        ctx.metadata = metadata
+        out = like_empty(features)
+        SCN.OutputLayer_updateOutput(metadata, features.contiguous(), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        grad_input = like_empty(grad_output)
+        SCN.OutputLayer_updateGradInput(ctx.metadata, grad_input, grad_output.contiguous())
+        ctx.metadata = None
+        return grad_input, None
+
+
+class InputLayer(Module):
+    def __init__(self, dimension, spatial_size, mode=3, normal_guide_scale=10240):
+        Module.__init__(self)
+        self.dimension = dimension
+        self.spatial_size = toLongTensor(dimension, spatial_size)
+        self.mode = mode
+        self.normal_guide_scale = normal_guide_scale
+
+    def forward(self, input):
+        coords, features = input[0], input[1]
+        normals = input[2] if len(input) > 2 else None
+        batch_size = input[3] if len(input) > 3 else 0
+        output = SparseConvNetTensor(metadata=Metadata(self.dimension), spatial_size=self.spatial_size)
+        output.features = _InputLayerFunction.apply(features, output.metadata, self.spatial_size,
+                                                    coords.to(torch.int64), batch_size, self.mode, normals,
+                                                    self.normal_guide_scale)
+        return output
+
+
+class OutputLayer(Module):
+    def __init__(self, dimension):
+        Module.__init__(self)
+        self.dimension = dimension
+
+    def forward(self, input):
+        return _OutputLayerFunction.apply(input.features, input.metadata)

@@ -1,0 +1,90 @@
+"""BatchNormalization over active sites with the fused (leaky) ReLU.
+
+Operator API of sparseconvnet/batchNormalization.py:13-161: eps 1e-4, momentum 0.9 with the
+reference's convention running = momentum*running + (1-momentum)*batch,
+`leakiness` 0 = ReLU, 1 = no activation; buffers `running_mean`/`running_var`,
+parameters `weight`/`bias`.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import Module, Parameter
+
+from .. import SCN
+from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTensorReturn
+
+
+class _BatchNormFunction(Function):
+    @staticmethod
+    def forward(ctx, features, weight, bias, running_mean, running_var, eps, momentum, train, leakiness):
+        ctx.train, ctx.leakiness = train, leakiness
+        out = like_empty(features)
+        save_mean = like_empty(features)
+        save_invstd = like_empty(features)
+        SCN.BatchNormalization_updateOutput(features, out, save_mean, save_invstd, running_mean, running_var,
+                                            weight, bias, eps, momentum, train, leakiness)
+        ctx.save_for_backward(features, out, weight, bias, running_mean, running_var, save_mean, save_invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        features, out, weight, bias, running_mean, running_var, save_mean, save_invstd = ctx.saved_tensors
+        assert ctx.train
+        # the backend rewrites d_out in place (sparseconvnet/SCN/CUDA/BatchNormalization.cu:151-153):
+        # hand it a private contiguous copy so that autograd's buffer is never mutated
+        grad_output = grad_output.contiguous().clone()
+        grad_input = like_empty(grad_output)
+        grad_weight = torch.zeros_like(weight)
+        grad_bias = torch.zeros_like(bias)
+        SCN.BatchNormalization_backward(features, grad_input, out, grad_output, save_mean, save_invstd,
+                                        running_mean, running_var, weight, bias, grad_weight, grad_bias,
+                                        ctx.leakiness)
+        return (grad_input, optionalTensorReturn(grad_weight), optionalTensorReturn(grad_bias)) + (None,) * 6
+
+
+class BatchNormalization(Module):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=1):
+        Module.__init__(self)
+        self.nPlanes, self.eps, self.momentum = nPlanes, eps, momentum
+        self.affine, self.leakiness = affine, leakiness
+        self.register_buffer("running_mean", torch.zeros(nPlanes))
+        self.register_buffer("running_var", torch.ones(nPlanes))
+        if affine:
+            self.weight = Parameter(torch.ones(nPlanes))
+            self.bias = Parameter(torch.zeros(nPlanes))
+
+    def forward(self, input):
+        assert input.features.nelement() == 0 or input.features.size(1) == self.nPlanes, \
+            (self.nPlanes, input.features.shape)
+        output = SparseConvNetTensor(metadata=input.metadata, spatial_size=input.spatial_size)
+        output.features = _BatchNormFunction.apply(
+            input.features, optionalTensor(self, "weight"), optionalTensor(self, "bias"), self.running_mean,
+            self.running_var, self.eps, self.momentum, self.training, self.leakiness)
+        return output
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+    def _name(self):
+        return "BatchNorm"
+
+    def __repr__(self):
+        s = "%s(%d,eps=%s,momentum=%s,affine=%s" % (self._name(), self.nPlanes, self.eps, self.momentum, self.affine)
+        if self.leakiness > 0 and type(self) is not BatchNormReLU:
+            s += ",leakiness=%s" % self.leakiness
+        return s + ")"
+
+
+class BatchNormReLU(BatchNormalization):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9):
+        BatchNormalization.__init__(self, nPlanes, eps, momentum, True, 0)
+
+    def _name(self):
+        return "BatchNormReLU"
+
+
+class BatchNormLeakyReLU(BatchNormalization):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, leakiness=0.333):
+        BatchNormalization.__init__(self, nPlanes, eps, momentum, True, leakiness)
+
+    def _name(self):
+        return "BatchNormLeakyReLU"

@@ -1,0 +1,74 @@
+"""Value type and small helpers of the operator API.
+
+Mirrors sparseconvnet/sparseConvNetTensor.py:13-26, sparseconvnet/metadata.py:16-17 and
+sparseconvnet/utils.py:13-28 (behaviour, not text).
+"""
+import torch
+
+from .. import SCN
+
+
+def Metadata(dim):
+    """factory used by InputLayer (sparseconvnet/metadata.py:16-17)"""
+    if dim != 3:
+        raise NotImplementedError("only dimension 3 is reachable in the reference GPU path "
+                                  "(sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cpp:40-44)")
+    return SCN.Metadata_3()
+
+
+class SparseConvNetTensor(object):
+    """features [N, planes] + the shared Metadata + the spatial size of the grid."""
+
+    def __init__(self, features=None, metadata=None, spatial_size=None):
+        self.features = features
+        self.metadata = metadata
+        self.spatial_size = spatial_size
+
+    def get_spatial_locations(self, spatial_size=None):
+        """LongTensor [N,4]: coordinates and batch index of the active sites"""
+        size = self.spatial_size if spatial_size is None else spatial_size
+        return self.metadata.getSpatialLocations(size)
+
+    def type(self, t=None):
+        if t is None:
+            return self.features.type()
+        self.features = self.features.type(t)
+        return self
+
+    def cuda(self):
+        self.features = self.features.cuda()
+        return self
+
+    def cpu(self):
+        self.features = self.features.cpu()
+        return self
+
+    def __repr__(self):
+        return "SparseConvNetTensor<<features.shape=%r, spatial size=%r>>" % (
+            None if self.features is None else tuple(self.features.shape), self.spatial_size)
+
+
+def toLongTensor(dimension, x):
+    """int | list | LongTensor -> LongTensor[dimension] (sparseconvnet/utils.py:13-20)"""
+    if torch.is_tensor(x) and x.dtype == torch.int64 and not x.is_cuda:
+        return x
+    if isinstance(x, (list, tuple)):
+        assert len(x) == dimension
+        return torch.tensor(list(x), dtype=torch.int64)
+    return torch.full((dimension,), int(x), dtype=torch.int64)
+
+
+def optionalTensor(module, name):
+    """missing parameter -> zero-element tensor, read as NULL by the backend
+    (sparseconvnet/utils.py:23-24, sparseconvnet/SCN/Metadata/Metadata.cpp:28-30)"""
+    t = getattr(module, name, None)
+    return t if t is not None else torch.Tensor()
+
+
+def optionalTensorReturn(t):
+    return t if t.numel() else None
+
+
+def like_empty(t):
+    """the `input_features.new()` of the reference: an empty tensor on the same device"""
+    return torch.empty(0, dtype=t.dtype, device=t.device)

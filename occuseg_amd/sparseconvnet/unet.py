@@ -1,0 +1,44 @@
+"""scn.UNet -- the network the headline metric is defined on.
+
+Same module tree (hence the same state_dict keys) as sparseconvnet/networkArchitectures.py:202-306:
+per level  block* ; ConcatTable(Identity, BN -> Conv 2/2 -> U(next) -> BN -> Deconv 2/2) ; JoinTable ; block*,
+residual block = ConcatTable(Identity | NiN, BN -> SC3 -> BN -> SC3) -> AddTable.
+"""
+from .containers import AddTable, ConcatTable, Identity, JoinTable, NetworkInNetwork, Sequential
+from .conv import Convolution, Deconvolution, SubmanifoldConvolution
+from .norm import BatchNormLeakyReLU
+
+
+def UNet(dimension, reps, nPlanes, residual_blocks=False, downsample=[2, 2], leakiness=0):
+    def bn(n):
+        return BatchNormLeakyReLU(n, leakiness=leakiness)
+
+    def sc(a, b):
+        return SubmanifoldConvolution(dimension, a, b, 3, False)
+
+    def add_block(m, a, b):
+        if residual_blocks:  # ResNet style
+            shortcut = Identity() if a == b else NetworkInNetwork(a, b, False)
+            body = Sequential().add(bn(a)).add(sc(a, b)).add(bn(b)).add(sc(b, b))
+            m.add(ConcatTable().add(shortcut).add(body)).add(AddTable())
+        else:  # VGG style
+            m.add(Sequential().add(bn(a)).add(sc(a, b)))
+
+    def level(planes):
+        m = Sequential()
+        for _ in range(reps):
+            add_block(m, planes[0], planes[0])
+        if len(planes) > 1:
+            down_up = (Sequential()
+                       .add(bn(planes[0]))
+                       .add(Convolution(dimension, planes[0], planes[1], downsample[0], downsample[1], False))
+                       .add(level(planes[1:]))
+                       .add(bn(planes[1]))
+                       .add(Deconvolution(dimension, planes[1], planes[0], downsample[0], downsample[1], False)))
+            m.add(ConcatTable().add(Identity()).add(down_up))
+            m.add(JoinTable())
+            for i in range(reps):
+                add_block(m, planes[0] * (2 if i == 0 else 1), planes[0])
+        return m
+
+    return level(list(nPlanes))

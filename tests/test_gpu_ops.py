@@ -1,0 +1,178 @@
+"""-m gpu: gather-mm-scatter, batch norm and I/O layers through the SCN boundary vs the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, build_metadata, random_points
+
+pytestmark = pytest.mark.gpu
+
+F3 = torch.tensor([3, 3, 3])
+F2 = torch.tensor([2, 2, 2])
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def _setup(gpu, seed=0, n=3000, batch=2, extent=24):
+    from oracle import rules as R
+    coords = random_points(seed, n, batch, extent, origin=3)
+    m, size = build_metadata(coords, gpu)
+    grid, header, table, sop = R.input_layer_rules(coords)
+    return m, size, grid, table, coords
+
+
+# (Ci, Co): MFMA tile path (multiples of 16, NW = 4/3/2/1), Ci chunking (>64), generic path (3, 5, 20)
+PLANES = [(16, 16), (32, 64), (64, 64), (64, 48), (48, 32), (128, 64), (80, 16), (3, 32), (5, 7), (20, 24)]
+
+
+@pytest.mark.parametrize("ci,co", PLANES)
+def test_submanifold_fwd_bwd(gpu, ci, co):
+    from occuseg_amd import SCN
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu)
+    rules, _ = R.submanifold_rules(grid)
+    rng = np.random.default_rng(ci * 100 + co)
+    x = rng.normal(size=(grid.n, ci)).astype(np.float32)
+    w = (rng.normal(size=(27, ci, co)) * (2.0 / ci / 27) ** 0.5).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    dy = rng.normal(size=(grid.n, co)).astype(np.float32)
+    for bias in (None, b):
+        want, macs = A.conv_forward(x, w, rules, grid.n, bias, dtype=np.float64)
+        out = torch.empty(0, device=gpu)
+        bt = _t(bias, gpu) if bias is not None else torch.empty(0, device=gpu)
+        got_macs = SCN.SubmanifoldConvolution_updateOutput(size, F3, m, _t(x, gpu), out, _t(w, gpu), bt, 1)
+        assert got_macs == macs
+        assert_close(out.cpu().numpy(), want, "submanifold fwd %d->%d" % (ci, co))
+    d_in, d_w, d_b = A.conv_backward(x, dy, w, rules, want_bias=True, dtype=np.float64)
+    gi = torch.empty(0, device=gpu)
+    gw = torch.zeros(27, ci, co, device=gpu)
+    gb = torch.zeros(co, device=gpu)
+    SCN.SubmanifoldConvolution_backward(size, F3, m, _t(x, gpu), gi, _t(dy, gpu), _t(w, gpu), gw, gb, 1)
+    assert_close(gi.cpu().numpy(), d_in, "submanifold dInput")
+    assert_close(gw.cpu().numpy(), d_w, "submanifold dWeight")
+    assert_close(gb.cpu().numpy(), d_b, "submanifold dBias")
+
+
+@pytest.mark.parametrize("ci,co", [(16, 32), (64, 128), (96, 64), (32, 48), (3, 8), (128, 192)])
+def test_conv_deconv_fwd_bwd(gpu, ci, co):
+    from occuseg_amd import SCN
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu, seed=1)
+    coarse, rules, _ = R.strided_rules(grid)
+    out_size = size // 2
+    rng = np.random.default_rng(ci + co)
+    x = rng.normal(size=(grid.n, ci)).astype(np.float32)
+    w = (rng.normal(size=(8, ci, co)) * (2.0 / ci / 8) ** 0.5).astype(np.float32)
+    dy = rng.normal(size=(coarse.n, co)).astype(np.float32)
+    empty = torch.empty(0, device=gpu)
+    # strided convolution: fine -> coarse
+    want, macs = A.conv_forward(x, w, rules, coarse.n, dtype=np.float64)
+    out = torch.empty(0, device=gpu)
+    got_macs = SCN.Convolution_updateOutput(size, out_size, F2, F2, m, _t(x, gpu), out, _t(w, gpu), empty)
+    assert got_macs == macs and out.shape == (coarse.n, co)
+    assert_close(out.cpu().numpy(), want, "conv fwd")
+    d_in, d_w, _ = A.conv_backward(x, dy, w, rules, dtype=np.float64)
+    gi, gw = torch.empty(0, device=gpu), torch.zeros(8, ci, co, device=gpu)
+    SCN.Convolution_backward(size, out_size, F2, F2, m, _t(x, gpu), gi, _t(dy, gpu), _t(w, gpu), gw, empty)
+    assert_close(gi.cpu().numpy(), d_in, "conv dInput")
+    assert_close(gw.cpu().numpy(), d_w, "conv dWeight")
+    # deconvolution: coarse -> fine, own weights [8, co, ci], same rulebook with columns swapped
+    xd = rng.normal(size=(coarse.n, co)).astype(np.float32)
+    wd = (rng.normal(size=(8, co, ci)) * (2.0 / co / 8) ** 0.5).astype(np.float32)
+    dyd = rng.normal(size=(grid.n, ci)).astype(np.float32)
+    want, macs = A.conv_forward(xd, wd, rules, grid.n, in_col=1, out_col=0, dtype=np.float64)
+    out = torch.empty(0, device=gpu)
+    SCN.Deconvolution_updateOutput(out_size, size, F2, F2, m, _t(xd, gpu), out, _t(wd, gpu), empty)
+    assert_close(out.cpu().numpy(), want, "deconv fwd")
+    d_in, d_w, _ = A.conv_backward(xd, dyd, wd, rules, in_col=1, out_col=0, dtype=np.float64)
+    gi, gw = torch.empty(0, device=gpu), torch.zeros(8, co, ci, device=gpu)
+    SCN.Deconvolution_backward(out_size, size, F2, F2, m, _t(xd, gpu), gi, _t(dyd, gpu), _t(wd, gpu), gw, empty)
+    assert_close(gi.cpu().numpy(), d_in, "deconv dInput")
+    assert_close(gw.cpu().numpy(), d_w, "deconv dWeight")
+
+
+@pytest.mark.parametrize("n,c", [(8192, 16), (5000, 64), (2, 16), (70001, 96), (333, 7), (1200, 768)])
+@pytest.mark.parametrize("leak", [0.0, 0.333, 1.0])
+def test_batchnorm(gpu, n, c, leak):
+    from occuseg_amd import SCN
+    from oracle import arith as A
+    rng = np.random.default_rng(n + c)
+    x = (rng.normal(size=(n, c)) * rng.uniform(0.5, 2, c) + rng.normal(size=c)).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    b = rng.normal(size=c).astype(np.float32)
+    rm0 = rng.normal(size=c).astype(np.float32)
+    rv0 = rng.uniform(0.5, 2, c).astype(np.float32)
+    dy = rng.normal(size=(n, c)).astype(np.float32)
+    for train in (True, False):
+        y, mean, invstd, rm, rv = A.batchnorm_forward(x, g, b, rm0, rv0, 1e-4, 0.9, train, leak, dtype=np.float64)
+        out, sm, si = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+        rmt, rvt = _t(rm0, gpu), _t(rv0, gpu)
+        SCN.BatchNormalization_updateOutput(_t(x, gpu), out, sm, si, rmt, rvt, _t(g, gpu), _t(b, gpu), 1e-4, 0.9,
+                                            train, leak)
+        assert_close(out.cpu().numpy(), y, "bn y train=%s" % train)
+        assert_close(sm.cpu().numpy(), mean, "bn saveMean")
+        assert_close(si.cpu().numpy(), invstd, "bn saveInvStd")
+        assert_close(rmt.cpu().numpy(), rm, "bn running_mean")
+        assert_close(rvt.cpu().numpy(), rv, "bn running_var")
+        if train:
+            d_in, d_masked, d_g, d_b = A.batchnorm_backward(x, y, dy, mean, invstd, g, leak, dtype=np.float64)
+            gi, gg, gb = torch.empty(0, device=gpu), torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
+            dyt = _t(dy, gpu)
+            SCN.BatchNormalization_backward(_t(x, gpu), gi, out, dyt, sm, si, rmt, rvt, _t(g, gpu), _t(b, gpu),
+                                            gg, gb, leak)
+            assert_close(gi.cpu().numpy(), d_in, "bn dInput")
+            assert_close(gg.cpu().numpy(), d_g, "bn dWeight")
+            assert_close(gb.cpu().numpy(), d_b, "bn dBias")
+            # the reference contract: d_output_features is rewritten in place (BatchNormalization.cu:151-153)
+            assert_close(dyt.cpu().numpy(), d_masked, "bn masked dOut written back")
+
+
+def test_batchnorm_no_affine(gpu):
+    from occuseg_amd import SCN
+    from oracle import arith as A
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(900, 32)).astype(np.float32)
+    y, mean, invstd, rm, rv = A.batchnorm_forward(x, None, None, np.zeros(32), np.ones(32), dtype=np.float64)
+    e = torch.empty(0, device=gpu)
+    out, sm, si = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+    SCN.BatchNormalization_updateOutput(_t(x, gpu), out, sm, si, torch.zeros(32, device=gpu),
+                                        torch.ones(32, device=gpu), e, e, 1e-4, 0.9, True, 1.0)
+    assert_close(out.cpu().numpy(), y, "bn no affine")
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("c", [3, 16])
+def test_io_layers(gpu, mode, c):
+    from occuseg_amd import SCN
+    from oracle import arith as A, rules as R
+    coords = random_points(3, 2000, 3, 12)
+    grid, header, table, sop = R.input_layer_rules(coords, mode=mode)
+    rng = np.random.default_rng(mode * 10 + c)
+    feats = rng.normal(size=(len(coords), c)).astype(np.float32)
+    m = SCN.Metadata_3()
+    size = torch.tensor([4096] * 3)
+    out = torch.empty(0, device=gpu)
+    SCN.InputLayer_updateOutput(m, size, torch.from_numpy(coords), _t(feats, gpu), out, 0, mode, None)
+    assert_close(out.cpu().numpy(), A.input_layer_forward(feats, table, mode, np.float64), "input fwd")
+    d_out = rng.normal(size=(grid.n, c)).astype(np.float32)
+    gi = torch.empty(0, device=gpu)
+    SCN.InputLayer_updateGradInput(m, gi, _t(d_out, gpu))
+    assert_close(gi.cpu().numpy(), A.input_layer_backward(d_out, table, len(coords), mode, np.float64), "input bwd")
+    # output layer: site row copied to every original point; backward sums them back
+    o = torch.empty(0, device=gpu)
+    SCN.OutputLayer_updateOutput(m, _t(d_out, gpu), o)
+    assert np.array_equal(o.cpu().numpy(), A.output_layer_forward(d_out, table, len(coords)))
+    g2 = torch.empty(0, device=gpu)
+    SCN.OutputLayer_updateGradInput(m, g2, _t(feats, gpu))
+    assert_close(g2.cpu().numpy(), A.output_layer_backward(feats, table, np.float64), "output bwd")
+
+
+def test_cpu_tensors_are_refused():
+    """no CPU fallback: the product path fails loudly instead of computing on the host"""
+    from occuseg_amd import SCN
+    x = torch.zeros(4, 16)
+    with pytest.raises(RuntimeError):
+        SCN.BatchNormalization_updateOutput(x, torch.empty(0), torch.empty(0), torch.empty(0), torch.zeros(16),
+                                            torch.ones(16), torch.empty(0), torch.empty(0), 1e-4, 0.9, True, 1.0)

@@ -1,0 +1,76 @@
+"""-m gpu: rulebook indices must be BIT-EXACT against the oracle (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_metadata, random_points
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    from occuseg_amd import scenes
+    edge = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [1023, 2047, 1023, 0],
+                     [1022, 2047, 1023, 0], [1023, 2046, 1022, 0], [5, 5, 5, 0], [5, 5, 5, 0], [5, 5, 5, 0],
+                     [0, 0, 0, 1], [1, 1, 1, 1], [1, 1, 1, 1], [2, 2, 2, 1], [3, 3, 3, 1]], np.int64)
+    yield "edges+dups", edge
+    yield "single-point", np.array([[7, 8, 9]], np.int64)
+    yield "dense-8cube-2samples", random_points(0, 400, 2, 8)
+    yield "sparse-3samples", random_points(1, 300, 3, 40, origin=10)
+    g = scenes.bernoulli_grid(32, 0.25, 0)
+    yield "bernoulli32", g
+    c, _ = scenes.batch([1000, 1001], target_sites=8000)
+    yield "scene-2x8k", c
+
+
+@pytest.mark.parametrize("name,coords", list(_cases()), ids=[n for n, _ in _cases()])
+def test_rulebooks_bit_exact(gpu, name, coords):
+    from oracle import rules as R
+    m, size = build_metadata(coords, gpu)
+    grid, header, table, site_of_point = R.input_layer_rules(coords)
+    # site order and coordinates
+    loc = m.getSpatialLocations(size).numpy()
+    assert loc.shape == grid.coords.shape
+    assert np.array_equal(loc, grid.coords)
+    # input rules (header + rows; padding beyond cnt is unspecified in the reference, 0 in both here)
+    h, t = m.getInputRulesHost()
+    assert np.array_equal(h, header)
+    assert np.array_equal(t, table)
+    assert np.array_equal(m.input_site_of_row.cpu().numpy().astype(np.int64), site_of_point)
+    f3 = torch.tensor([3, 3, 3])
+    f2 = torch.tensor([2, 2, 2])
+    for level in range(4):
+        rb = m.getSubmanifoldRuleBook(size, f3)
+        want, nbr = R.submanifold_rules(grid)
+        got = rb.host_lists()
+        for k in range(27):
+            assert np.array_equal(got[k], want[k]), (name, level, k)
+        assert np.array_equal(rb.nbr.cpu().numpy().T, nbr)
+        if int(size[0]) % 2 or grid.n == 0:
+            break
+        out_size = size // 2
+        rb2 = m.getRuleBook(size, out_size, f2, f2)
+        coarse, want2, child = R.strided_rules(grid)
+        got2 = rb2.host_lists()
+        for k in range(8):
+            assert np.array_equal(got2[k], want2[k]), (name, level, k)
+        assert m.getNActive(out_size) == coarse.n
+        assert np.array_equal(m.getSpatialLocations(out_size).numpy(), coarse.coords)
+        # tile-base tables: lower bounds on the output column at granules of 32 rows
+        for col, n_out in ((1, coarse.n), (0, grid.n)):
+            bases = rb2.bases[col].cpu().numpy()
+            for k in range(8):
+                ref = np.searchsorted(want2[k][:, col], np.arange(bases.shape[1]) * 32, side="left")
+                assert np.array_equal(bases[k], ref)
+        grid, size = coarse, out_size
+
+
+def test_out_of_box_is_an_error(gpu):
+    from occuseg_amd import SCN
+    m = SCN.Metadata_3()
+    bad = torch.tensor([[1024, 0, 0, 0]], dtype=torch.int64)
+    with pytest.raises(RuntimeError):
+        m.inputLayer(torch.tensor([4096] * 3), bad, 0, 4, gpu)
+    neg = torch.tensor([[0, -1, 0, 0]], dtype=torch.int64)
+    with pytest.raises(RuntimeError):
+        m.inputLayer(torch.tensor([4096] * 3), neg, 0, 4, gpu)
