@@ -21,7 +21,7 @@ class _RuleConvFunction(Function):
     @staticmethod
     def forward(ctx, features, weight, bias, kind, metadata, in_size, out_size, filter_size, filter_stride,
                 dilated_rate):
-        ctx.kind, ctx.metadata, ctx.dilated_rate = kind, metadata, dilated_rate
+        ctx.kind, ctx.scn_meta, ctx.dilated_rate = kind, metadata, dilated_rate
         ctx.sizes = (in_size, out_size, filter_size, filter_stride)
         out = like_empty(features)
         if kind == "submanifold":
@@ -46,7 +46,7 @@ class _RuleConvFunction(Function):
         grad_input = like_empty(grad_output) if ctx.needs_input_grad[0] else None
         grad_weight = torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
-        m = ctx.metadata
+        m = ctx.scn_meta
         if ctx.kind == "submanifold":
             SCN.SubmanifoldConvolution_backward(in_size, filter_size, m, features, grad_input, grad_output, weight,
                                                 grad_weight, grad_bias, ctx.dilated_rate)
@@ -56,7 +56,7 @@ class _RuleConvFunction(Function):
         else:
             SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
                                        grad_output, weight, grad_weight, grad_bias)
-        ctx.metadata = None
+        ctx.scn_meta = None
         return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7
 
 

@@ -16,7 +16,7 @@ from .tensor import Metadata, SparseConvNetTensor, like_empty, toLongTensor
 class _InputLayerFunction(Function):
     @staticmethod
     def forward(ctx, features, metadata, spatial_size, coords, batch_size, mode, normals, normal_guide_scale):
-        ctx.metadata = metadata
+        ctx.scn_meta = metadata
         out = like_empty(features)
         metadata.setNormalGuideScale(normal_guide_scale)
         SCN.InputLayer_updateOutput(metadata, spatial_size, coords, features.contiguous(), out, batch_size, mode,
@@ -26,15 +26,15 @@ class _InputLayerFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         grad_input = like_empty(grad_output)
-        SCN.InputLayer_updateGradInput(ctx.metadata, grad_input, grad_output.contiguous())
-        ctx.metadata = None
+        SCN.InputLayer_updateGradInput(ctx.scn_meta, grad_input, grad_output.contiguous())
+        ctx.scn_meta = None
         return (grad_input,) + (None,) * 7
 
 
 class _OutputLayerFunction(Function):
     @staticmethod
     def forward(ctx, features, metadata):
-        ctx.metadata = metadata
+        ctx.scn_meta = metadata
         out = like_empty(features)
         SCN.OutputLayer_updateOutput(metadata, features.contiguous(), out)
         return out
@@ -42,8 +42,8 @@ class _OutputLayerFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         grad_input = like_empty(grad_output)
-        SCN.OutputLayer_updateGradInput(ctx.metadata, grad_input, grad_output.contiguous())
-        ctx.metadata = None
+        SCN.OutputLayer_updateGradInput(ctx.scn_meta, grad_input, grad_output.contiguous())
+        ctx.scn_meta = None
         return grad_input, None
 
 

@@ -5,7 +5,7 @@ import torch
 REL_TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 relative on fp32 features"
 
 
-def assert_close(got, want, what="", rel=REL_TOL):
+def assert_close(got, want, what="", rel=REL_TOL, scale=None):
     """|got - want| <= rel * max|want| elementwise (tolerance scaled by the tensor's
     magnitude: elements that cancel to ~0 cannot be held to a per-element ratio,
     SURVEY.md section 7 'Hard parts')."""
@@ -14,7 +14,7 @@ def assert_close(got, want, what="", rel=REL_TOL):
     assert got.shape == want.shape, (what, got.shape, want.shape)
     if want.size == 0:
         return
-    scale = max(float(np.abs(want).max()), 1e-30)
+    scale = max(float(np.abs(want).max()), 1e-30) if scale is None else float(scale)
     err = float(np.abs(got - want).max())
     assert np.isfinite(got).all(), what + ": non-finite values"
     assert err <= rel * scale, "%s: max abs err %.3e > %.1e * max|ref| %.3e" % (what, err, rel, scale)

@@ -117,12 +117,18 @@ def test_batchnorm(gpu, n, c, leak):
         assert_close(rmt.cpu().numpy(), rm, "bn running_mean")
         assert_close(rvt.cpu().numpy(), rv, "bn running_var")
         if train:
-            d_in, d_masked, d_g, d_b = A.batchnorm_backward(x, y, dy, mean, invstd, g, leak, dtype=np.float64)
+            # backward takes output_features as an INPUT (the ReLU mask is y > 0): give the oracle the y the
+            # device produced, otherwise elements with |y| ~ 1e-8 flip the mask and differ by a whole d_out
+            d_in, d_masked, d_g, d_b = A.batchnorm_backward(x, out.cpu().numpy(), dy, mean, invstd, g, leak,
+                                                            dtype=np.float64)
             gi, gg, gb = torch.empty(0, device=gpu), torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
             dyt = _t(dy, gpu)
             SCN.BatchNormalization_backward(_t(x, gpu), gi, out, dyt, sm, si, rmt, rvt, _t(g, gpu), _t(b, gpu),
                                             gg, gb, leak)
-            assert_close(gi.cpu().numpy(), d_in, "bn dInput")
+            # dInput = (d - mean(d) - (x-mu)k) * invstd * gamma cancels heavily when N is tiny (for N=2 it is
+            # analytically ~0): hold it to 1e-4 of the magnitude of its terms, not of the cancelled result
+            term = float(np.abs(d_masked * invstd * g).max())
+            assert_close(gi.cpu().numpy(), d_in, "bn dInput", scale=max(term, float(np.abs(d_in).max())))
             assert_close(gg.cpu().numpy(), d_g, "bn dWeight")
             assert_close(gb.cpu().numpy(), d_b, "bn dBias")
             # the reference contract: d_output_features is rewritten in place (BatchNormalization.cu:151-153)

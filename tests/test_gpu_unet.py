@@ -1,0 +1,52 @@
+"""-m gpu: the ScanNet UNet (InputLayer -> stem -> scn.UNet -> BNReLU -> OutputLayer) end to end,
+forward + backward, against the float64 torch-autograd oracle on the same seeded scene."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(scn, m, levels, leak):
+    planes = [m * (i + 1) for i in range(levels)]
+    return scn.Sequential().add(scn.InputLayer(3, 4096, mode=4)).add(
+        scn.SubmanifoldConvolution(3, 3, m, 3, False)).add(
+        scn.UNet(3, 1, planes, residual_blocks=True, leakiness=leak)).add(
+        scn.BatchNormReLU(m)).add(scn.OutputLayer(3))
+
+
+@pytest.mark.parametrize("m,levels,leak", [(16, 3, 0.0), (32, 4, 0.2)])
+def test_unet_forward_backward(gpu, m, levels, leak):
+    import occuseg_amd
+    from occuseg_amd import scenes
+    from oracle import torch_ref
+    scn = occuseg_amd.install()
+    torch.manual_seed(m)
+    coords, feats = scenes.batch([1000, 1001], target_sites=5000)
+    net = _net(scn, m, levels, leak)
+    ref_out, stats = torch_ref.ref_forward(net, coords, feats, torch.float64)
+    gsel = torch.from_numpy(np.random.default_rng(0).normal(size=tuple(ref_out.shape)))
+    (ref_out * gsel).sum().backward()
+
+    net = net.to(gpu)
+    scn.forward_pass_multiplyAdd_count = 0
+    out = net([torch.from_numpy(coords), torch.from_numpy(feats).to(gpu), None, 2])
+    (out * gsel.to(gpu, torch.float32)).sum().backward()
+    assert scn.forward_pass_multiplyAdd_count > 0
+    assert_close(out.detach().cpu().numpy(), ref_out.detach().numpy(), "UNet output")
+    # gradients: one ReLU-mask flip (|y| ~ 1e-7 has a different sign in fp32 and fp64) moves a summed
+    # gradient by one term, so the bar for sums over ~1e4 sites is 1e-3 of the tensor's magnitude
+    for mod in net.modules():
+        ref = stats["params"].get(id(mod))
+        if not ref:
+            continue
+        for name, leaf in ref.items():
+            got = getattr(mod, name).grad
+            assert got is not None, (mod, name)
+            assert_close(got.cpu().numpy(), leaf.grad.numpy(), "grad %s.%s" % (mod, name), rel=1e-3)
+        if id(mod) in stats["bn"]:
+            mean, var = stats["bn"][id(mod)]
+            assert_close(mod.running_mean.cpu().numpy(), (0.1 * mean).numpy(), "running_mean")
+            assert_close(mod.running_var.cpu().numpy(), (0.9 + 0.1 * var).numpy(), "running_var")
