@@ -19,6 +19,25 @@ from ._lib import check, ptr, stream
 
 GRANULE = 32  # SCN_TILE_GRANULE
 
+# When set to a list, every gather-mm launch appends (kernel, flops, bytes, start_event, end_event):
+# used by bench.py to time the dominant kernels with HIP events on the launch stream.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _prof_end(ev, kernel, flops, nbytes):
+    if ev is not None:
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        PROFILE.append((kernel, flops, nbytes, ev, end))
+
 
 def _lib_():
     return _lib.load()
@@ -249,9 +268,14 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out):
     assert K == rb.K, (K, rb.K)
     assert inp.is_contiguous() and weight.is_contiguous()
     out.resize_(n_out, Co)
+    ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), ptr(bias) if bias is not None and bias.numel() else None,
                                ptr(rb.rules), ptr(rb.bases[out_col]), K, rb.stride, in_col, out_col, n_out,
                                Ci, Co, stream()))
+    # algorithmic work of one launch: flops = 2 R Ci Co;
+    # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
+    R = rb.total_pairs
+    _prof_end(ev, "conv_tile", 2.0 * R * Ci * Co, 4.0 * (R * Ci + n_out * Co) + 8.0 * R + 4.0 * K * Ci * Co)
 
 
 def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse):
@@ -269,8 +293,11 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
         else:
             _conv(d_out, d_in, wt, None, rb, out_col, in_col, n_in)
     if d_weight is not None and d_weight.numel():
+        ev = _prof_begin()
         check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts), K,
                                    rb.stride, in_col, out_col, Ci, Co, stream()))
+        R = rb.total_pairs
+        _prof_end(ev, "dw_tile", 2.0 * R * Ci * Co, 4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co)
     if d_bias is not None and d_bias.numel():
         check(lib.scn_column_sum(ptr(d_out), ptr(d_bias), d_out.size(0), Co, stream()))
 

@@ -55,8 +55,8 @@ def scene_points(seed, target_sites=150_000, scale=50, pts_per_voxel=2.5, noise_
     rects0 = _surfaces(np.random.default_rng(seed), 1.0)
     area0 = sum(np.linalg.norm(np.cross(u, v)) for _, u, v in rects0)
     vox_area = (1.0 / scale) ** 2
-    # effective thickness/occupancy factor ~1.15 found empirically for noise_vox=0.35
-    s = np.sqrt(target_sites * vox_area / (1.15 * area0))
+    # effective thickness/occupancy factor ~1.34 found empirically for noise_vox=0.35, 2.5 pts/voxel
+    s = np.sqrt(target_sites * vox_area / (1.34 * area0))
     rects = _surfaces(np.random.default_rng(seed), s)
     areas = np.array([np.linalg.norm(np.cross(u, v)) for _, u, v in rects])
     n_total = int(pts_per_voxel * areas.sum() / vox_area)

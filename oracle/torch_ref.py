@@ -13,6 +13,8 @@ Used (a) in float64 as the end-to-end parity reference of tests, (b) in float32
 with all host cores as ``bench.py``'s ``cpu_baseline`` ("port": same
 gather/sgemm/scatter work as the reference CPU path, at::mm == torch.mm).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -23,26 +25,32 @@ class _Ctx(object):
     """oracle Metadata: grids and rulebooks per spatial size"""
 
     def __init__(self, coords, mode):
+        t0 = time.perf_counter()
         self.grid0, self.header, self.table, self.site_of_point = R.input_layer_rules(coords, mode=mode)
         self.grids = {}
         self.sub = {}
         self.strided = {}
         self.n_points = len(coords)
         self.mode = mode
+        self.rule_seconds = time.perf_counter() - t0  # time spent generating rulebooks (numpy)
 
     def submanifold(self, size):
         if size not in self.sub:
+            t0 = time.perf_counter()
             rules, _ = R.submanifold_rules(self.grids[size])
             self.sub[size] = [(torch.from_numpy(r[:, 0].astype(np.int64)), torch.from_numpy(r[:, 1].astype(np.int64)))
                               for r in rules]
+            self.rule_seconds += time.perf_counter() - t0
         return self.sub[size]
 
     def conv(self, fine_size, coarse_size):
         if fine_size not in self.strided:
+            t0 = time.perf_counter()
             coarse, rules, _ = R.strided_rules(self.grids[fine_size])
             self.grids[coarse_size] = coarse
             self.strided[fine_size] = [(torch.from_numpy(r[:, 0].astype(np.int64)),
                                         torch.from_numpy(r[:, 1].astype(np.int64))) for r in rules]
+            self.rule_seconds += time.perf_counter() - t0
         return self.strided[fine_size]
 
 
