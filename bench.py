@@ -37,6 +37,18 @@ def build_net(scn, m):
         scn.BatchNormReLU(m)).add(scn.OutputLayer(3))
 
 
+def host_cores():
+    """cores this process may really use: min(affinity mask, cgroup v2 cpu.max quota)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _cpu_once(scn, m, target_sites, seed):
     from occuseg_amd import scenes
     from oracle import torch_ref
@@ -58,7 +70,7 @@ def cpu_baseline(m, target_sites, seed, budget_s=20.0):
     generator is not the reference's algorithm)."""
     import occuseg_amd
     scn = occuseg_amd.install()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     n0, dt = _cpu_once(scn, m, 10000, seed)
     want = int(min(target_sites, max(10000, budget_s * n0 / dt)))
