@@ -109,16 +109,27 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
                    int out_col, int64_t n_out, int32_t *bases, void *stream);
 
 /* ------------------------------------------------------- gather-mm-scatter ---
- * out[o,:] = (bias) + sum_k sum_{pairs of list k} in[pair.in_col,:] . W[k]
+ * out[o,:] = (bias) + sum_k sum_{pairs of list k} in[pair.in_col,:] . Wk
  * Replaces cuda_SubmanifoldConvolution_updateOutput / cuda_Convolution_updateOutput /
  * cuda_Deconvolution_updateOutput (sparseconvnet/SCN/CUDA/Convolution.cpp:36-66,:105-162;
- * sparseconvnet/SCN/CUDA/Deconvolution.cpp:20-49) and, with transposed weights, the dInput half
- * of the matching *_backward.  W is [K][Ci][Co] row major.  `out` is fully overwritten.
- * in_col/out_col: 0/1 for conv + submanifold, 1/0 for deconvolution
- * (sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49). */
-int scn_conv_forward(const float *in, float *out, const float *W, const float *bias,
-                     const int32_t *rules, const int32_t *bases, int K, int64_t stride,
-                     int in_col, int out_col, int64_t n_out, int Ci, int Co, void *stream);
+ * sparseconvnet/SCN/CUDA/Deconvolution.cpp:20-49) and the dInput half of the matching *_backward
+ * (sparseconvnet/SCN/CUDA/Convolution.cpp:69-102,:165-210).  `out` is fully overwritten.
+ *   Ci = planes of `in`, Co = planes of `out`.
+ *   Wk[ci][co] = w_transposed ? W[ks][co][ci] : W[ks][ci][co],  ks = w_reverse ? K-1-k : k,
+ *   where W is the module's weight [K][Ci][Co] (forward) or [K][Co][Ci] (dInput: w_transposed = 1;
+ *   submanifold dInput additionally w_reverse = 1 and the SAME lists, because
+ *   (i,o) in list k  <=>  (o,i) in list 26-k).
+ *   in_col/out_col: 0/1 for conv + submanifold, 1/0 for deconvolution
+ *   (sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49); bases = scn_tile_bases(.., out_col, n_out).
+ *   wpack: scn_conv_wpack_bytes(K,Ci,Co) bytes of scratch (weights re-laid out in MFMA fragment order). */
+size_t scn_conv_wpack_bytes(int K, int Ci, int Co);
+int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
+                     const float *bias, const int32_t *rules, const int32_t *bases, int K,
+                     int64_t stride, int in_col, int out_col, int64_t n_out, int Ci, int Co,
+                     void *wpack, void *stream);
+
+/* debugging aid for A/B runs: key 0 = gather-mm kernel variant (1 synchronous, 2 pipelined [default]) */
+int scn_set_tuning(int key, int value);
 
 /* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller,
  * as the reference's callers do: sparseconvnet/submanifoldConvolution.py:114-115).
@@ -126,10 +137,6 @@ int scn_conv_forward(const float *in, float *out, const float *W, const float *b
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, int K, int64_t stride, int in_col, int out_col,
                      int Ci, int Co, void *stream);
-
-/* Wt[k][co][ci] = W[reverse ? K-1-k : k][ci][co] */
-int scn_weight_transpose(const float *W, float *Wt, int K, int Ci, int Co, int reverse,
-                         void *stream);
 
 /* column sums: d_bias[c] = sum_rows dOut[r][c] (sparseconvnet/SCN/CUDA/Convolution.cu:52-75) */
 int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream);

@@ -262,16 +262,21 @@ class Metadata_3(object):
 
 
 # ----------------------------------------------------------------- helpers ---
-def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out):
+def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False):
+    """out = gather-mm-scatter over rb; weight is the module's [K, a, b] tensor, used as [K, Ci, Co]
+    (forward) or, with w_transposed, as its per-offset transpose (dInput)."""
     lib = _lib_()
-    K, Ci, Co = weight.shape
+    K = weight.size(0)
+    Ci, Co = (weight.size(2), weight.size(1)) if w_transposed else (weight.size(1), weight.size(2))
     assert K == rb.K, (K, rb.K)
-    assert inp.is_contiguous() and weight.is_contiguous()
+    assert inp.is_contiguous() and weight.is_contiguous() and inp.size(1) == Ci
     out.resize_(n_out, Co)
+    wpack = torch.empty(K * Ci * Co, dtype=torch.float32, device=inp.device)
     ev = _prof_begin()
-    check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), ptr(bias) if bias is not None and bias.numel() else None,
+    check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
+                               ptr(bias) if bias is not None and bias.numel() else None,
                                ptr(rb.rules), ptr(rb.bases[out_col]), K, rb.stride, in_col, out_col, n_out,
-                               Ci, Co, stream()))
+                               Ci, Co, ptr(wpack), stream()))
     # algorithmic work of one launch (SURVEY.md section 8d): flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
     R = rb.total_pairs
@@ -279,19 +284,17 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out):
 
 
 def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse):
-    """d_in = conv(d_out, W^T) with the two columns swapped; dW; d_bias."""
+    """d_in = gather-mm-scatter of d_out with the transposed weights; dW; d_bias."""
     lib = _lib_()
     K, Ci, Co = weight.shape
     d_out = d_out.contiguous()
     if d_in is not None:
-        wt = torch.empty((K, Co, Ci), dtype=weight.dtype, device=weight.device)
-        check(lib.scn_weight_transpose(ptr(weight), ptr(wt), K, Ci, Co, int(reverse), stream()))
         if reverse:
             # submanifold: dIn[i] = sum_k' dOut[nbr(i,k')] . W[26-k']^T over the SAME lists (rules are
-            # symmetric: (i,o) in list k <=> (o,i) in list 26-k), so columns keep their roles
-            _conv(d_out, d_in, wt, None, rb, in_col, out_col, n_in)
+            # symmetric: (i,o) in list k <=> (o,i) in list 26-k), so the columns keep their roles
+            _conv(d_out, d_in, weight, None, rb, in_col, out_col, n_in, True, True)
         else:
-            _conv(d_out, d_in, wt, None, rb, out_col, in_col, n_in)
+            _conv(d_out, d_in, weight, None, rb, out_col, in_col, n_in, True, False)
     if d_weight is not None and d_weight.numel():
         ev = _prof_begin()
         check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts), K,

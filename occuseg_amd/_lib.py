@@ -29,10 +29,11 @@ SIGNATURES = {
     "scn_submanifold_rules": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "scn_strided_rules": (c_int, [_P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "scn_tile_bases": (c_int, [_P, _P, c_int, c_int64, c_int, c_int64, _P, _P]),
-    "scn_conv_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64,
-                                 c_int, c_int, _P]),
+    "scn_conv_wpack_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64,
+                                 c_int, c_int, _P, _P]),
+    "scn_set_tuning": (c_int, [c_int, c_int]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, c_int, _P]),
-    "scn_weight_transpose": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
     "scn_bn_temp_bytes": (c_size_t, [c_int]),
     "scn_bn_forward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_int, c_double,

@@ -26,6 +26,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int KMAX = 27;
 
+
 // ---------------------------------------------------------------- forward ---
 template <int NW, int COS, int M, int CK>
 __global__ void __launch_bounds__(64 * NW)
@@ -124,12 +125,259 @@ __global__ void __launch_bounds__(64 * NW)
   }
 }
 
+// ------------------------------------------------------ weight packing ---
+// Source element (k, r, c) = reduction plane r, output plane c of list k:
+//   transposed ? W[ks][c][r] : W[ks][r][c],  ks = reverse ? K-1-k : k   (W row-major [K][rows][cols]).
+// mode 0: plain   Wp[k][r][c]
+// mode 1: MFMA B-fragment order Wp[k][r/16][c/16][lq][li][e] = (k, 16(r/16) + 4 lq + e, 16(c/16) + li):
+//         a wave reads the 16x16 block it needs for 4 consecutive mfma_16x16x4 as ONE coalesced 1 KiB load.
+__global__ void __launch_bounds__(256)
+    k_weight_pack(const float *__restrict__ W, float *__restrict__ Wp, int K, int Cr, int Cc,
+                  int transposed, int reverse, int mode) {
+  const int64_t total = (int64_t)K * Cr * Cc;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int k, r, c;
+    if (mode == 0) {
+      k = (int)(t / ((int64_t)Cr * Cc));
+      const int rem = (int)(t % ((int64_t)Cr * Cc));
+      r = rem / Cc; c = rem % Cc;
+    } else {
+      int64_t u = t;
+      const int e = (int)(u & 3); u >>= 2;
+      const int li = (int)(u & 15); u >>= 4;
+      const int lq = (int)(u & 3); u >>= 2;
+      const int cs = (int)(u % (Cc / 16)); u /= (Cc / 16);
+      const int rs = (int)(u % (Cr / 16)); u /= (Cr / 16);
+      k = (int)u;
+      r = rs * 16 + lq * 4 + e;
+      c = cs * 16 + li;
+    }
+    const int ks = reverse ? K - 1 - k : k;
+    Wp[t] = transposed ? W[((int64_t)ks * Cc + c) * Cr + r] : W[((int64_t)ks * Cr + r) * Cc + c];
+  }
+}
+
+// ------------------------------------------------- forward, pipelined (v2) ---
+// Same decomposition as k_conv_tile, restructured so that the matrix pipe does not wait for HBM:
+//   * M = 32 NW output rows per workgroup (128 for 4 waves): fewer padded pair groups, W[k] fetched once
+//     per 128 rows;
+//   * the gathered rows of phase p+1 and the weight fragments of phase p+1 are requested into registers
+//     BEFORE the MFMAs of phase p start and are written to LDS after them (issue-early / write-late);
+//     the pair indices are fetched two lists ahead (triple-buffered in LDS), so no phase waits on a
+//     dependent index -> row load chain;
+//   * weights come pre-packed in fragment order (k_weight_pack mode 1): one 16-byte load per lane per
+//     16 input planes;
+//   * workgroups are renumbered so that each XCD owns a contiguous range of tiles: neighbouring tiles
+//     gather overlapping rows and now share one L2.
+template <int NW, int COS, int CK, int DBG = 0>
+__global__ void __launch_bounds__(64 * NW)
+    k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
+                 const float *__restrict__ bias, const int2 *__restrict__ rules,
+                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb) {
+  // requires Ci % CK == 0 (the launcher picks CK as the largest of 64/32/16 dividing Ci)
+  constexpr int M = 32 * NW;
+  constexpr int COB = NW * COS * 16;
+  constexpr int NT = 64 * NW;
+  constexpr int AS = CK + 4;
+  constexpr int OS = COB + 4;
+  constexpr int CH = CK / 4;            // 16-byte chunks per staged row
+  constexpr int NSLOT = M * CH / NT;    // row-chunks each thread stages per phase (= CK/8)
+  constexpr int NIDX = (M + NT - 1) / NT;
+  constexpr int NS16 = CK / 16;
+  __shared__ __attribute__((aligned(16))) float a_tile[M * AS];
+  __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
+  __shared__ int srcbuf[3][M];
+  __shared__ int olbuf[3][M];
+  __shared__ int klist[KMAX];
+  __shared__ int kseg[KMAX][2];
+  __shared__ int nk_s;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+
+  // XCD-aware renumbering (bijective): blocks b, b+8, .. share an XCD; give each a contiguous tile range
+  int lin;
+  {
+    const int total = ntiles * ncb;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile = lin / ncb;
+  const int co0 = (lin % ncb) * COB;
+  const int64_t o0 = (int64_t)tile * M;
+  const int g0 = tile * (M / SCN_TILE_GRANULE);
+  const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
+
+  for (int i = tid; i < M * COB; i += NT) {
+    const int r = i / COB, c = i % COB;
+    o_tile[r * OS + c] = bias ? bias[co0 + c] : 0.f;
+  }
+  if (tid < 64) {
+    // one lane per kernel offset: segment of list k inside this tile, then a ballot-compacted list of
+    // the non-empty offsets (K <= 27 < 64)
+    int s = 0, e = 0;
+    if (tid < K) {
+      s = bases[(int64_t)tid * (n_gran + 1) + g0];
+      e = bases[(int64_t)tid * (n_gran + 1) + g1];
+    }
+    const unsigned long long m = __ballot(e > s);
+    if (e > s) {
+      const int pos = __popcll(m & ((1ull << tid) - 1ull));
+      klist[pos] = tid;
+      kseg[pos][0] = s;
+      kseg[pos][1] = e - s;
+    }
+    if (tid == 0) nk_s = __popcll(m);
+  }
+  __syncthreads();
+  const int nk = nk_s;
+  const int nch = Ci / CK;
+  const int nphase = nk * nch;
+
+  // Branch-free staging: rows past the end of a segment re-read its last pair (same cache lines) and
+  // scatter into the sink row M, so no lane ever diverges inside a phase.
+  auto load_indices = [&](int kk, int2 (&pr)[NIDX]) __attribute__((always_inline)) {
+    const int2 *rk = rules + (int64_t)klist[kk] * stride + kseg[kk][0];
+    const int c = kseg[kk][1];
+#pragma unroll
+    for (int j = 0; j < NIDX; ++j) pr[j] = rk[min(tid + j * NT, c - 1)];
+  };
+  auto store_indices = [&](int kk, const int2 (&pr)[NIDX]) __attribute__((always_inline)) {
+    const int c = kseg[kk][1];
+    const int b = kk % 3;
+#pragma unroll
+    for (int j = 0; j < NIDX; ++j) {
+      const int r = tid + j * NT;
+      if (r < M) {
+        srcbuf[b][r] = in_col ? pr[j].y : pr[j].x;
+        olbuf[b][r] = (r < c) ? (int)((in_col ? pr[j].x : pr[j].y) - o0) : M;
+      }
+    }
+  };
+  floatx4 pre[NSLOT];
+  auto issue_rows = [&](int p) __attribute__((always_inline)) {
+    const int kk = p / nch, c0 = (p - kk * nch) * CK;
+    const int *sb = srcbuf[kk % 3];
+    int src[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) src[j] = sb[(tid + j * NT) / CH];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int ch = (tid + j * NT) % CH;
+      pre[j] = (DBG == 2) ? floatx4{1.f, 2.f, 3.f, (float)src[j]}
+                          : *(const floatx4 *)(in + (int64_t)src[j] * Ci + c0 + ch * 4);
+    }
+  };
+  auto store_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int idx = tid + j * NT;
+      *(floatx4 *)(a_tile + (idx / CH) * AS + (idx % CH) * 4) = pre[j];
+    }
+  };
+  floatx4 wcur[COS][NS16], wnext[COS][NS16];
+  auto issue_weights = [&](int p, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
+    const int kk = p / nch, c0 = (p - kk * nch) * CK;
+    const int k = klist[kk];
+    // Wp[k][r/16][c/16][lane][4]
+    const float *base = Wp + (((int64_t)k * (Ci / 16) + c0 / 16) * (Co / 16)) * 256 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < COS; ++q) {
+      const int cs = co0 / 16 + w * COS + q;
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp)
+        wr[q][sp] = *(const floatx4 *)(base + ((int64_t)sp * (Co / 16) + cs) * 256);
+    }
+  };
+  // one 16-pair group x COS plane slices: A fragments from LDS, NS16 x 4 MFMAs per slice
+  auto mma_group = [&](int g, floatx4 (&acc)[COS]) __attribute__((always_inline)) {
+    const float *ap = a_tile + (g * 16 + li) * AS + 4 * lq;
+    floatx4 a[NS16];
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp) a[sp] = *(const floatx4 *)(ap + sp * 16);
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp)
+#pragma unroll
+      for (int q = 0; q < COS; ++q) {
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp].x, wcur[q][sp].x, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp].y, wcur[q][sp].y, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp].z, wcur[q][sp].z, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp].w, wcur[q][sp].w, acc[q], 0, 0, 0);
+      }
+  };
+
+  if (nphase > 0) {
+    int2 pr[NIDX];
+    load_indices(0, pr);
+    store_indices(0, pr);
+    if (nk > 1) {
+      load_indices(1, pr);
+      store_indices(1, pr);
+    }
+    __syncthreads();
+    issue_rows(0);
+    issue_weights(0, wcur);
+
+    for (int p = 0; p < nphase; ++p) {
+      const int kk = p / nch, chn = p - kk * nch;
+      const int ngroups = (kseg[kk][1] + 15) >> 4;
+      store_rows();  // waits for the row loads issued one phase ago
+      __syncthreads();
+      const bool more = p + 1 < nphase;
+      const bool fetch_idx = (chn == 0) && (kk + 2 < nk);
+      int2 prn[NIDX];
+      if (more) {
+        issue_rows(p + 1);
+        issue_weights(p + 1, wnext);
+      }
+      if (fetch_idx) load_indices(kk + 2, prn);
+
+      const int *olb = olbuf[kk % 3];
+      for (int g = 0; g < ngroups; ++g) {
+        floatx4 acc[COS];
+#pragma unroll
+        for (int q = 0; q < COS; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+        int orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) orow[r] = olb[g * 16 + 4 * lq + r] * OS;
+        mma_group(g, acc);
+#pragma unroll
+        for (int q = 0; q < COS; ++q) {
+          const int cw = (w * COS + q) * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (DBG == 1) asm volatile("" ::"v"(acc[q][r]));
+            else o_tile[orow[r] + cw] += acc[q][r];  // plain read-add-write: ds_add_f32 measured 2.5x slower end to end
+          }
+        }
+      }
+      if (fetch_idx) store_indices(kk + 2, prn);
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < COS; ++q)
+#pragma unroll
+          for (int sp = 0; sp < NS16; ++sp) wcur[q][sp] = wnext[q][sp];
+      }
+      __syncthreads();  // a_tile and this list's ol[] are free again
+    }
+  }
+  const int rows = (int)min((int64_t)M, n_out - o0);
+  for (int i = tid; i < rows * (COB / 4); i += NT) {
+    const int r = i / (COB / 4), c4 = i % (COB / 4);
+    *(float4 *)(out + (o0 + r) * Co + co0 + c4 * 4) = *(const float4 *)(o_tile + r * OS + c4 * 4);
+  }
+}
+
 // generic fallback (any Ci, Co; scalar FMA): 32 output rows x 64 planes per block
 __global__ void __launch_bounds__(256)
     k_conv_generic(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
                    const float *__restrict__ bias, const int2 *__restrict__ rules,
                    const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
-                   int64_t n_out, int n_gran, int Ci, int Co) {
+                   int64_t n_out, int n_gran, int Ci, int Co, int w_transposed, int w_reverse) {
   constexpr int M = SCN_TILE_GRANULE;
   __shared__ float o_tile[M][65];
   const int tid = threadIdx.x;
@@ -148,9 +396,12 @@ __global__ void __launch_bounds__(256)
         const int src = in_col ? p.y : p.x;
         const int dst = (int)((in_col ? p.x : p.y) - o0);
         const float *ip = in + (int64_t)src * Ci;
-        const float *wp = W + (int64_t)k * Ci * Co + co;
+        const int ks = w_reverse ? K - 1 - k : k;
+        // element (ci, co) of list k: transposed ? W[ks][co][ci] : W[ks][ci][co]
+        const float *wp = W + (int64_t)ks * Ci * Co + (w_transposed ? (int64_t)co * Ci : co);
+        const int64_t ws = w_transposed ? 1 : Co;
         float acc = 0.f;
-        for (int ci = 0; ci < Ci; ++ci) acc += ip[ci] * wp[(int64_t)ci * Co];
+        for (int ci = 0; ci < Ci; ++ci) acc += ip[ci] * wp[ci * ws];
         o_tile[dst][tid & 63] += acc;  // one pair per output row inside a list: no race
       }
     __syncthreads();
@@ -265,6 +516,9 @@ __global__ void __launch_bounds__(256)
 }  // namespace scn
 using namespace scn;
 
+static int g_conv_dbg = 0;
+static int g_conv_variant = 2;  // 1 = first synchronous kernel (kept for A/B runs), 2 = pipelined
+
 template <int NW, int COS, int M, int CK>
 static int launch_tile(const float *in, float *out, const float *W, const float *bias,
                        const int32_t *rules, const int32_t *bases, int K, int64_t stride,
@@ -277,27 +531,87 @@ static int launch_tile(const float *in, float *out, const float *W, const float 
   return 0;
 }
 
+template <int NW, int COS, int CK>
+static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias,
+                        const int32_t *rules, const int32_t *bases, int K, int64_t stride,
+                        int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
+  constexpr int M = 32 * NW;
+  const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+  const int ntiles = (int)((n_out + M - 1) / M);
+  const int ncb = Co / (NW * COS * 16);
+  if (NW == 4 && CK == 64 && g_conv_dbg == 1)
+    k_conv_tile2<NW, COS, CK, 1><<<(unsigned)(ntiles * ncb), 64 * NW, 0, stream>>>(
+        in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 2)
+    k_conv_tile2<NW, COS, CK, 2><<<(unsigned)(ntiles * ncb), 64 * NW, 0, stream>>>(
+        in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb);
+  else
+  k_conv_tile2<NW, COS, CK><<<(unsigned)(ntiles * ncb), 64 * NW, 0, stream>>>(
+      in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int NW>
+static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias,
+                           const int32_t *rules, const int32_t *bases, int K, int64_t stride,
+                           int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
+  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+}
+
 extern "C" {
 
-int scn_conv_forward(const float *in, float *out, const float *W, const float *bias,
-                     const int32_t *rules, const int32_t *bases, int K, int64_t stride,
-                     int in_col, int out_col, int64_t n_out, int Ci, int Co, void *stream_) {
+int scn_set_tuning(int key, int value) {
+  if (key == 0 && (value == 1 || value == 2)) {
+    g_conv_variant = value;
+    return 0;
+  }
+  if (key == 1) {
+    g_conv_dbg = value;
+    return 0;
+  }
+  return fail(2, "scn_set_tuning: unknown key/value%s", "");
+}
+
+size_t scn_conv_wpack_bytes(int K, int Ci, int Co) { return (size_t)K * Ci * Co * 4; }
+
+int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
+                     const float *bias, const int32_t *rules, const int32_t *bases, int K,
+                     int64_t stride, int in_col, int out_col, int64_t n_out, int Ci, int Co,
+                     void *wpack, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_forward: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_forward: in_col/out_col must be 0/1 or 1/0");
   SCN_REQUIRE(Ci > 0 && Co > 0, "scn_conv_forward: bad plane counts");
   if (n_out <= 0) return 0;
   if (Ci % 16 == 0 && Co % 16 == 0) {
+    SCN_REQUIRE(wpack != nullptr, "scn_conv_forward: wpack workspace required");
+    float *Wp = (float *)wpack;
+    const int64_t total = (int64_t)K * Ci * Co;
+    int pg = (int)((total + 255) / 256);
+    if (pg > 2048) pg = 2048;
     const int s16 = Co / 16;
-    if (s16 % 4 == 0) return launch_tile<4, 1, 64, 64>(in, out, W, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-    if (s16 % 3 == 0) return launch_tile<3, 1, 64, 64>(in, out, W, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-    if (s16 % 2 == 0) return launch_tile<2, 1, 64, 64>(in, out, W, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-    return launch_tile<1, 1, 64, 64>(in, out, W, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    if (g_conv_variant == 1) {
+      k_weight_pack<<<pg, 256, 0, stream>>>(W, Wp, K, Ci, Co, w_transposed, w_reverse, 0);
+      SCN_CHECK_LAUNCH();
+      if (s16 % 4 == 0) return launch_tile<4, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+      if (s16 % 3 == 0) return launch_tile<3, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+      if (s16 % 2 == 0) return launch_tile<2, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+      return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    }
+    k_weight_pack<<<pg, 256, 0, stream>>>(W, Wp, K, Ci, Co, w_transposed, w_reverse, 1);
+    SCN_CHECK_LAUNCH();
+    if (s16 % 4 == 0) return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    if (s16 % 3 == 0) return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    if (s16 % 2 == 0) return launch_tile2_ck<2>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    return launch_tile2_ck<1>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)n_gran, (unsigned)((Co + 63) / 64));
   k_conv_generic<<<grid, 256, 0, stream>>>(in, out, W, bias, (const int2 *)rules, bases, K, stride, in_col,
-                                          n_out, n_gran, Ci, Co);
+                                          n_out, n_gran, Ci, Co, w_transposed, w_reverse);
   SCN_CHECK_LAUNCH();
   return 0;
 }

@@ -73,20 +73,42 @@ __global__ void __launch_bounds__(256) k_bn_stats(const float *x, int64_t N, int
   });
 }
 
+// Sum the per-block partials of 16 columns with 256 threads (16 columns x 16 partial lanes), in fp64.
+// Returns the two column sums to the threads with bl == 0.
+__device__ __forceinline__ bool bn_sum_partials(const float *partial, int nblk, int C, int &c, double &s0, double &s1) {
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  c = blockIdx.x * 16 + cl;
+  double a = 0, b = 0;
+  if (c < C)
+    for (int blk = bl; blk < nblk; blk += 16) {
+      a += (double)partial[(int64_t)blk * 2 * C + c];
+      b += (double)partial[(int64_t)blk * 2 * C + C + c];
+    }
+  red[0][bl][cl] = a;
+  red[1][bl][cl] = b;
+  __syncthreads();
+  if (bl != 0 || c >= C) return false;
+  s0 = 0; s1 = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    s0 += red[0][j][cl];
+    s1 += red[1][j][cl];
+  }
+  return true;
+}
+
 // arithmetic of sparseconvnet/SCN/CPU/BatchNormalization.cpp:19-52 with the row sums finished in fp64
-__global__ void k_bn_finalize(const float *partial, int nblk, int64_t N, int C, float *save_mean,
-                              float *save_invstd, float *running_mean, float *running_var,
-                              const float *weight, const float *bias, float eps, float momentum,
-                              int train, float *wb) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256)
+    k_bn_finalize(const float *partial, int nblk, int64_t N, int C, float *save_mean,
+                  float *save_invstd, float *running_mean, float *running_var,
+                  const float *weight, const float *bias, float eps, float momentum,
+                  int train, float *wb) {
+  int c;
+  double s = 0, ss = 0;
+  if (!bn_sum_partials(partial, train ? nblk : 0, C, c, s, ss)) return;
   float mean, invstd;
   if (train) {
-    double s = 0, ss = 0;
-    for (int b = 0; b < nblk; ++b) {
-      s += (double)partial[(int64_t)b * 2 * C + c];
-      ss += (double)partial[(int64_t)b * 2 * C + C + c];
-    }
     const double m = s / (double)N;
     const double var_n = ss - m * m * (double)N;  // "saveInvStd" before the rsqrt: sum of squared deviations
     mean = (float)m;
@@ -154,16 +176,12 @@ __global__ void __launch_bounds__(256)
 }
 
 // (sparseconvnet/SCN/CPU/BatchNormalization.cpp:88-93,:103-106); coef = [gradMean | k | invstd*gamma]
-__global__ void k_bn_bwd_finalize(const float *partial, int nblk, int64_t N, int C,
-                                  const float *save_invstd, const float *weight, float *d_weight,
-                                  float *d_bias, float *coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256)
+    k_bn_bwd_finalize(const float *partial, int nblk, int64_t N, int C, const float *save_invstd,
+                      const float *weight, float *d_weight, float *d_bias, float *coef) {
+  int c;
   double s = 0, dp = 0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[(int64_t)b * 2 * C + c];
-    dp += (double)partial[(int64_t)b * 2 * C + C + c];
-  }
+  if (!bn_sum_partials(partial, nblk, C, c, s, dp)) return;
   const float invstd = save_invstd[c];
   if (d_bias) d_bias[c] = (float)s;
   if (d_weight) d_weight[c] = (float)(dp * (double)invstd);
@@ -278,25 +296,6 @@ __global__ void k_column_sum(const float *x, float *out, int64_t rows, int C) {
   }
 }
 
-// Wt[k][co][ci] = W[ks][ci][co] through a 32x33 LDS tile
-__global__ void __launch_bounds__(256)
-    k_weight_transpose(const float *W, float *Wt, int K, int Ci, int Co, int reverse) {
-  __shared__ float tile[32][33];
-  const int k = blockIdx.z;
-  const int ks = reverse ? K - 1 - k : k;
-  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int r = ty; r < 32; r += 8) {
-    const int ci = ci0 + r, co = co0 + tx;
-    tile[r][tx] = (ci < Ci && co < Co) ? W[((int64_t)ks * Ci + ci) * Co + co] : 0.f;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int co = co0 + r, ci = ci0 + tx;
-    if (co < Co && ci < Ci) Wt[((int64_t)k * Co + co) * Ci + ci] = tile[tx][r];
-  }
-}
-
 static inline int grid_for(int64_t n, int block = 256, int cap = 4096) {
   int64_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -335,7 +334,7 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
     else k_bn_stats<1><<<grid, 256, 0, stream>>>(x, N, C, partial);
     SCN_CHECK_LAUNCH();
   }
-  k_bn_finalize<<<(C + 255) / 256, 256, 0, stream>>>(partial, nblk, N, C, save_mean, save_invstd,
+  k_bn_finalize<<<(C + 15) / 16, 256, 0, stream>>>(partial, nblk, N, C, save_mean, save_invstd,
                                                     running_mean, running_var, weight, bias,
                                                     (float)eps, (float)momentum, train, wb);
   SCN_CHECK_LAUNCH();
@@ -363,7 +362,7 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
   if (v4) k_bn_bwd_stats<4><<<grid, 256, 0, stream>>>(x, y, d_out, save_mean, N, C, (float)leakiness, partial);
   else k_bn_bwd_stats<1><<<grid, 256, 0, stream>>>(x, y, d_out, save_mean, N, C, (float)leakiness, partial);
   SCN_CHECK_LAUNCH();
-  k_bn_bwd_finalize<<<(C + 255) / 256, 256, 0, stream>>>(partial, nblk, N, C, save_invstd, weight,
+  k_bn_bwd_finalize<<<(C + 15) / 16, 256, 0, stream>>>(partial, nblk, N, C, save_invstd, weight,
                                                         d_weight, d_bias, coef);
   SCN_CHECK_LAUNCH();
   const int64_t total = N * C;
@@ -411,14 +410,6 @@ int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream
   int blocks = (int)((rows + 255) / 256);
   if (blocks > 512) blocks = 512;
   k_column_sum<<<blocks, 256, 0, stream>>>(x, out, rows, C);
-  SCN_CHECK_LAUNCH();
-  return 0;
-}
-
-int scn_weight_transpose(const float *W, float *Wt, int K, int Ci, int Co, int reverse,
-                         void *stream_) {
-  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, K);
-  k_weight_transpose<<<grid, 256, 0, as_stream(stream_)>>>(W, Wt, K, Ci, Co, reverse);
   SCN_CHECK_LAUNCH();
   return 0;
 }
