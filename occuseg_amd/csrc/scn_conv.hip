@@ -293,21 +293,39 @@ __global__ void __launch_bounds__(64 * NW)
         wr[q][sp] = *(const floatx4 *)(base + ((int64_t)sp * (Co / 16) + cs) * 256);
     }
   };
-  // one 16-pair group x COS plane slices: A fragments from LDS, NS16 x 4 MFMAs per slice
-  auto mma_group = [&](int g, floatx4 (&acc)[COS]) __attribute__((always_inline)) {
+  // One 16-pair group x COS plane slices.  Operands are SWAPPED (A = weight fragment, B = gathered rows):
+  // D[i = plane][j = pair], so a lane ends up with 4 consecutive output planes of ONE pair and the
+  // accumulate into the LDS output tile is a single 16-byte read-add-write per slice.
+  auto load_a = [&](int g, floatx4 (&a)[NS16]) __attribute__((always_inline)) {
     const float *ap = a_tile + (g * 16 + li) * AS + 4 * lq;
-    floatx4 a[NS16];
 #pragma unroll
     for (int sp = 0; sp < NS16; ++sp) a[sp] = *(const floatx4 *)(ap + sp * 16);
+  };
+  auto mma_group = [&](const floatx4 (&a)[NS16], floatx4 (&acc)[COS]) __attribute__((always_inline)) {
+    // one accumulator chain per slice: with two waves per SIMD the 40-cycle dependent latency is
+    // covered by the partner wave (two chains + a final add measured 3-5 % slower)
+#pragma unroll
+    for (int q = 0; q < COS; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sp = 0; sp < NS16; ++sp)
 #pragma unroll
       for (int q = 0; q < COS; ++q) {
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp].x, wcur[q][sp].x, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp].y, wcur[q][sp].y, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp].z, wcur[q][sp].z, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sp].w, wcur[q][sp].w, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].x, a[sp].x, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].y, a[sp].y, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].z, a[sp].z, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].w, a[sp].w, acc[q], 0, 0, 0);
       }
+  };
+  auto scatter = [&](int orow, const floatx4 (&acc)[COS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < COS; ++q) {
+      if (DBG == 1) {
+        asm volatile("" ::"v"(acc[q]));
+      } else {
+        floatx4 *op = (floatx4 *)(o_tile + orow + (w * COS + q) * 16 + 4 * lq);
+        *op += acc[q];  // plain read-add-write: ds_add_f32 measured 2.5x slower end to end
+      }
+    }
   };
 
   if (nphase > 0) {
@@ -336,25 +354,24 @@ __global__ void __launch_bounds__(64 * NW)
       }
       if (fetch_idx) load_indices(kk + 2, prn);
 
+      // software pipeline over the pair groups: fragments of group g+1 are read while the MFMAs of
+      // group g run; the result of group g is added to the output tile behind the MFMAs of group g+1
       const int *olb = olbuf[kk % 3];
+      floatx4 a_cur[NS16], a_nxt[NS16], acc_cur[COS], acc_prev[COS];
+      int orow_prev = 0;
+      load_a(0, a_cur);
       for (int g = 0; g < ngroups; ++g) {
-        floatx4 acc[COS];
+        const int orow = olb[g * 16 + li] * OS;
+        if (g + 1 < ngroups) load_a(g + 1, a_nxt);
+        mma_group(a_cur, acc_cur);
+        if (g > 0) scatter(orow_prev, acc_prev);
 #pragma unroll
-        for (int q = 0; q < COS; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-        int orow[4];
+        for (int q = 0; q < COS; ++q) acc_prev[q] = acc_cur[q];
+        orow_prev = orow;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) orow[r] = olb[g * 16 + 4 * lq + r] * OS;
-        mma_group(g, acc);
-#pragma unroll
-        for (int q = 0; q < COS; ++q) {
-          const int cw = (w * COS + q) * 16 + li;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (DBG == 1) asm volatile("" ::"v"(acc[q][r]));
-            else o_tile[orow[r] + cw] += acc[q][r];  // plain read-add-write: ds_add_f32 measured 2.5x slower end to end
-          }
-        }
+        for (int sp = 0; sp < NS16; ++sp) a_cur[sp] = a_nxt[sp];
       }
+      scatter(orow_prev, acc_prev);
       if (fetch_idx) store_indices(kk + 2, prn);
       if (more) {
 #pragma unroll

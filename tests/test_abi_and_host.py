@@ -1,0 +1,118 @@
+"""not gpu: the C-ABI library loads and exports every symbol include/scn_hip.h declares (no compute
+calls), and the host-side mirror keeps the reference's operator interface."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "scn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(scn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from occuseg_amd import _lib
+    names = _declared()
+    assert len(names) >= 25
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    lib = _lib.load()  # raises if the .so is missing or a symbol cannot be resolved
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.scn_abi_version() == 1
+    # size queries are host-only arithmetic: safe without a GPU
+    assert lib.scn_hash_capacity(1000) == 2048
+    assert lib.scn_conv_wpack_bytes(27, 64, 64) == 27 * 64 * 64 * 4
+    assert lib.scn_bn_temp_bytes(64) > 2 * 64 * 4
+    assert lib.scn_rules_temp_bytes(1000, 27) >= 27 * 4 * 4
+
+
+def test_product_path_has_no_cpu_fallback_and_never_imports_the_oracle():
+    from occuseg_amd import SCN
+    x = torch.zeros(4, 16)
+    e = torch.empty(0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        SCN.BatchNormalization_updateOutput(x, e, e, e, torch.zeros(16), torch.ones(16), e, e, 1e-4, 0.9, True, 1.0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        SCN.SubmanifoldConvolution_updateOutput(torch.tensor([8, 8, 8]), torch.tensor([3, 3, 3]), SCN.Metadata_3(),
+                                                x, e, torch.zeros(27, 16, 16), e, 1)
+    pkg = os.path.join(ROOT, "occuseg_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_out_of_scope_entry_points_raise():
+    from occuseg_amd import SCN
+    import occuseg_amd.sparseconvnet as scn
+    with pytest.raises(NotImplementedError):
+        SCN.MaxPooling_updateOutput()
+    with pytest.raises(NotImplementedError):
+        scn.MaxPooling
+    m = SCN.Metadata_3()
+    with pytest.raises(NotImplementedError):
+        m.getSubmanifoldRuleBook(torch.tensor([8, 8, 8]), torch.tensor([5, 5, 5]))
+    with pytest.raises(NotImplementedError):
+        m.getRuleBook(torch.tensor([8, 8, 8]), torch.tensor([3, 3, 3]), torch.tensor([3, 3, 3]), torch.tensor([2, 2, 2]))
+
+
+def test_unet_module_tree_matches_reference_layout():
+    """state_dict keys / shapes of InstanceDenseUNet's backbone: 43,434,432 parameters
+    at m=64, weight [volume, nIn, nOut], BN buffers running_mean/running_var."""
+    import occuseg_amd
+    scn = occuseg_amd.install()
+    import sparseconvnet
+    assert sparseconvnet is scn
+    m = 64
+    net = scn.Sequential().add(scn.InputLayer(3, 4096, mode=4)).add(scn.SubmanifoldConvolution(3, 3, m, 3, False)).add(
+        scn.UNet(3, 1, [m, 2 * m, 3 * m, 4 * m, 5 * m, 6 * m], residual_blocks=True)).add(scn.BatchNormReLU(m)).add(
+        scn.OutputLayer(3))
+    assert sum(p.numel() for p in net.parameters()) == 43434432
+    sd = net.state_dict()
+    assert sd["1.weight"].shape == (27, 3, 64)
+    assert sd["2.0.1.1.weight"].shape == (27, 64, 64)            # first residual block, first SC
+    assert sd["2.2.1.1.weight"].shape == (8, 64, 128)            # level-0 strided convolution
+    assert sd["2.2.1.4.weight"].shape == (8, 128, 64)            # matching deconvolution
+    assert sd["2.4.0.weight"].shape == (128, 64)                 # NiN shortcut of the decoder block
+    assert sd["2.4.1.1.weight"].shape == (27, 128, 64)
+    assert "2.0.1.0.running_mean" in sd and "2.0.1.0.running_var" in sd and "3.bias" in sd
+    kinds = [type(mod).__name__ for mod in net.modules()]
+    assert kinds.count("SubmanifoldConvolution") == 23 and kinds.count("Convolution") == 5
+    assert kinds.count("Deconvolution") == 5 and kinds.count("NetworkInNetwork") == 5
+    assert sum(k.startswith("BatchNorm") for k in kinds) == 33
+    bn = scn.BatchNormalization(8)
+    assert (bn.eps, bn.momentum, bn.leakiness) == (1e-4, 0.9, 1)
+    assert scn.BatchNormReLU(8).leakiness == 0 and scn.BatchNormLeakyReLU(8).leakiness == 0.333
+
+
+def test_spatial_size_arithmetic():
+    import occuseg_amd.sparseconvnet as scn
+    c = scn.Convolution(3, 4, 8, 2, 2, False)
+    d = scn.Deconvolution(3, 8, 4, 2, 2, False)
+    s = torch.tensor([4096, 4096, 4096])
+    assert c.output_spatial_size(s).tolist() == [2048] * 3 and c.output_spatial_size(s).dtype == torch.int64
+    assert d.output_spatial_size(torch.tensor([2048] * 3)).tolist() == [4096] * 3
+    assert c.input_spatial_size(torch.tensor([2048] * 3)).tolist() == [4096] * 3
+    with pytest.raises(AssertionError):
+        c.output_spatial_size(torch.tensor([4097, 4096, 4096]))
+    assert scn.toLongTensor(3, 5).tolist() == [5, 5, 5] and scn.toLongTensor(3, [1, 2, 3]).tolist() == [1, 2, 3]
+    assert scn.optionalTensor(c, "bias").numel() == 0 and scn.optionalTensorReturn(torch.empty(0)) is None
+    assert repr(c) == "Convolution 4->8 C2/2" and repr(scn.SubmanifoldConvolution(3, 4, 8, 3, False)) == \
+        "SubmanifoldConvolution 4->8 C3"
+
+
+def test_scenes_are_deterministic_and_inside_the_key_box():
+    import numpy as np
+    from occuseg_amd import scenes
+    a, fa = scenes.batch([1000, 1001], 4000)
+    b, fb = scenes.batch([1000, 1001], 4000)
+    assert np.array_equal(a, b) and np.array_equal(fa, fb)
+    assert a[:, 0].max() < 1024 and a[:, 1].max() < 2048 and a[:, 2].max() < 1024 and a[:, :3].min() >= 10
+    assert np.all(np.diff(a[:, 3]) >= 0) and set(a[:, 3]) == {0, 1}
+    assert len(scenes.solid_block(6)) == 216 and scenes.bernoulli_grid(32, 0.25, 0).shape[1] == 3

@@ -1,0 +1,61 @@
+"""not gpu: the N>1 path on CPU -- two processes, gloo backend.  Checks the flat gradient bucket
+(one all-reduce of one contiguous buffer, averaged) and the scene sharding used by bench.py."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from occuseg_amd import dp
+    torch.manual_seed(0)  # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    bucket = dp.FlatGradBucket(net.parameters())
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())
+    seeds = dp.shard(list(range(100, 100 + 4 * world)), rank, world)
+    assert seeds == list(range(100 + 4 * rank, 104 + 4 * rank))
+    g = torch.Generator().manual_seed(seeds[0])
+    x = torch.randn(7, 6, generator=g)
+    bucket.zero()
+    net(x).sum().backward()
+    local = bucket.flat.clone()
+    bucket.all_reduce_mean()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = sum(gathered) / world
+    ok = torch.allclose(bucket.flat, want, atol=1e-7) and all(
+        torch.equal(p.grad.flatten(), bucket.flat[o:o + p.numel()])
+        for p, o in zip(net.parameters(), [0, 30, 35, 50]))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
+
+
+def test_bucket_is_a_noop_without_process_group():
+    from occuseg_amd import dp
+    net = torch.nn.Linear(3, 2)
+    b = dp.FlatGradBucket(net.parameters())
+    net(torch.ones(1, 3)).sum().backward()
+    before = b.flat.clone()
+    b.all_reduce_mean()
+    assert torch.equal(before, b.flat) and b.flat.abs().sum() > 0

@@ -1,0 +1,215 @@
+"""not gpu: the oracle itself -- two independent rule generators agree, structural invariants of
+SURVEY.md Appendix A hold, arithmetic matches the reference's own CPU loops (oracle/_ref) and the
+committed golden vectors, hand-derived backward formulas match torch autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, random_points
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cases():
+    from occuseg_amd import scenes
+    yield "dense", random_points(0, 300, 2, 7)
+    yield "sparse", random_points(1, 200, 3, 30, origin=10)
+    yield "box-edges", np.array([[0, 0, 0, 0], [1023, 2047, 1023, 0], [1022, 2046, 1022, 0], [1023, 2047, 1022, 0],
+                                 [0, 2047, 0, 1], [1, 2047, 0, 1], [1023, 0, 0, 1]], np.int64)
+    yield "bernoulli", np.concatenate([scenes.bernoulli_grid(12, 0.3, 3), np.zeros((0, 3), np.int64)])
+
+
+@pytest.mark.parametrize("name,coords", list(_cases()), ids=[n for n, _ in _cases()])
+def test_rules_numpy_vs_bruteforce(name, coords):
+    from oracle import bruteforce as BF, rules as R
+    grid, header, table, sop = R.input_layer_rules(coords)
+    c4 = [tuple(int(v) for v in (list(r) + [0])[:4]) for r in coords.tolist()]
+    sc, ctr, rows, ma = BF.sites_and_input_rules(c4)
+    assert [tuple(r) for r in grid.coords.tolist()] == sc
+    assert list(grid.ctr) == ctr and header.tolist() == [4, ma, len(coords), len(sc)]
+    for s, r in enumerate(rows):
+        assert table[s, 0] == r[0] and table[s, 1:1 + r[0]].tolist() == r[1:]
+        assert all(sop[p] == s for p in r[1:])
+    sub, nbr = R.submanifold_rules(grid)
+    bsub = BF.submanifold_rules(sc)
+    for k in range(27):
+        assert [tuple(x) for x in sub[k].tolist()] == bsub[k]
+    coarse, strd, child = R.strided_rules(grid)
+    cc, cctr, bstr = BF.strided_rules(sc)
+    assert [tuple(r) for r in coarse.coords.tolist()] == cc and list(coarse.ctr) == cctr
+    for k in range(8):
+        assert [tuple(x) for x in strd[k].tolist()] == bstr[k]
+
+
+def test_rule_invariants():
+    """lists ascending in `out`; list 13 is the identity; (i,o) in k <=> (o,i) in 26-k;
+    every fine site in exactly one strided list; strided lists ascending in BOTH columns."""
+    from oracle import rules as R
+    coords = random_points(5, 1500, 3, 14)
+    grid, _, _, _ = R.input_layer_rules(coords)
+    sub, nbr = R.submanifold_rules(grid)
+    assert np.array_equal(sub[13], np.stack([np.arange(grid.n)] * 2, 1))
+    for k in range(27):
+        assert np.all(np.diff(sub[k][:, 1]) > 0)
+        a = set(map(tuple, sub[k].tolist()))
+        b = set((o, i) for i, o in sub[26 - k].tolist())
+        assert a == b
+        # no pair crosses a sample boundary
+        assert np.array_equal(grid.coords[sub[k][:, 0], 3], grid.coords[sub[k][:, 1], 3])
+    coarse, strd, child = R.strided_rules(grid)
+    seen = np.concatenate([r[:, 0] for r in strd])
+    assert np.array_equal(np.sort(seen), np.arange(grid.n))
+    for r in strd:
+        assert np.all(np.diff(r[:, 0]) > 0) and np.all(np.diff(r[:, 1]) > 0)
+    assert np.array_equal(coarse.coords[:, :3][np.concatenate([r[:, 1] for r in strd])],
+                          grid.coords[:, :3][seen] >> 1)
+
+
+def test_key_order_is_z_y_x():
+    from oracle import rules as R
+    c = np.array([[5, 0, 0], [0, 1, 0], [0, 0, 1], [1023, 2047, 0], [0, 0, 0]], np.int64)
+    grid, _, _, _ = R.input_layer_rules(c)
+    assert grid.coords[:, :3].tolist() == [[0, 0, 0], [5, 0, 0], [0, 1, 0], [1023, 2047, 0], [0, 0, 1]]
+
+
+def test_golden_rulebooks():
+    from oracle import rules as R
+    for name in ("g1_rules_8cube", "g2_rules_bernoulli32", "g3_rules_bernoulli14"):
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        grid, header, table, sop = R.input_layer_rules(g["coords"])
+        assert np.array_equal(grid.coords, g["site_coords"]) and np.array_equal(header, g["header"])
+        assert np.array_equal(table, g["table"]) and np.array_equal(sop, g["site_of_point"])
+        sub, _ = R.submanifold_rules(grid)
+        coarse, strd, _ = R.strided_rules(grid)
+        assert all(np.array_equal(sub[k], g["sub%02d" % k]) for k in range(27))
+        assert all(np.array_equal(strd[k], g["str%d" % k]) for k in range(8))
+        assert np.array_equal(coarse.coords, g["coarse_coords"])
+
+
+def _g3():
+    from oracle import rules as R
+    g = np.load(os.path.join(GOLD, "g3_conv_bernoulli14.npz"))
+    r = np.load(os.path.join(GOLD, "g3_rules_bernoulli14.npz"))
+    sub = [r["sub%02d" % k] for k in range(27)]
+    strd = [r["str%d" % k] for k in range(8)]
+    return g, sub, strd, len(r["site_coords"]), len(r["coarse_coords"])
+
+
+def test_golden_conv_arithmetic():
+    """oracle.arith (float32 and float64) against vectors produced by the reference's own CPU code"""
+    from oracle import arith as A
+    g, sub, strd, n, nc = _g3()
+    for dt, rel in ((np.float32, 2e-6), (np.float64, 2e-6)):
+        y, _ = A.conv_forward(g["x"], g["w"], sub, n, dtype=dt)
+        assert_close(y, g["y"], "SC fwd", rel)
+        dx, dw, _ = A.conv_backward(g["x"], g["dy"], g["w"], sub, dtype=dt)
+        assert_close(dx, g["dx"], "SC dInput", rel)
+        assert_close(dw, g["dw"], "SC dWeight", rel)
+        yc, _ = A.conv_forward(g["x"], g["wc"], strd, nc, dtype=dt)
+        assert_close(yc, g["yc"], "conv fwd", rel)
+        dxc, dwc, _ = A.conv_backward(g["x"], g["dyc"], g["wc"], strd, dtype=dt)
+        assert_close(dxc, g["dxc"], "conv dInput", rel)
+        assert_close(dwc, g["dwc"], "conv dWeight", rel)
+        yd, _ = A.conv_forward(g["xd"], g["wd"], strd, n, in_col=1, out_col=0, dtype=dt)
+        assert_close(yd, g["yd"], "deconv fwd", rel)
+        dxd, dwd, _ = A.conv_backward(g["xd"], g["dyd"], g["wd"], strd, in_col=1, out_col=0, dtype=dt)
+        assert_close(dxd, g["dxd"], "deconv dInput", rel)
+        assert_close(dwd, g["dwd"], "deconv dWeight", rel)
+
+
+def test_golden_batchnorm_and_io():
+    from oracle import arith as A
+    g = np.load(os.path.join(GOLD, "g4_batchnorm.npz"))
+    for nn in (1024, 2):
+        x, gm, b, rm0, rv0, dy = (g["%s%d" % (k, nn)] for k in ("x", "g", "b", "rm", "rv", "dy"))
+        for li, leak in enumerate((0.0, 0.333, 1.0)):
+            for train in (1, 0):
+                tag = "%d_l%d_t%d" % (nn, li, train)
+                y, sm, si, rm, rv = A.batchnorm_forward(x, gm, b, rm0, rv0, 1e-4, 0.9, bool(train), leak, np.float64)
+                # the reference sums x^2 in float32 (BatchNormalization.cpp:26): allow its own rounding
+                assert_close(y, g["y" + tag], "bn y " + tag, 2e-5)
+                assert_close(sm, g["sm" + tag], "bn mean", 2e-5)
+                assert_close(si, g["si" + tag], "bn invstd", 2e-5)
+                assert_close(rm, g["rmo" + tag], "bn running_mean", 2e-5)
+                assert_close(rv, g["rvo" + tag], "bn running_var", 2e-5)
+                if train:
+                    dx, dm, dw, db = A.batchnorm_backward(x, g["y" + tag], dy, g["sm" + tag], g["si" + tag], gm, leak,
+                                                          np.float64)
+                    scale = max(float(np.abs(dm * g["si" + tag] * gm).max()), float(np.abs(g["dx" + tag]).max()))
+                    assert_close(dx, g["dx" + tag], "bn dInput", 5e-5, scale=scale)
+                    assert_close(dm, g["dm" + tag], "bn masked dOut", 1e-6)
+                    assert_close(dw, g["dw" + tag], "bn dWeight", 5e-5)
+                    assert_close(db, g["db" + tag], "bn dBias", 5e-5)
+    io = np.load(os.path.join(GOLD, "g5_io_layers.npz"))
+    for mode in (3, 4):
+        o = A.input_layer_forward(io["feats"], io["table"], mode, np.float64)
+        assert_close(o, io["out_m%d" % mode], "input fwd", 1e-6)
+        di = A.input_layer_backward(io["out_m%d" % mode], io["table"], len(io["feats"]), mode, np.float64)
+        assert_close(di, io["din_m%d" % mode], "input bwd", 1e-6)
+
+
+def test_oracle_vs_reference_build_live():
+    """when oracle/_ref exists (build container, or shipped to the GPU box) re-check on fresh random data"""
+    from oracle import arith as A, ref, rules as R
+    if not ref.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference): golden vectors cover this")
+    coords = random_points(11, 900, 2, 11)
+    grid, _, table, _ = R.input_layer_rules(coords)
+    sub, _ = R.submanifold_rules(grid)
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(grid.n, 24)).astype(np.float32)
+    w = rng.normal(size=(27, 24, 8)).astype(np.float32) * 0.1
+    dy = rng.normal(size=(grid.n, 8)).astype(np.float32)
+    assert_close(A.conv_forward(x, w, sub, grid.n)[0], ref.conv_forward(x, w, sub, grid.n), "fwd", 2e-6)
+    dx, dw, _ = A.conv_backward(x, dy, w, sub)
+    rdx, rdw = ref.conv_backward(x, dy, w, sub)
+    assert_close(dx, rdx, "dInput", 2e-6)
+    assert_close(dw, rdw, "dWeight", 2e-6)
+    xb = rng.normal(size=(777, 24)).astype(np.float32) + 3
+    y, sm, si, rm, rv = A.batchnorm_forward(xb, None, None, np.zeros(24), np.ones(24), leakiness=0.2)
+    ry, rsm, rsi, rrm, rrv = ref.bn_forward(xb, None, None, np.zeros(24), np.ones(24), leakiness=0.2)
+    assert_close(y, ry, "bn y", 2e-5)
+    assert_close(rv, rrv, "bn running var", 2e-5)
+    f = rng.normal(size=(len(coords), 5)).astype(np.float32)
+    assert_close(A.input_layer_forward(f, table, 4), ref.input_forward(f, table, 4), "input", 1e-6)
+
+
+def test_backward_formulas_match_autograd():
+    """oracle.arith.conv_backward / batchnorm_backward vs torch autograd of the forward formulas"""
+    from oracle import arith as A, rules as R
+    coords = random_points(7, 500, 2, 9)
+    grid, _, _, _ = R.input_layer_rules(coords)
+    sub, _ = R.submanifold_rules(grid)
+    rng = np.random.default_rng(0)
+    x = torch.tensor(rng.normal(size=(grid.n, 6)), requires_grad=True)
+    w = torch.tensor(rng.normal(size=(27, 6, 5)), requires_grad=True)
+    out = torch.zeros(grid.n, 5, dtype=torch.float64)
+    for k, r in enumerate(sub):
+        out = out.index_add(0, torch.from_numpy(r[:, 1].astype(np.int64)),
+                            x.index_select(0, torch.from_numpy(r[:, 0].astype(np.int64))) @ w[k])
+    dy = torch.tensor(rng.normal(size=(grid.n, 5)))
+    (out * dy).sum().backward()
+    dx, dw, db = A.conv_backward(x.detach().numpy(), dy.numpy(), w.detach().numpy(), sub, want_bias=True,
+                                 dtype=np.float64)
+    assert_close(dx, x.grad.numpy(), "dInput", 1e-12)
+    assert_close(dw, w.grad.numpy(), "dWeight", 1e-12)
+    assert_close(db, dy.sum(0).numpy(), "dBias", 1e-12)
+    xb = torch.tensor(rng.normal(size=(300, 4)) + 1.0, requires_grad=True)
+    g = torch.tensor(rng.uniform(0.5, 2, 4), requires_grad=True)
+    b = torch.tensor(rng.normal(size=4), requires_grad=True)
+    mean = xb.mean(0)
+    var = ((xb - mean) ** 2).mean(0)
+    y = (xb - mean) / torch.sqrt(var + 1e-4) * g + b
+    y = torch.where(y > 0, y, 0.3 * y)
+    dyb = torch.tensor(rng.normal(size=(300, 4)))
+    (y * dyb).sum().backward()
+    yo, sm, si, _, _ = A.batchnorm_forward(xb.detach().numpy(), g.detach().numpy(), b.detach().numpy(), np.zeros(4),
+                                           np.ones(4), 1e-4, 0.9, True, 0.3, np.float64)
+    assert_close(yo, y.detach().numpy(), "bn fwd", 1e-10)
+    dxo, _, dgo, dbo = A.batchnorm_backward(xb.detach().numpy(), yo, dyb.numpy(), sm, si, g.detach().numpy(), 0.3,
+                                            np.float64)
+    assert_close(dxo, xb.grad.numpy(), "bn dInput", 1e-9)
+    assert_close(dgo, g.grad.numpy(), "bn dWeight", 1e-9)
+    assert_close(dbo, b.grad.numpy(), "bn dBias", 1e-9)
