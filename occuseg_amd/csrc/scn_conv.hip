@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(256)
 //     16 input planes;
 //   * workgroups are renumbered so that each XCD owns a contiguous range of tiles: neighbouring tiles
 //     gather overlapping rows and now share one L2.
-template <int NW, int COS, int CK, int DBG = 0>
-__global__ void __launch_bounds__(64 * NW)
+template <int NW, int COS, int CK, int DBG = 0, int NWM = 1>
+__global__ void __launch_bounds__(64 * NW * NWM)
     k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(64 * NW)
   // requires Ci % CK == 0 (the launcher picks CK as the largest of 64/32/16 dividing Ci)
   constexpr int M = 32 * NW;
   constexpr int COB = NW * COS * 16;
-  constexpr int NT = 64 * NW;
+  constexpr int NT = 64 * NW * NWM;  // NWM waves share each plane slice and split the pair groups
   constexpr int AS = CK + 4;
   constexpr int OS = COB + 4;
   constexpr int CH = CK / 4;            // 16-byte chunks per staged row
@@ -195,7 +195,8 @@ __global__ void __launch_bounds__(64 * NW)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = tid >> 6;
+  const int w = (tid >> 6) % NW;   // plane slice of this wave
+  const int wm = (tid >> 6) / NW;  // which share of the pair groups
   const int li = lane & 15, lq = lane >> 4;
 
   // XCD-aware renumbering (bijective): blocks b, b+8, .. share an XCD; give each a contiguous tile range
@@ -259,24 +260,32 @@ __global__ void __launch_bounds__(64 * NW)
     }
   };
   floatx4 pre[NSLOT];
+  // slot j of a thread covers row (tid + j NT) / CH; with CH * 16 == NT (CK 64, 4 waves) that is pair
+  // group j, so "j < groups of this list" is wave-uniform and unused groups cost nothing.
+  constexpr bool SLOT_IS_GROUP = (NT == CH * 16) && (DBG & 4);
   auto issue_rows = [&](int p) __attribute__((always_inline)) {
     const int kk = p / nch, c0 = (p - kk * nch) * CK;
     const int *sb = srcbuf[kk % 3];
+    const int ng = (kseg[kk][1] + 15) >> 4;
     int src[NSLOT];
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) src[j] = sb[(tid + j * NT) / CH];
+    for (int j = 0; j < NSLOT; ++j)
+      if (!SLOT_IS_GROUP || j < ng) src[j] = sb[(tid + j * NT) / CH];
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       const int ch = (tid + j * NT) % CH;
-      pre[j] = (DBG == 2) ? floatx4{1.f, 2.f, 3.f, (float)src[j]}
-                          : *(const floatx4 *)(in + (int64_t)src[j] * Ci + c0 + ch * 4);
+      if (!SLOT_IS_GROUP || j < ng)
+        pre[j] = (DBG & 2) ? floatx4{1.f, 2.f, 3.f, (float)src[j]}
+                            : *(const floatx4 *)(in + (int64_t)src[j] * Ci + c0 + ch * 4);
     }
   };
-  auto store_rows = [&]() __attribute__((always_inline)) {
+  auto store_rows = [&](int p) __attribute__((always_inline)) {
+    const int ng = (kseg[p / nch][1] + 15) >> 4;
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       const int idx = tid + j * NT;
-      *(floatx4 *)(a_tile + (idx / CH) * AS + (idx % CH) * 4) = pre[j];
+      if (DBG & 16) asm volatile("" ::"v"(pre[j]));
+      else if (!SLOT_IS_GROUP || j < ng) *(floatx4 *)(a_tile + (idx / CH) * AS + (idx % CH) * 4) = pre[j];
     }
   };
   floatx4 wcur[COS][NS16], wnext[COS][NS16];
@@ -299,13 +308,34 @@ __global__ void __launch_bounds__(64 * NW)
   auto load_a = [&](int g, floatx4 (&a)[NS16]) __attribute__((always_inline)) {
     const float *ap = a_tile + (g * 16 + li) * AS + 4 * lq;
 #pragma unroll
-    for (int sp = 0; sp < NS16; ++sp) a[sp] = *(const floatx4 *)(ap + sp * 16);
+    for (int sp = 0; sp < NS16; ++sp)
+      a[sp] = (DBG & 8) ? floatx4{(float)g, 1.f, 2.f, (float)sp} : *(const floatx4 *)(ap + sp * 16);
   };
   auto mma_group = [&](const floatx4 (&a)[NS16], floatx4 (&acc)[COS]) __attribute__((always_inline)) {
     // one accumulator chain per slice: with two waves per SIMD the 40-cycle dependent latency is
     // covered by the partner wave (two chains + a final add measured 3-5 % slower)
 #pragma unroll
     for (int q = 0; q < COS; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if ((DBG & 32) && NS16 == 4) {
+      floatx4 acc2[COS];
+#pragma unroll
+      for (int q = 0; q < COS; ++q) {
+        acc2[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].x, a[sp].x, acc[q], 0, 0, 0);
+          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp + 2].x, a[sp + 2].x, acc2[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].y, a[sp].y, acc[q], 0, 0, 0);
+          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp + 2].y, a[sp + 2].y, acc2[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].z, a[sp].z, acc[q], 0, 0, 0);
+          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp + 2].z, a[sp + 2].z, acc2[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].w, a[sp].w, acc[q], 0, 0, 0);
+          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp + 2].w, a[sp + 2].w, acc2[q], 0, 0, 0);
+        }
+        acc[q] += acc2[q];
+      }
+      return;
+    }
 #pragma unroll
     for (int sp = 0; sp < NS16; ++sp)
 #pragma unroll
@@ -319,7 +349,7 @@ __global__ void __launch_bounds__(64 * NW)
   auto scatter = [&](int orow, const floatx4 (&acc)[COS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < COS; ++q) {
-      if (DBG == 1) {
+      if (DBG & 1) {
         asm volatile("" ::"v"(acc[q]));
       } else {
         floatx4 *op = (floatx4 *)(o_tile + orow + (w * COS + q) * 16 + 4 * lq);
@@ -343,8 +373,8 @@ __global__ void __launch_bounds__(64 * NW)
     for (int p = 0; p < nphase; ++p) {
       const int kk = p / nch, chn = p - kk * nch;
       const int ngroups = (kseg[kk][1] + 15) >> 4;
-      store_rows();  // waits for the row loads issued one phase ago
-      __syncthreads();
+      store_rows(p);  // waits for the row loads issued one phase ago
+      if (!(DBG & 64)) __syncthreads();
       const bool more = p + 1 < nphase;
       const bool fetch_idx = (chn == 0) && (kk + 2 < nk);
       int2 prn[NIDX];
@@ -359,19 +389,21 @@ __global__ void __launch_bounds__(64 * NW)
       const int *olb = olbuf[kk % 3];
       floatx4 a_cur[NS16], a_nxt[NS16], acc_cur[COS], acc_prev[COS];
       int orow_prev = 0;
-      load_a(0, a_cur);
-      for (int g = 0; g < ngroups; ++g) {
-        const int orow = olb[g * 16 + li] * OS;
-        if (g + 1 < ngroups) load_a(g + 1, a_nxt);
-        mma_group(a_cur, acc_cur);
-        if (g > 0) scatter(orow_prev, acc_prev);
+      if (wm < ngroups) {
+        load_a(wm, a_cur);
+        for (int g = wm; g < ngroups; g += NWM) {
+          const int orow = olb[g * 16 + li] * OS;
+          if (g + NWM < ngroups) load_a(g + NWM, a_nxt);
+          mma_group(a_cur, acc_cur);
+          if (g > wm) scatter(orow_prev, acc_prev);
 #pragma unroll
-        for (int q = 0; q < COS; ++q) acc_prev[q] = acc_cur[q];
-        orow_prev = orow;
+          for (int q = 0; q < COS; ++q) acc_prev[q] = acc_cur[q];
+          orow_prev = orow;
 #pragma unroll
-        for (int sp = 0; sp < NS16; ++sp) a_cur[sp] = a_nxt[sp];
+          for (int sp = 0; sp < NS16; ++sp) a_cur[sp] = a_nxt[sp];
+        }
+        scatter(orow_prev, acc_prev);
       }
-      scatter(orow_prev, acc_prev);
       if (fetch_idx) store_indices(kk + 2, prn);
       if (more) {
 #pragma unroll
@@ -379,7 +411,7 @@ __global__ void __launch_bounds__(64 * NW)
 #pragma unroll
           for (int sp = 0; sp < NS16; ++sp) wcur[q][sp] = wnext[q][sp];
       }
-      __syncthreads();  // a_tile and this list's ol[] are free again
+      if (!(DBG & 64)) __syncthreads();  // a_tile and this list's ol[] are free again
     }
   }
   const int rows = (int)min((int64_t)M, n_out - o0);
@@ -556,15 +588,22 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / (NW * COS * 16);
-  if (NW == 4 && CK == 64 && g_conv_dbg == 1)
-    k_conv_tile2<NW, COS, CK, 1><<<(unsigned)(ntiles * ncb), 64 * NW, 0, stream>>>(
-        in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 2)
-    k_conv_tile2<NW, COS, CK, 2><<<(unsigned)(ntiles * ncb), 64 * NW, 0, stream>>>(
-        in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb);
-  else
-  k_conv_tile2<NW, COS, CK><<<(unsigned)(ntiles * ncb), 64 * NW, 0, stream>>>(
-      in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb);
+#define SCN_LAUNCH_T2(D)                                                                                   \
+  k_conv_tile2<NW, COS, CK, D><<<(unsigned)(ntiles * ncb), 64 * NW, 0, stream>>>(                          \
+      in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb)
+  if (NW == 4 && CK == 64 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 2) SCN_LAUNCH_T2(2);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 4) SCN_LAUNCH_T2(4);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 5) SCN_LAUNCH_T2(5);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 9) SCN_LAUNCH_T2(9);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 11) SCN_LAUNCH_T2(11);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 27) SCN_LAUNCH_T2(27);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 17) SCN_LAUNCH_T2(17);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 91) SCN_LAUNCH_T2(91);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 64) SCN_LAUNCH_T2(64);
+  else if (NW == 4 && CK == 64 && g_conv_dbg == 32) SCN_LAUNCH_T2(32);
+  else SCN_LAUNCH_T2(0);
+#undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();
   return 0;
 }
