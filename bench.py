@@ -162,7 +162,7 @@ def main():
     if rank == 0:
         # per-kernel HIP-event timings over the timed region (events were recorded on the launch stream)
         agg = {}
-        for kernel, flops, nbytes, e0, e1 in prof:
+        for kernel, flops, nbytes, e0, e1, _shape in prof:
             a = agg.setdefault(kernel, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops

@@ -32,11 +32,11 @@ def _prof_begin():
     return ev
 
 
-def _prof_end(ev, kernel, flops, nbytes):
+def _prof_end(ev, kernel, flops, nbytes, shape=None):
     if ev is not None:
         end = torch.cuda.Event(enable_timing=True)
         end.record()
-        PROFILE.append((kernel, flops, nbytes, ev, end))
+        PROFILE.append((kernel, flops, nbytes, ev, end, shape))
 
 
 def _lib_():
@@ -280,7 +280,8 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     # algorithmic work of one launch: flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
     R = rb.total_pairs
-    _prof_end(ev, "conv_tile", 2.0 * R * Ci * Co, 4.0 * (R * Ci + n_out * Co) + 8.0 * R + 4.0 * K * Ci * Co)
+    _prof_end(ev, "conv_tile", 2.0 * R * Ci * Co, 4.0 * (R * Ci + n_out * Co) + 8.0 * R + 4.0 * K * Ci * Co,
+              (K, n_out, Ci, Co, int(w_transposed)))
 
 
 def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse):
@@ -300,7 +301,8 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
         check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts), K,
                                    rb.stride, in_col, out_col, Ci, Co, stream()))
         R = rb.total_pairs
-        _prof_end(ev, "dw_tile", 2.0 * R * Ci * Co, 4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co)
+        _prof_end(ev, "dw_tile", 2.0 * R * Ci * Co, 4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co,
+                  (K, inp.size(0), Ci, Co, 0))
     if d_bias is not None and d_bias.numel():
         check(lib.scn_column_sum(ptr(d_out), ptr(d_bias), d_out.size(0), Co, stream()))
 

@@ -20,6 +20,8 @@
 // float atomics into dW (as the reference, sparseconvnet/SCN/CUDA/Convolution.cu:749).
 #include "scn_common.h"
 
+#include <type_traits>
+
 namespace scn {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -169,14 +171,14 @@ __global__ void __launch_bounds__(256)
 //     16 input planes;
 //   * workgroups are renumbered so that each XCD owns a contiguous range of tiles: neighbouring tiles
 //     gather overlapping rows and now share one L2.
-template <int NW, int COS, int CK, int DBG = 0, int NWM = 1>
+template <int NW, int COS, int CK, int DBG = 0, int NWM = 1, int M_ = 0>
 __global__ void __launch_bounds__(64 * NW * NWM)
     k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb) {
   // requires Ci % CK == 0 (the launcher picks CK as the largest of 64/32/16 dividing Ci)
-  constexpr int M = 32 * NW;
+  constexpr int M = M_ ? M_ : 32 * NW;
   constexpr int COB = NW * COS * 16;
   constexpr int NT = 64 * NW * NWM;  // NWM waves share each plane slice and split the pair groups
   constexpr int AS = CK + 4;
@@ -316,26 +318,6 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     // covered by the partner wave (two chains + a final add measured 3-5 % slower)
 #pragma unroll
     for (int q = 0; q < COS; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-    if ((DBG & 32) && NS16 == 4) {
-      floatx4 acc2[COS];
-#pragma unroll
-      for (int q = 0; q < COS; ++q) {
-        acc2[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].x, a[sp].x, acc[q], 0, 0, 0);
-          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp + 2].x, a[sp + 2].x, acc2[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].y, a[sp].y, acc[q], 0, 0, 0);
-          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp + 2].y, a[sp + 2].y, acc2[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].z, a[sp].z, acc[q], 0, 0, 0);
-          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp + 2].z, a[sp + 2].z, acc2[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].w, a[sp].w, acc[q], 0, 0, 0);
-          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp + 2].w, a[sp + 2].w, acc2[q], 0, 0, 0);
-        }
-        acc[q] += acc2[q];
-      }
-      return;
-    }
 #pragma unroll
     for (int sp = 0; sp < NS16; ++sp)
 #pragma unroll
@@ -344,6 +326,28 @@ __global__ void __launch_bounds__(64 * NW * NWM)
         acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].y, a[sp].y, acc[q], 0, 0, 0);
         acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].z, a[sp].z, acc[q], 0, 0, 0);
         acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].w, a[sp].w, acc[q], 0, 0, 0);
+      }
+  };
+  auto mma_group2 = [&](const floatx4 (&a0)[NS16], const floatx4 (&a1)[NS16], floatx4 (&acc0)[COS],
+                        floatx4 (&acc1)[COS]) __attribute__((always_inline)) {
+    // two pair groups at once: two independent accumulator chains, MFMAs alternate between them
+#pragma unroll
+    for (int q = 0; q < COS; ++q) {
+      acc0[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      acc1[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp)
+#pragma unroll
+      for (int q = 0; q < COS; ++q) {
+        acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].x, a0[sp].x, acc0[q], 0, 0, 0);
+        acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].x, a1[sp].x, acc1[q], 0, 0, 0);
+        acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].y, a0[sp].y, acc0[q], 0, 0, 0);
+        acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].y, a1[sp].y, acc1[q], 0, 0, 0);
+        acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].z, a0[sp].z, acc0[q], 0, 0, 0);
+        acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].z, a1[sp].z, acc1[q], 0, 0, 0);
+        acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].w, a0[sp].w, acc0[q], 0, 0, 0);
+        acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].w, a1[sp].w, acc1[q], 0, 0, 0);
       }
   };
   auto scatter = [&](int orow, const floatx4 (&acc)[COS]) __attribute__((always_inline)) {
@@ -374,7 +378,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
       const int kk = p / nch, chn = p - kk * nch;
       const int ngroups = (kseg[kk][1] + 15) >> 4;
       store_rows(p);  // waits for the row loads issued one phase ago
-      if (!(DBG & 64)) __syncthreads();
+      __syncthreads();
       const bool more = p + 1 < nphase;
       const bool fetch_idx = (chn == 0) && (kk + 2 < nk);
       int2 prn[NIDX];
@@ -387,6 +391,46 @@ __global__ void __launch_bounds__(64 * NW * NWM)
       // software pipeline over the pair groups: fragments of group g+1 are read while the MFMAs of
       // group g run; the result of group g is added to the output tile behind the MFMAs of group g+1
       const int *olb = olbuf[kk % 3];
+      if (!(DBG & 32) && NWM == 1) {
+        // NG pair groups per pass: NG independent accumulator chains whose MFMAs alternate, all A
+        // fragments requested up front, all NG results added to the output tile behind the MFMAs
+        auto pass = [&](int g, auto ng_tag) __attribute__((always_inline)) {
+          constexpr int NG = decltype(ng_tag)::value;
+          floatx4 a[NG][NS16], c[NG][COS];
+          int orow[NG];
+#pragma unroll
+          for (int i = 0; i < NG; ++i) {
+            orow[i] = olb[(g + i) * 16 + li] * OS;
+            load_a(g + i, a[i]);
+#pragma unroll
+            for (int q = 0; q < COS; ++q) c[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int sp = 0; sp < NS16; ++sp)
+#pragma unroll
+            for (int q = 0; q < COS; ++q) {
+#pragma unroll
+              for (int i = 0; i < NG; ++i)
+                c[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].x, a[i][sp].x, c[i][q], 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < NG; ++i)
+                c[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].y, a[i][sp].y, c[i][q], 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < NG; ++i)
+                c[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].z, a[i][sp].z, c[i][q], 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < NG; ++i)
+                c[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[q][sp].w, a[i][sp].w, c[i][q], 0, 0, 0);
+            }
+#pragma unroll
+          for (int i = 0; i < NG; ++i) scatter(orow[i], c[i]);
+        };
+        int g = 0;
+        if (!(DBG & 64))
+          for (; g + 3 < ngroups; g += 4) pass(g, std::integral_constant<int, 4>{});
+        for (; g + 1 < ngroups; g += 2) pass(g, std::integral_constant<int, 2>{});
+        if (g < ngroups) pass(g, std::integral_constant<int, 1>{});
+      } else {
       floatx4 a_cur[NS16], a_nxt[NS16], acc_cur[COS], acc_prev[COS];
       int orow_prev = 0;
       if (wm < ngroups) {
@@ -404,6 +448,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
         }
         scatter(orow_prev, acc_prev);
       }
+      }
       if (fetch_idx) store_indices(kk + 2, prn);
       if (more) {
 #pragma unroll
@@ -411,7 +456,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
 #pragma unroll
           for (int sp = 0; sp < NS16; ++sp) wcur[q][sp] = wnext[q][sp];
       }
-      if (!(DBG & 64)) __syncthreads();  // a_tile and this list's ol[] are free again
+      __syncthreads();  // a_tile and this list's ol[] are free again
     }
   }
   const int rows = (int)min((int64_t)M, n_out - o0);
@@ -580,38 +625,37 @@ static int launch_tile(const float *in, float *out, const float *W, const float 
   return 0;
 }
 
-template <int NW, int COS, int CK>
+template <int NW, int COS, int CK, int NWM = 1, int M_ = 0>
 static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias,
                         const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                         int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
-  constexpr int M = 32 * NW;
+  constexpr int M = M_ ? M_ : 32 * NW;
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / (NW * COS * 16);
 #define SCN_LAUNCH_T2(D)                                                                                   \
-  k_conv_tile2<NW, COS, CK, D><<<(unsigned)(ntiles * ncb), 64 * NW, 0, stream>>>(                          \
+  k_conv_tile2<NW, COS, CK, D, NWM, M_><<<(unsigned)(ntiles * ncb), 64 * NW * NWM, 0, stream>>>(          \
       in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb)
-  if (NW == 4 && CK == 64 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 2) SCN_LAUNCH_T2(2);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 4) SCN_LAUNCH_T2(4);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 5) SCN_LAUNCH_T2(5);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 9) SCN_LAUNCH_T2(9);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 11) SCN_LAUNCH_T2(11);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 27) SCN_LAUNCH_T2(27);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 17) SCN_LAUNCH_T2(17);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 91) SCN_LAUNCH_T2(91);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 64) SCN_LAUNCH_T2(64);
-  else if (NW == 4 && CK == 64 && g_conv_dbg == 32) SCN_LAUNCH_T2(32);
+  if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 9) SCN_LAUNCH_T2(9);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 27) SCN_LAUNCH_T2(27);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 32) SCN_LAUNCH_T2(32);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 64) SCN_LAUNCH_T2(64);
   else SCN_LAUNCH_T2(0);
 #undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();
   return 0;
 }
 
+static int g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile (A/B runs)
+static int g_conv_wide = 0;  // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
+
 template <int NW>
 static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias,
                            const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                            int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
+  if (NW == 4 && g_conv_wide && Ci % 64 == 0 && Co % 128 == 0)
+    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
   if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
   if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
   return launch_tile2<NW, 1, 16>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
@@ -626,6 +670,14 @@ int scn_set_tuning(int key, int value) {
   }
   if (key == 1) {
     g_conv_dbg = value;
+    return 0;
+  }
+  if (key == 2) {
+    g_conv_wide = value;
+    return 0;
+  }
+  if (key == 3) {
+    g_conv_small_off = value;
     return 0;
   }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
@@ -659,9 +711,17 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     }
     k_weight_pack<<<pg, 256, 0, stream>>>(W, Wp, K, Ci, Co, w_transposed, w_reverse, 1);
     SCN_CHECK_LAUNCH();
-    if (s16 % 4 == 0) return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-    if (s16 % 3 == 0) return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-    if (s16 % 2 == 0) return launch_tile2_ck<2>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    // Tile shape: 4 waves (128 rows x 64 planes) when that still yields >= 2 workgroups per CU; the
+    // coarse UNet levels (a few hundred to a few thousand sites) get 64x32 or 32x16 tiles instead, so
+    // that all 256 CUs have work (their features and weights are L2 resident, the re-gather is free).
+    auto blocks = [&](int nw) { return ((n_out + 32 * nw - 1) / (32 * nw)) * (int64_t)(Co / (16 * nw)); };
+    const int64_t want = 512;
+    if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off))
+      return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    if (s16 % 3 == 0 && s16 % 2 != 0)
+      return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    if (s16 % 2 == 0 && (blocks(2) >= want || g_conv_small_off))
+      return launch_tile2_ck<2>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
     return launch_tile2_ck<1>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
