@@ -507,14 +507,13 @@ __global__ void __launch_bounds__(256)
 
 // ---------------------------------------------------------------- dWeight ---
 // block: 4 waves as 2x2; wave owns TI x TJ 16x16 tiles; block tile CIB x COB.
-template <int TI, int TJ>
+template <int TI, int TJ, int PS = 32>
 __global__ void __launch_bounds__(256)
     k_dw_tile(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
               const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
               int in_col, int Ci, int Co, int chunk) {
   constexpr int CIB = 32 * TI, COB = 32 * TJ;
   constexpr int IS = CIB + 16, DS = COB + 16;  // row strides: (stride % 32) == 16 -> ds_read_b32 conflict-free
-  constexpr int PS = 32;                       // pairs per staged step
   __shared__ __attribute__((aligned(16))) float in_t[PS * IS];
   __shared__ __attribute__((aligned(16))) float do_t[PS * DS];
   const int k = blockIdx.y;
@@ -535,28 +534,53 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int b = 0; b < TJ; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+  // Staging is software pipelined and branch free: the pair indices of step s+2 and the rows of step
+  // s+1 are requested into registers before the MFMAs of step s; rows past the end of the chunk are
+  // clamped to its last pair and multiplied by zero.
+  constexpr int NI = PS * (CIB / 4) / 256;  // 16-byte chunks of input rows per thread and step
+  constexpr int ND = PS * (COB / 4) / 256;
+  static_assert(NI >= 1 && ND >= 1, "tile too small for 256 threads");
+  int2 pi_[NI], pd_[ND];
+  floatx4 ri[NI], rd[ND];
+  auto load_pairs = [&](int pb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pi_[j] = rk[min(pb + (tid + j * 256) / (CIB / 4), p1 - 1)];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) pd_[j] = rk[min(pb + (tid + j * 256) / (COB / 4), p1 - 1)];
+  };
+  auto load_rows = [&](int pb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int idx = tid + j * 256, row = idx / (CIB / 4), ch = idx % (CIB / 4);
+      const floatx4 v = *(const floatx4 *)(in + (int64_t)(in_col ? pi_[j].y : pi_[j].x) * Ci + ci0 + ch * 4);
+      ri[j] = v * ((pb + row < p1) ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const int idx = tid + j * 256, row = idx / (COB / 4), ch = idx % (COB / 4);
+      const floatx4 v = *(const floatx4 *)(dout + (int64_t)(in_col ? pd_[j].x : pd_[j].y) * Co + co0 + ch * 4);
+      rd[j] = v * ((pb + row < p1) ? 1.f : 0.f);
+    }
+  };
+  load_pairs(p0);
+  load_rows(p0);
+  load_pairs(p0 + PS);
   for (int pb = p0; pb < p1; pb += PS) {
-    __syncthreads();
-    // stage 32 pairs: in rows [32 x CIB], dout rows [32 x COB]; zero rows past the end
-    for (int idx = tid; idx < PS * (CIB / 4); idx += 256) {
-      const int row = idx / (CIB / 4), ch = idx % (CIB / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pb + row < p1) {
-        const int2 p = rk[pb + row];
-        v = *(const float4 *)(in + (int64_t)(in_col ? p.y : p.x) * Ci + ci0 + ch * 4);
-      }
-      *(float4 *)(in_t + row * IS + ch * 4) = v;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int idx = tid + j * 256;
+      *(floatx4 *)(in_t + (idx / (CIB / 4)) * IS + (idx % (CIB / 4)) * 4) = ri[j];
     }
-    for (int idx = tid; idx < PS * (COB / 4); idx += 256) {
-      const int row = idx / (COB / 4), ch = idx % (COB / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pb + row < p1) {
-        const int2 p = rk[pb + row];
-        v = *(const float4 *)(dout + (int64_t)(in_col ? p.x : p.y) * Co + co0 + ch * 4);
-      }
-      *(float4 *)(do_t + row * DS + ch * 4) = v;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const int idx = tid + j * 256;
+      *(floatx4 *)(do_t + (idx / (COB / 4)) * DS + (idx % (COB / 4)) * 4) = rd[j];
     }
     __syncthreads();
+    if (pb + PS < p1) {
+      load_rows(pb + PS);       // indices were requested one step ago
+      load_pairs(pb + 2 * PS);  // clamped: harmless past the end
+    }
 #pragma unroll
     for (int ps = 0; ps < PS / 4; ++ps) {
       float a[TI], b[TJ];
@@ -571,6 +595,7 @@ __global__ void __launch_bounds__(256)
         for (int tb = 0; tb < TJ; ++tb)
           acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
+    __syncthreads();
   }
   // D[row = ci][col = co]: lane holds rows 4 lq + r, column li
 #pragma unroll
@@ -744,10 +769,13 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     const unsigned gx = (unsigned)((stride + chunk - 1) / chunk);
     if (Ci % 64 == 0 && Co % 64 == 0) {
       dim3 grid(gx, K, (Ci / 64) * (Co / 64));
-      k_dw_tile<2, 2><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+      if (g_conv_dbg == 100)  // A/B: 32 pairs per step
+        k_dw_tile<2, 2, 32><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+      else
+        k_dw_tile<2, 2, 64><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
     } else {
       dim3 grid(gx, K, (Ci / 32) * (Co / 32));
-      k_dw_tile<1, 1><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+      k_dw_tile<1, 1, 64><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
     }
     SCN_CHECK_LAUNCH();
     return 0;

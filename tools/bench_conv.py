@@ -59,12 +59,14 @@ def main():
                     lib.scn_set_tuning(2, int(v) // 1000)
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                     line += "  v%s %.3f ms %.1f TF" % (v, ms, flops / ms / 1e9)
-                if args.dw:
+                for dv in ([0, 100] if args.dw else []):
+                    lib.scn_set_tuning(1, dv)
                     dy = torch.randn(n, co, device=dev)
                     dw = torch.zeros_like(w)
                     ms = timeit(lambda: _lib.check(lib.scn_conv_dweight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
                                 rb.rules.data_ptr(), rb.counts.data_ptr(), 27, rb.stride, 0, 1, ci, co, _lib.stream())))
-                    line += "  dW %.3f ms %.1f TF" % (ms, flops / ms / 1e9)
+                    line += "  dW[%d] %.3f ms %.1f TF" % (dv, ms, flops / ms / 1e9)
+                lib.scn_set_tuning(1, 0)
                 print(line, flush=True)
         out_size = size // 2
         md.getRuleBook(size, out_size, f2, f2)
