@@ -466,43 +466,79 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   }
 }
 
-// generic fallback (any Ci, Co; scalar FMA): 32 output rows x 64 planes per block
+// generic fallback (any Ci, Co; scalar FMA; used by the 3 -> m stem): 32 output rows x 64 planes per
+// block.  The tile's segments of all K lists are first inverted into an LDS table src[k][row] (one
+// barrier), then thread (row, 8 planes) walks the offsets on its own: no per-offset barrier, the
+// weights (K*Ci*64 floats) sit in LDS when they fit.
+template <bool W_IN_LDS>
 __global__ void __launch_bounds__(256)
     k_conv_generic(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
                    const float *__restrict__ bias, const int2 *__restrict__ rules,
                    const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                    int64_t n_out, int n_gran, int Ci, int Co, int w_transposed, int w_reverse) {
   constexpr int M = SCN_TILE_GRANULE;
-  __shared__ float o_tile[M][65];
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [K][Ci][64] when W_IN_LDS
+  __shared__ int src[KMAX][M];
   const int tid = threadIdx.x;
   const int64_t o0 = (int64_t)blockIdx.x * M;
-  const int co = blockIdx.y * 64 + (tid & 63);
-  const int pj = tid >> 6;  // 4 pairs in flight
-  for (int i = tid; i < M * 64; i += 256) o_tile[i >> 6][i & 63] = (bias && co < Co) ? bias[co] : 0.f;
+  const int cb = blockIdx.y * 64;
+  for (int i = tid; i < K * M; i += 256) src[i / M][i % M] = -1;
+  if (W_IN_LDS)
+    for (int i = tid; i < K * Ci * 64; i += 256) {
+      const int k = i / (Ci * 64), r = i % (Ci * 64), ci = r / 64, co = cb + r % 64;
+      const int ks = w_reverse ? K - 1 - k : k;
+      float v = 0.f;
+      if (co < Co) v = w_transposed ? W[((int64_t)ks * Co + co) * Ci + ci] : W[((int64_t)ks * Ci + ci) * Co + co];
+      wl[i] = v;
+    }
   __syncthreads();
   for (int k = 0; k < K; ++k) {
     const int s = bases[(int64_t)k * (n_gran + 1) + blockIdx.x];
     const int e = bases[(int64_t)k * (n_gran + 1) + blockIdx.x + 1];
     const int2 *rk = rules + (int64_t)k * stride;
-    if (co < Co)
-      for (int j = s + pj; j < e; j += 4) {
-        const int2 p = rk[j];
-        const int src = in_col ? p.y : p.x;
-        const int dst = (int)((in_col ? p.x : p.y) - o0);
-        const float *ip = in + (int64_t)src * Ci;
-        const int ks = w_reverse ? K - 1 - k : k;
-        // element (ci, co) of list k: transposed ? W[ks][co][ci] : W[ks][ci][co]
-        const float *wp = W + (int64_t)ks * Ci * Co + (w_transposed ? (int64_t)co * Ci : co);
-        const int64_t ws = w_transposed ? 1 : Co;
-        float acc = 0.f;
-        for (int ci = 0; ci < Ci; ++ci) acc += ip[ci] * wp[ci * ws];
-        o_tile[dst][tid & 63] += acc;  // one pair per output row inside a list: no race
-      }
-    __syncthreads();
+    for (int j = s + tid; j < e; j += 256) {
+      const int2 p = rk[j];
+      src[k][(int)((in_col ? p.x : p.y) - o0)] = in_col ? p.y : p.x;
+    }
   }
-  const int rows = (int)min((int64_t)M, n_out - o0);
-  if (co < Co)
-    for (int r = pj; r < rows; r += 4) out[(o0 + r) * Co + co] = o_tile[r][tid & 63];
+  __syncthreads();
+  const int r = tid >> 3, cg = (tid & 7) * 8;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = (bias && cb + cg + c < Co) ? bias[cb + cg + c] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int i = src[k][r];
+    if (i < 0) continue;
+    const float *ip = in + (int64_t)i * Ci;
+    const int ks = w_reverse ? K - 1 - k : k;
+    for (int ci = 0; ci < Ci; ++ci) {
+      const float x = ip[ci];
+      if (W_IN_LDS) {
+        const float4 w0 = *(const float4 *)(wl + (k * Ci + ci) * 64 + cg);
+        const float4 w1 = *(const float4 *)(wl + (k * Ci + ci) * 64 + cg + 4);
+        acc[0] += x * w0.x; acc[1] += x * w0.y; acc[2] += x * w0.z; acc[3] += x * w0.w;
+        acc[4] += x * w1.x; acc[5] += x * w1.y; acc[6] += x * w1.z; acc[7] += x * w1.w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int co = cb + cg + c;
+          if (co < Co)
+            acc[c] += x * (w_transposed ? W[((int64_t)ks * Co + co) * Ci + ci] : W[((int64_t)ks * Ci + ci) * Co + co]);
+        }
+      }
+    }
+  }
+  if (o0 + r < n_out) {
+    float *op = out + (o0 + r) * Co + cb + cg;
+    if (Co % 4 == 0 && cb + cg + 8 <= Co) {
+      *(float4 *)op = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *(float4 *)(op + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (cb + cg + c < Co) op[c] = acc[c];
+    }
+  }
 }
 
 // ---------------------------------------------------------------- dWeight ---
@@ -624,9 +660,18 @@ __global__ void __launch_bounds__(256)
   for (int e = threadIdx.x; e < Ci * Co; e += 256) {
     const int ci = e / Co, co = e % Co;
     float acc = 0.f;
-    for (int p = p0; p < p1; ++p) {
-      const int2 pr = rk[p];
-      acc += in[(int64_t)(in_col ? pr.y : pr.x) * Ci + ci] * dout[(int64_t)(in_col ? pr.x : pr.y) * Co + co];
+    for (int p = p0; p < p1; p += 8) {  // 8 independent pair -> row load chains in flight
+      int2 pr[8];
+      float x[8], d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pr[u] = rk[min(p + u, p1 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        x[u] = in[(int64_t)(in_col ? pr[u].y : pr[u].x) * Ci + ci];
+        d[u] = dout[(int64_t)(in_col ? pr[u].x : pr[u].y) * Co + co];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (p + u < p1) ? x[u] * d[u] : 0.f;
     }
     unsafeAtomicAdd(dW + ((int64_t)k * Ci + ci) * Co + co, acc);
   }
@@ -751,8 +796,13 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)n_gran, (unsigned)((Co + 63) / 64));
-  k_conv_generic<<<grid, 256, 0, stream>>>(in, out, W, bias, (const int2 *)rules, bases, K, stride, in_col,
-                                          n_out, n_gran, Ci, Co, w_transposed, w_reverse);
+  const size_t wbytes = (size_t)K * Ci * 64 * 4;
+  if (wbytes <= 40 * 1024)
+    k_conv_generic<true><<<grid, 256, wbytes, stream>>>(in, out, W, bias, (const int2 *)rules, bases, K, stride,
+                                                        in_col, n_out, n_gran, Ci, Co, w_transposed, w_reverse);
+  else
+    k_conv_generic<false><<<grid, 256, 0, stream>>>(in, out, W, bias, (const int2 *)rules, bases, K, stride,
+                                                    in_col, n_out, n_gran, Ci, Co, w_transposed, w_reverse);
   SCN_CHECK_LAUNCH();
   return 0;
 }
