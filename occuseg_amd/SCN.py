@@ -56,6 +56,16 @@ def _need_cuda(t, what):
         raise RuntimeError("occuseg_amd.SCN.%s: only float32 features are supported" % what)
 
 
+# Rulebook requests seen during the previous forward pass, keyed by the input spatial size.  The
+# reference builds every rulebook lazily at first use (sparseconvnet/SCN/Metadata/Metadata.cpp:504-529,
+# :598-625); doing that here would put a stream synchronisation (site counts are data dependent) in
+# the middle of the queued convolutions of every level.  Instead the next InputLayer call replays
+# the recorded requests up front, while the queue is still empty, so the host runs ahead of the GPU
+# for the rest of the step.  Purely a scheduling matter: the lazily built result is identical.
+_PLANS = {}
+PREBUILD = True
+
+
 class _Grid(object):
     """Active sites of one scale (device resident)."""
     __slots__ = ("n", "coords", "keys", "hash_keys", "hash_vals", "hash_cap")
@@ -111,6 +121,7 @@ class Metadata_3(object):
         self.input_order = None
         self.input_site_of_row = None
         self.input_site_start = None
+        self._plan = []
 
     def setNormalGuideScale(self, s):
         self.normal_guide_scale = int(s)
@@ -167,6 +178,25 @@ class Metadata_3(object):
         self.input_mode = int(mode)
         self.input_P = P
         self.input_order, self.input_site_of_row, self.input_site_start = order, site_of_row, site_start
+        old_plan = _PLANS.get(key, [])
+        self._plan = []          # requests made by the ops of THIS forward pass (stale ones drop out)
+        _PLANS[key] = self._plan
+        if PREBUILD and old_plan:
+            pending = []
+            for req in old_plan:
+                if req[0] == "sub":
+                    rb = self.getSubmanifoldRuleBook(req[1], req[2], _defer=True)
+                    pending.append(rb)
+                else:
+                    self.getRuleBook(req[1], req[2], req[3], req[4], _defer=True)
+            if pending:  # ONE device->host copy for the pair counts of all submanifold rulebooks
+                totals = torch.stack([rb.counts.sum() for rb in pending]).cpu().tolist()
+                for rb, t in zip(pending, totals):
+                    rb.total_pairs = int(t)
+
+    def _record(self, req):
+        if req not in self._plan:
+            self._plan.append(req)
 
     def getNActive(self, spatialSize):
         return self.nActive[_size_key(spatialSize)]
@@ -185,7 +215,7 @@ class Metadata_3(object):
         rb.bases[out_col] = bases
         rb.n_rows[out_col] = n_out
 
-    def getSubmanifoldRuleBook(self, spatialSize, filterSize, dilated_rate=1):
+    def getSubmanifoldRuleBook(self, spatialSize, filterSize, dilated_rate=1, _defer=False):
         """cache key (spatialSize, filterSize) as sparseconvnet/SCN/Metadata/Metadata.cpp:504-529"""
         fs = _size_key(filterSize)
         if fs != (3, 3, 3):
@@ -211,11 +241,14 @@ class Metadata_3(object):
             rb = _RuleBook(27, N, rules, counts)
             rb.nbr = nbr
             self._tile_bases(rb, 1, N)
-            rb.total_pairs = int(counts.sum().item())
+            if not _defer:
+                rb.total_pairs = int(counts.sum().item())
             self.submanifoldRuleBooks[key] = rb
+        if not _defer:
+            self._record(("sub", key[:3], fs))
         return rb
 
-    def getRuleBook(self, inputSpatialSize, outputSpatialSize, size, stride):
+    def getRuleBook(self, inputSpatialSize, outputSpatialSize, size, stride, _defer=False):
         """Metadata::getRuleBook (sparseconvnet/SCN/Metadata/Metadata.cpp:598-625): builds the coarse
         grid as a side effect and sets nActive[outputSpatialSize]."""
         fs, st = _size_key(size), _size_key(stride)
@@ -244,6 +277,8 @@ class Metadata_3(object):
             self._tile_bases(rb, 0, Nf)
             rb.total_pairs = Nf  # every fine site appears in exactly one list
             self.ruleBooks[key] = rb
+        if not _defer:
+            self._record(("conv", iS, oS, fs, st))
         return rb
 
     # -- host views for tests / tooling ---------------------------------------

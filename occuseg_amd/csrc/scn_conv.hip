@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
-                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb) {
+                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb, int ksplit) {
   // requires Ci % CK == 0 (the launcher picks CK as the largest of 64/32/16 dividing Ci)
   constexpr int M = M_ ? M_ : 32 * NW;
   constexpr int COB = NW * COS * 16;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
 
   for (int i = tid; i < M * COB; i += NT) {
     const int r = i / COB, c = i % COB;
-    o_tile[r * OS + c] = bias ? bias[co0 + c] : 0.f;
+    o_tile[r * OS + c] = (bias && blockIdx.y == 0) ? bias[co0 + c] : 0.f;
   }
   if (tid < 64) {
     // one lane per kernel offset: segment of list k inside this tile, then a ballot-compacted list of
@@ -227,8 +227,10 @@ __global__ void __launch_bounds__(64 * NW * NWM)
       s = bases[(int64_t)tid * (n_gran + 1) + g0];
       e = bases[(int64_t)tid * (n_gran + 1) + g1];
     }
-    const unsigned long long m = __ballot(e > s);
-    if (e > s) {
+    // ksplit > 1 (coarse levels): this workgroup takes the offsets k == blockIdx.y (mod ksplit)
+    const bool mine = e > s && (tid % ksplit) == (int)blockIdx.y;
+    const unsigned long long m = __ballot(mine);
+    if (mine) {
       const int pos = __popcll(m & ((1ull << tid) - 1ull));
       klist[pos] = tid;
       kseg[pos][0] = s;
@@ -460,9 +462,17 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     }
   }
   const int rows = (int)min((int64_t)M, n_out - o0);
-  for (int i = tid; i < rows * (COB / 4); i += NT) {
-    const int r = i / (COB / 4), c4 = i % (COB / 4);
-    *(float4 *)(out + (o0 + r) * Co + co0 + c4 * 4) = *(const float4 *)(o_tile + r * OS + c4 * 4);
+  if (ksplit == 1) {
+    for (int i = tid; i < rows * (COB / 4); i += NT) {
+      const int r = i / (COB / 4), c4 = i % (COB / 4);
+      *(float4 *)(out + (o0 + r) * Co + co0 + c4 * 4) = *(const float4 *)(o_tile + r * OS + c4 * 4);
+    }
+  } else if (nphase > 0 || blockIdx.y == 0) {
+    // partial sums of an offset subset: `out` was zeroed by the launcher, float atomics combine them
+    for (int i = tid; i < rows * COB; i += NT) {
+      const int r = i / COB, c = i % COB;
+      unsafeAtomicAdd(out + (o0 + r) * Co + co0 + c, o_tile[r * OS + c]);
+    }
   }
 }
 
@@ -681,6 +691,7 @@ __global__ void __launch_bounds__(256)
 using namespace scn;
 
 static int g_conv_dbg = 0;
+static int g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile, never split offsets (A/B runs)
 static int g_conv_variant = 2;  // 1 = first synchronous kernel (kept for A/B runs), 2 = pipelined
 
 template <int NW, int COS, int M, int CK>
@@ -703,9 +714,17 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / (NW * COS * 16);
+  // coarse UNet levels: too few tiles to fill 256 CUs and every workgroup walks all K offsets one
+  // after the other -> split the offsets over up to 27 workgroups per tile and combine with atomics
+  int ksplit = 1;
+  if (!g_conv_small_off && K > 1 && (NW < 4 || (int64_t)ntiles * ncb < 512))
+    while (ksplit < 27 && (int64_t)ntiles * ncb * ksplit < 4096) ksplit *= 3;
+  if (ksplit > K) ksplit = K;
+  if (ksplit > 1) SCN_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)n_out * Co * sizeof(float), stream));
+  const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_T2(D)                                                                                   \
-  k_conv_tile2<NW, COS, CK, D, NWM, M_><<<(unsigned)(ntiles * ncb), 64 * NW * NWM, 0, stream>>>(          \
-      in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb)
+  k_conv_tile2<NW, COS, CK, D, NWM, M_><<<grid2, 64 * NW * NWM, 0, stream>>>(                             \
+      in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit)
   if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 9) SCN_LAUNCH_T2(9);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 27) SCN_LAUNCH_T2(27);
@@ -717,7 +736,6 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   return 0;
 }
 
-static int g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile (A/B runs)
 static int g_conv_wide = 0;  // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 template <int NW>
