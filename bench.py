@@ -173,12 +173,24 @@ def main():
             kernels[kname] = {"launches": cnt, "avg_ms": 1e3 * secs / cnt, "tflops": flops / secs / 1e12,
                               "algo_GBs": nbytes / secs / 1e9, "share_of_step": secs / dt}
         dom = max(agg, key=lambda k: agg[k][3]) if agg else None
+        # HBM bytes per launch of the dominant kernel: rocprofv3 PMC counters cannot be read from inside
+        # this process; they are collected by running THIS command under `rocprofv3 --pmc FETCH_SIZE` and
+        # `--pmc WRITE_SIZE` (separate passes) and summarised by tools/pmc_traffic.py into profiles/.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.m == 64 and args.scenes_per_gpu == 4 and args.sites == 150000:
+            try:
+                traffic = json.load(open(tpath)).get(dom or "", {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
         roof = None
         if dom:
             cnt, flops, nbytes, secs = agg[dom]
             achieved = (flops / cnt) / (secs / cnt) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this "
+                                      "command; FETCH_SIZE x2 per the gfx950 note)" if traffic else None,
                     "launches": cnt, "avg_launch_ms": 1e3 * secs / cnt,
                     "algo_flops_per_launch": flops / cnt, "algo_bytes_per_launch": nbytes / cnt,
                     "algo_GBs": nbytes / secs / 1e9, "hbm_frac_of_8TBs": nbytes / secs / 1e9 / HBM_PEAK_GBS}
