@@ -245,6 +245,8 @@ class Metadata_3(object):
                 rb.total_pairs = int(counts.sum().item())
             self.submanifoldRuleBooks[key] = rb
         if not _defer:
+            if rb.total_pairs is None:
+                rb.total_pairs = int(rb.counts.sum().item())
             self._record(("sub", key[:3], fs))
         return rb
 

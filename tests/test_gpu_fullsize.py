@@ -1,0 +1,87 @@
+"""-m gpu: BASELINE.json's full sizes through size-independent properties (the oracle would take
+minutes there).  configs[4]: 2M-active-voxel single layer, m=128, on (5b) a solid 126^3 block and
+(5a) a 160^3 Bernoulli(0.488) grid."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F3 = torch.tensor([3, 3, 3])
+
+
+def _meta(coords, gpu):
+    from occuseg_amd import SCN
+    m = SCN.Metadata_3()
+    size = torch.tensor([4096] * 3)
+    m.inputLayer(size, torch.from_numpy(coords), 0, 4, gpu)
+    return m, size
+
+
+def test_solid_block_2m_sites_m128(gpu):
+    from occuseg_amd import SCN, scenes
+    side = 126
+    coords = scenes.solid_block(side, offset=3)
+    m, size = _meta(coords, gpu)
+    n = side ** 3
+    assert m.getNActive(size) == n == 2000376
+    rb = m.getSubmanifoldRuleBook(size, F3)
+    # closed form: offset (dx,dy,dz) has (side-|dx|)(side-|dy|)(side-|dz|) pairs
+    want = [(side - abs(dx)) * (side - abs(dy)) * (side - abs(dz)) for dx in (-1, 0, 1) for dy in (-1, 0, 1)
+            for dz in (-1, 0, 1)]
+    assert rb.counts.cpu().tolist() == want
+    assert rb.total_pairs == (3 * side - 2) ** 3
+    # site order is (z,y,x)-major: site id of (x,y,z) = (z*side + y)*side + x; check list 0 = offset (-1,-1,-1)
+    r0 = rb.rules[0, :5].cpu().numpy()
+    first_out = (1 * side + 1) * side + 1
+    assert r0[0].tolist() == [0, first_out] and np.all(np.diff(r0[:, 1]) > 0)
+    # linearity / counting property: ones (x) ones -> out[o] = Ci * (#active neighbours of o)
+    ci = co = 128
+    x = torch.ones(n, ci, device=gpu)
+    w = torch.ones(27, ci, co, device=gpu)
+    out = torch.empty(0, device=gpu)
+    macs = SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x, out, w, torch.empty(0, device=gpu), 1)
+    assert macs == float((3 * side - 2) ** 3) * ci * co
+    nb = (rb.nbr >= 0).sum(0).to(torch.float32)            # neighbours per site, from the device table
+    assert torch.equal(out[:, 0], nb * ci) and torch.equal(out[:, co - 1], nb * ci)
+    assert float(out.sum().item()) == float((3 * side - 2) ** 3) * ci * co  # exact in fp32? (integers < 2^24 per term)
+    # dInput of ones equals the forward by the k <-> 26-k symmetry; dWeight[k] = pairs_k everywhere
+    gi, gw = torch.empty(0, device=gpu), torch.zeros(27, ci, co, device=gpu)
+    SCN.SubmanifoldConvolution_backward(size, F3, m, x, gi, torch.ones(n, co, device=gpu), w, gw,
+                                        torch.empty(0, device=gpu), 1)
+    assert torch.equal(gi[:, 0], nb * co)
+    got = gw[:, 0, 0].cpu().numpy()
+    assert np.allclose(got, np.array(want, np.float64), rtol=1e-6)
+
+
+def test_bernoulli_2m_sites_symmetry_and_checksum(gpu):
+    from occuseg_amd import SCN, scenes
+    coords = scenes.bernoulli_grid(160, 0.488, 7, offset=2)
+    m, size = _meta(coords, gpu)
+    n = m.getNActive(size)
+    assert abs(n - 2.0e6) < 2e4
+    rb = m.getSubmanifoldRuleBook(size, F3)
+    counts = rb.counts.cpu().numpy()
+    assert counts[13] == n and np.array_equal(counts, counts[::-1])      # list k and 26-k have equal length
+    nu = counts.sum() / n
+    assert 13.0 < nu < 14.4                                              # 1 + 26 p
+    # every list ascending in `out`; list 26-k is list k with the columns swapped (as a set: compare checksums)
+    for k in (0, 5, 12):
+        a = rb.rules[k, :counts[k]].to(torch.int64)
+        b = rb.rules[26 - k, :counts[k]].to(torch.int64)
+        assert bool((a[1:, 1] > a[:-1, 1]).all())
+        assert int((a[:, 0] * 1000003 + a[:, 1]).sum()) == int((b[:, 1] * 1000003 + b[:, 0]).sum())
+    # random features: linearity in the input, at full size, m = 128
+    torch.manual_seed(0)
+    x1, x2 = torch.randn(n, 128, device=gpu), torch.randn(n, 128, device=gpu)
+    w = torch.randn(27, 128, 128, device=gpu) * 0.02
+    e = torch.empty(0, device=gpu)
+    o1, o2, o3 = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+    SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x1, o1, w, e, 1)
+    SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x2, o2, w, e, 1)
+    SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x1 + 2 * x2, o3, w, e, 1)
+    err = (o3 - (o1 + 2 * o2)).abs().max().item()
+    assert err <= 1e-4 * o3.abs().max().item()
+    # deterministic: the same launch twice is bitwise identical (no atomics on the output)
+    o4 = torch.empty(0, device=gpu)
+    SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x1, o4, w, e, 1)
+    assert torch.equal(o1, o4)
