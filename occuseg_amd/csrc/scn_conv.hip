@@ -181,13 +181,20 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   constexpr int M = M_ ? M_ : 32 * NW;
   constexpr int COB = NW * COS * 16;
   constexpr int NT = 64 * NW * NWM;  // NWM waves share each plane slice and split the pair groups
-  constexpr int AS = CK + 4;
+  // a_tile: plain rows padded by 4 floats (row stride 68 floats = 4 banks mod 64: the 16 rows a
+  // ds_read_b128 lane group touches cover all 64 banks).  A variant split into 4 planes, one per MFMA
+  // k-quad, makes the reads fully conflict free but was slower overall (QP below).
+  constexpr bool QP = (DBG & 128) != 0;  // opt-in for A/B runs only: measured 10 % SLOWER (the 16-byte staging
+                                         // writes of one row then hit 4 planes on the same banks)
+  constexpr int AQ = QP ? CK / 4 : CK;  // floats per row inside one plane (16 for CK 64)
+  constexpr int AS = AQ + 4;            // padded row stride inside a plane
+  constexpr int APL = QP ? M * AS : 0;  // plane stride
   constexpr int OS = COB + 4;
   constexpr int CH = CK / 4;            // 16-byte chunks per staged row
   constexpr int NSLOT = M * CH / NT;    // row-chunks each thread stages per phase (= CK/8)
   constexpr int NIDX = (M + NT - 1) / NT;
   constexpr int NS16 = CK / 16;
-  __shared__ __attribute__((aligned(16))) float a_tile[M * AS];
+  __shared__ __attribute__((aligned(16))) float a_tile[QP ? 4 * APL : M * AS];
   __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
   __shared__ int srcbuf[3][M];
   __shared__ int olbuf[3][M];
@@ -289,7 +296,9 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     for (int j = 0; j < NSLOT; ++j) {
       const int idx = tid + j * NT;
       if (DBG & 16) asm volatile("" ::"v"(pre[j]));
-      else if (!SLOT_IS_GROUP || j < ng) *(floatx4 *)(a_tile + (idx / CH) * AS + (idx % CH) * 4) = pre[j];
+      else if (!SLOT_IS_GROUP || j < ng)
+        *(floatx4 *)(a_tile + (QP ? ((idx % CH) & 3) * APL + (idx / CH) * AS + ((idx % CH) >> 2) * 4
+                                  : (idx / CH) * AS + (idx % CH) * 4)) = pre[j];
     }
   };
   floatx4 wcur[COS][NS16], wnext[COS][NS16];
@@ -310,10 +319,10 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   // D[i = plane][j = pair], so a lane ends up with 4 consecutive output planes of ONE pair and the
   // accumulate into the LDS output tile is a single 16-byte read-add-write per slice.
   auto load_a = [&](int g, floatx4 (&a)[NS16]) __attribute__((always_inline)) {
-    const float *ap = a_tile + (g * 16 + li) * AS + 4 * lq;
+    const float *ap = QP ? a_tile + lq * APL + (g * 16 + li) * AS : a_tile + (g * 16 + li) * AS + 4 * lq;
 #pragma unroll
     for (int sp = 0; sp < NS16; ++sp)
-      a[sp] = (DBG & 8) ? floatx4{(float)g, 1.f, 2.f, (float)sp} : *(const floatx4 *)(ap + sp * 16);
+      a[sp] = (DBG & 8) ? floatx4{(float)g, 1.f, 2.f, (float)sp} : *(const floatx4 *)(ap + sp * (QP ? 4 : 16));
   };
   auto mma_group = [&](const floatx4 (&a)[NS16], floatx4 (&acc)[COS]) __attribute__((always_inline)) {
     // one accumulator chain per slice: with two waves per SIMD the 40-cycle dependent latency is
@@ -730,6 +739,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 27) SCN_LAUNCH_T2(27);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 32) SCN_LAUNCH_T2(32);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 64) SCN_LAUNCH_T2(64);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 128) SCN_LAUNCH_T2(128);
   else SCN_LAUNCH_T2(0);
 #undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();

@@ -55,8 +55,8 @@ def main():
                 line = "L%d N=%d nu=%.1f SC %d->%d GF=%.1f:" % (lv, n, rb.total_pairs / n, ci, co, flops / 1e9)
                 for v in args.variants.split(","):
                     lib.scn_set_tuning(0, int(v) % 10)
-                    lib.scn_set_tuning(1, (int(v) // 10) % 100)
-                    lib.scn_set_tuning(2, int(v) // 1000)
+                    lib.scn_set_tuning(1, (int(v) // 10) % 1000)
+                    lib.scn_set_tuning(2, int(v) // 10000)
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                     line += "  v%s %.3f ms %.1f TF" % (v, ms, flops / ms / 1e9)
                 for dv in ([0, 100] if args.dw else []):
