@@ -114,7 +114,7 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
  * cuda_Deconvolution_updateOutput (sparseconvnet/SCN/CUDA/Convolution.cpp:36-66,:105-162;
  * sparseconvnet/SCN/CUDA/Deconvolution.cpp:20-49) and the dInput half of the matching *_backward
  * (sparseconvnet/SCN/CUDA/Convolution.cpp:69-102,:165-210).  `out` is fully overwritten.
- *   Ci = planes of `in`, Co = planes of `out`.
+ *   Ci = planes of `in` (n_in rows, n_in*Ci*4 < 2 GiB), Co = planes of `out` (n_out rows).
  *   Wk[ci][co] = w_transposed ? W[ks][co][ci] : W[ks][ci][co],  ks = w_reverse ? K-1-k : k,
  *   where W is the module's weight [K][Ci][Co] (forward) or [K][Co][Ci] (dInput: w_transposed = 1;
  *   submanifold dInput additionally w_reverse = 1 and the SAME lists, because
@@ -125,11 +125,13 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
 size_t scn_conv_wpack_bytes(int K, int Ci, int Co);
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
                      const float *bias, const int32_t *rules, const int32_t *bases, int K,
-                     int64_t stride, int in_col, int out_col, int64_t n_out, int Ci, int Co,
-                     void *wpack, void *stream);
+                     int64_t stride, int in_col, int out_col, int64_t n_in, int64_t n_out, int Ci,
+                     int Co, void *wpack, void *stream);
 
 /* debugging aid for A/B runs: key 0 = gather-mm kernel variant (1 synchronous, 2 pipelined [default]) */
 int scn_set_tuning(int key, int value);
+/* debugging aid: cycle sums per pipeline segment of the diagnostic kernel build (8 x u64, host) */
+int scn_debug_stamps(unsigned long long *out_host);
 
 /* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller,
  * as the reference's callers do: sparseconvnet/submanifoldConvolution.py:114-115).

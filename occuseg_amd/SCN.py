@@ -312,8 +312,8 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None,
-                               ptr(rb.rules), ptr(rb.bases[out_col]), K, rb.stride, in_col, out_col, n_out,
-                               Ci, Co, ptr(wpack), stream()))
+                               ptr(rb.rules), ptr(rb.bases[out_col]), K, rb.stride, in_col, out_col, inp.size(0),
+                               n_out, Ci, Co, ptr(wpack), stream()))
     # algorithmic work of one launch: flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
     R = rb.total_pairs

@@ -31,8 +31,9 @@ SIGNATURES = {
     "scn_tile_bases": (c_int, [_P, _P, c_int, c_int64, c_int, c_int64, _P, _P]),
     "scn_conv_wpack_bytes": (c_size_t, [c_int, c_int, c_int]),
     "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64,
-                                 c_int, c_int, _P, _P]),
+                                 c_int64, c_int, c_int, _P, _P]),
     "scn_set_tuning": (c_int, [c_int, c_int]),
+    "scn_debug_stamps": (c_int, [_P]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, c_int, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
     "scn_bn_temp_bytes": (c_size_t, [c_int]),

@@ -25,8 +25,20 @@
 namespace scn {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KMAX = 27;
+
+// diagnostic build only (DBG bit 8 = 256): per-segment cycle sums of the pipelined kernel, added from
+// lane 0 of every wave at kernel end into a buffer nothing else reads (scn_debug_stamps copies it out).
+__device__ unsigned long long g_stamps[8];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
 
 
 // ---------------------------------------------------------------- forward ---
@@ -176,7 +188,8 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
-                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb, int ksplit) {
+                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb, int ksplit,
+                 unsigned in_bytes, unsigned wp_bytes) {
   // requires Ci % CK == 0 (the launcher picks CK as the largest of 64/32/16 dividing Ci)
   constexpr int M = M_ ? M_ : 32 * NW;
   constexpr int COB = NW * COS * 16;
@@ -193,11 +206,13 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   constexpr int CH = CK / 4;            // 16-byte chunks per staged row
   constexpr int NSLOT = M * CH / NT;    // row-chunks each thread stages per phase (= CK/8)
   constexpr int NIDX = (M + NT - 1) / NT;
+  constexpr int RPS = NT / CH;          // rows between two slots of one thread
   constexpr int NS16 = CK / 16;
   __shared__ __attribute__((aligned(16))) float a_tile[QP ? 4 * APL : M * AS];
   __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
-  __shared__ int srcbuf[3][M];
-  __shared__ int olbuf[3][M];
+  __shared__ unsigned srcbuf[4][M];  // byte offset of each pair's input row; slot-major so a thread's NSLOT
+                                     // offsets are contiguous: index(row) = (row % RPS) * NSLOT + row / RPS
+  __shared__ int olbuf[4][M];
   __shared__ int klist[KMAX];
   __shared__ int kseg[KMAX][2];
   __shared__ int nk_s;
@@ -207,6 +222,12 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   const int w = (tid >> 6) % NW;   // plane slice of this wave
   const int wm = (tid >> 6) / NW;  // which share of the pair groups
   const int li = lane & 15, lq = lane >> 4;
+  // Gathered rows and weight fragments are fetched with buffer loads: the per-lane part of the address
+  // is ONE 32-bit add (row byte offsets are precomputed once per pair into LDS), everything else is scalar.
+  // With flat 64-bit addressing the address arithmetic of the 12 loads a wave issues per phase took
+  // 27-34 % of its cycles (in-kernel stamps, tools/stamps.py).
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
 
   // XCD-aware renumbering (bijective): blocks b, b+8, .. share an XCD; give each a contiguous tile range
   int lin;
@@ -260,37 +281,40 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   };
   auto store_indices = [&](int kk, const int2 (&pr)[NIDX]) __attribute__((always_inline)) {
     const int c = kseg[kk][1];
-    const int b = kk % 3;
+    const int b = kk & 3;
 #pragma unroll
     for (int j = 0; j < NIDX; ++j) {
       const int r = tid + j * NT;
       if (r < M) {
-        srcbuf[b][r] = in_col ? pr[j].y : pr[j].x;
+        srcbuf[b][(r % RPS) * NSLOT + r / RPS] = (unsigned)(in_col ? pr[j].y : pr[j].x) * (unsigned)(Ci * 4);
         olbuf[b][r] = (r < c) ? (int)((in_col ? pr[j].x : pr[j].y) - o0) : M;
       }
     }
   };
-  floatx4 pre[NSLOT];
+  floatx4 preA[NSLOT];  // gathered rows in flight, one phase ahead
   // slot j of a thread covers row (tid + j NT) / CH; with CH * 16 == NT (CK 64, 4 waves) that is pair
   // group j, so "j < groups of this list" is wave-uniform and unused groups cost nothing.
   constexpr bool SLOT_IS_GROUP = (NT == CH * 16) && (DBG & 4);
-  auto issue_rows = [&](int p) __attribute__((always_inline)) {
+  const unsigned lane_chunk = (unsigned)(tid % CH) * 16u;  // this thread's 16-byte chunk inside a staged row
+  auto issue_rows = [&](int p, floatx4 (&pre)[NSLOT]) __attribute__((always_inline)) {
     const int kk = p / nch, c0 = (p - kk * nch) * CK;
-    const int *sb = srcbuf[kk % 3];
-    const int ng = (kseg[kk][1] + 15) >> 4;
-    int src[NSLOT];
+    const unsigned *sb = srcbuf[kk & 3] + (tid / CH) * NSLOT;
+    unsigned off[NSLOT];
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j)
-      if (!SLOT_IS_GROUP || j < ng) src[j] = sb[(tid + j * NT) / CH];
+    for (int j = 0; j < NSLOT; ++j) off[j] = sb[j];
+    const int ng = (kseg[kk][1] + 15) >> 4;
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
-      const int ch = (tid + j * NT) % CH;
-      if (!SLOT_IS_GROUP || j < ng)
-        pre[j] = (DBG & 2) ? floatx4{1.f, 2.f, 3.f, (float)src[j]}
-                            : *(const floatx4 *)(in + (int64_t)src[j] * Ci + c0 + ch * 4);
+      if (SLOT_IS_GROUP && j >= ng) continue;  // wave-uniform: slot j stages pair group j
+      if (DBG & 2) {
+        pre[j] = floatx4{1.f, 2.f, 3.f, (float)off[j]};
+      } else {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off[j] + lane_chunk, c0 * 4, 0);
+        pre[j] = __builtin_bit_cast(floatx4, v);
+      }
     }
   };
-  auto store_rows = [&](int p) __attribute__((always_inline)) {
+  auto store_rows = [&](int p, const floatx4 (&pre)[NSLOT]) __attribute__((always_inline)) {
     const int ng = (kseg[p / nch][1] + 15) >> 4;
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
@@ -305,15 +329,16 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   auto issue_weights = [&](int p, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
     const int kk = p / nch, c0 = (p - kk * nch) * CK;
     const int k = klist[kk];
-    // Wp[k][r/16][c/16][lane][4]
-    const float *base = Wp + (((int64_t)k * (Ci / 16) + c0 / 16) * (Co / 16)) * 256 + lane * 4;
+    // Wp[k][r/16][c/16][lane][4] floats: scalar block offset + lane * 16 bytes
+    const int blk0 = (k * (Ci / 16) + c0 / 16) * (Co / 16) + co0 / 16 + w * COS;
 #pragma unroll
-    for (int q = 0; q < COS; ++q) {
-      const int cs = co0 / 16 + w * COS + q;
+    for (int q = 0; q < COS; ++q)
 #pragma unroll
-      for (int sp = 0; sp < NS16; ++sp)
-        wr[q][sp] = *(const floatx4 *)(base + ((int64_t)sp * (Co / 16) + cs) * 256);
-    }
+      for (int sp = 0; sp < NS16; ++sp) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wp_rsrc, (unsigned)lane * 16u,
+                                                              (blk0 + sp * (Co / 16) + q) * 1024, 0);
+        wr[q][sp] = __builtin_bit_cast(floatx4, v);
+      }
   };
   // One 16-pair group x COS plane slices.  Operands are SWAPPED (A = weight fragment, B = gathered rows):
   // D[i = plane][j = pair], so a lane ends up with 4 consecutive output planes of ONE pair and the
@@ -375,33 +400,51 @@ __global__ void __launch_bounds__(64 * NW * NWM)
 
   if (nphase > 0) {
     int2 pr[NIDX];
+    // Prefetch distances: gathered rows and weight fragments ONE phase ahead (two phases ahead with a
+    // second register set measured 3-4 % slower: the kernel is not waiting on that latency), pair
+    // indices FOUR lists ahead (requested during list kk, parked in registers over list kk+1's first
+    // phase, written to one of 4 LDS buffers at its end: the list that used the buffer is done).
     load_indices(0, pr);
     store_indices(0, pr);
     if (nk > 1) {
       load_indices(1, pr);
       store_indices(1, pr);
     }
+    if (nk > 2) {
+      load_indices(2, pr);
+      store_indices(2, pr);
+    }
+    int2 prq[NIDX];  // indices of a later list, in flight / parked
+    int prq_list = -1;
+    if (nk > 3) {
+      load_indices(3, prq);
+      prq_list = 3;
+    }
     __syncthreads();
-    issue_rows(0);
+    issue_rows(0, preA);
     issue_weights(0, wcur);
 
-    for (int p = 0; p < nphase; ++p) {
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    auto phase = [&](int p, floatx4 (&pre)[NSLOT]) __attribute__((always_inline)) {
       const int kk = p / nch, chn = p - kk * nch;
       const int ngroups = (kseg[kk][1] + 15) >> 4;
-      store_rows(p);  // waits for the row loads issued one phase ago
+      if (DBG & 256) t0 = stamp();
+      store_rows(p, pre);  // waits for the row loads issued one phase ago
+      if (DBG & 256) { t1 = stamp(); seg[0] += t1 - t0; t0 = t1; }
       __syncthreads();
+      if (DBG & 256) { t1 = stamp(); seg[1] += t1 - t0; t0 = t1; }
       const bool more = p + 1 < nphase;
-      const bool fetch_idx = (chn == 0) && (kk + 2 < nk);
+      const bool fetch_idx = (chn == 0) && (kk + 4 < nk);
+      const bool park_idx = (chn == 0) && prq_list == kk + 3;  // indices requested one list ago
       int2 prn[NIDX];
-      if (more) {
-        issue_rows(p + 1);
-        issue_weights(p + 1, wnext);
-      }
-      if (fetch_idx) load_indices(kk + 2, prn);
+      if (more) issue_weights(p + 1, wnext);
+      if (more) issue_rows(p + 1, pre);  // this register set was just written to LDS
+      if (fetch_idx) load_indices(kk + 4, prn);
+      if (DBG & 256) { t1 = stamp(); seg[2] += t1 - t0; t0 = t1; }
 
       // software pipeline over the pair groups: fragments of group g+1 are read while the MFMAs of
       // group g run; the result of group g is added to the output tile behind the MFMAs of group g+1
-      const int *olb = olbuf[kk % 3];
+      const int *olb = olbuf[kk & 3];
       if (!(DBG & 32) && NWM == 1) {
         // NG pair groups per pass: NG independent accumulator chains whose MFMAs alternate, all A
         // fragments requested up front, all NG results added to the output tile behind the MFMAs
@@ -460,15 +503,26 @@ __global__ void __launch_bounds__(64 * NW * NWM)
         scatter(orow_prev, acc_prev);
       }
       }
-      if (fetch_idx) store_indices(kk + 2, prn);
+      if (DBG & 256) { t1 = stamp(); seg[3] += t1 - t0; t0 = t1; }
+      if (park_idx) store_indices(kk + 3, prq);
+      if (fetch_idx) {
+#pragma unroll
+        for (int j = 0; j < NIDX; ++j) prq[j] = prn[j];
+        prq_list = kk + 4;
+      }
       if (more) {
 #pragma unroll
         for (int q = 0; q < COS; ++q)
 #pragma unroll
           for (int sp = 0; sp < NS16; ++sp) wcur[q][sp] = wnext[q][sp];
       }
+      if (DBG & 256) { t1 = stamp(); seg[4] += t1 - t0; t0 = t1; }
       __syncthreads();  // a_tile and this list's ol[] are free again
-    }
+      if (DBG & 256) { t1 = stamp(); seg[5] += t1 - t0; }
+    };
+    for (int p = 0; p < nphase; ++p) phase(p, preA);
+    if ((DBG & 256) && lane == 0)
+      for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], seg[i]);
   }
   const int rows = (int)min((int64_t)M, n_out - o0);
   if (ksplit == 1) {
@@ -718,11 +772,12 @@ static int launch_tile(const float *in, float *out, const float *W, const float 
 template <int NW, int COS, int CK, int NWM = 1, int M_ = 0>
 static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias,
                         const int32_t *rules, const int32_t *bases, int K, int64_t stride,
-                        int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
+                        int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, hipStream_t stream) {
   constexpr int M = M_ ? M_ : 32 * NW;
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / (NW * COS * 16);
+  const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
   // coarse UNet levels: too few tiles to fill 256 CUs and every workgroup walks all K offsets one
   // after the other -> split the offsets over up to 27 workgroups per tile and combine with atomics
   int ksplit = 1;
@@ -733,13 +788,17 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_T2(D)                                                                                   \
   k_conv_tile2<NW, COS, CK, D, NWM, M_><<<grid2, 64 * NW * NWM, 0, stream>>>(                             \
-      in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit)
+      in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit, \
+      in_bytes, wp_bytes)
   if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 9) SCN_LAUNCH_T2(9);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 27) SCN_LAUNCH_T2(27);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 32) SCN_LAUNCH_T2(32);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 64) SCN_LAUNCH_T2(64);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 128) SCN_LAUNCH_T2(128);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 256) SCN_LAUNCH_T2(256);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 4) SCN_LAUNCH_T2(4);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 260) SCN_LAUNCH_T2(260);
   else SCN_LAUNCH_T2(0);
 #undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();
@@ -751,15 +810,23 @@ static int g_conv_wide = 0;  // tuning key 2: 1 = use the 8-wave 128-plane confi
 template <int NW>
 static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias,
                            const int32_t *rules, const int32_t *bases, int K, int64_t stride,
-                           int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
+                           int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, hipStream_t stream) {
   if (NW == 4 && g_conv_wide && Ci % 64 == 0 && Co % 128 == 0)
-    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
+  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
+  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
+  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
 }
 
 extern "C" {
+
+// debugging aid: read (and clear) the per-segment cycle sums of the diagnostic kernel build
+int scn_debug_stamps(unsigned long long *out_host) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  SCN_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(z)));
+  SCN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
+  return 0;
+}
 
 int scn_set_tuning(int key, int value) {
   if (key == 0 && (value == 1 || value == 2)) {
@@ -785,7 +852,7 @@ size_t scn_conv_wpack_bytes(int K, int Ci, int Co) { return (size_t)K * Ci * Co 
 
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
                      const float *bias, const int32_t *rules, const int32_t *bases, int K,
-                     int64_t stride, int in_col, int out_col, int64_t n_out, int Ci, int Co,
+                     int64_t stride, int in_col, int out_col, int64_t n_in, int64_t n_out, int Ci, int Co,
                      void *wpack, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_forward: filter volume must be 1..27");
@@ -794,12 +861,14 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
   if (n_out <= 0) return 0;
   if (Ci % 16 == 0 && Co % 16 == 0) {
     SCN_REQUIRE(wpack != nullptr, "scn_conv_forward: wpack workspace required");
+    // the pipelined kernel addresses `in` and the packed weights with 32-bit buffer offsets
+    const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 31) || (int64_t)K * Ci * Co * 4 >= ((int64_t)1 << 31);
     float *Wp = (float *)wpack;
     const int64_t total = (int64_t)K * Ci * Co;
     int pg = (int)((total + 255) / 256);
     if (pg > 2048) pg = 2048;
     const int s16 = Co / 16;
-    if (g_conv_variant == 1) {
+    if (g_conv_variant == 1 || huge) {
       k_weight_pack<<<pg, 256, 0, stream>>>(W, Wp, K, Ci, Co, w_transposed, w_reverse, 0);
       SCN_CHECK_LAUNCH();
       if (s16 % 4 == 0) return launch_tile<4, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
@@ -815,12 +884,12 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     auto blocks = [&](int nw) { return ((n_out + 32 * nw - 1) / (32 * nw)) * (int64_t)(Co / (16 * nw)); };
     const int64_t want = 512;
     if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off))
-      return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+      return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
     if (s16 % 3 == 0 && s16 % 2 != 0)
-      return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+      return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
     if (s16 % 2 == 0 && (blocks(2) >= want || g_conv_small_off))
-      return launch_tile2_ck<2>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-    return launch_tile2_ck<1>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+      return launch_tile2_ck<2>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
+    return launch_tile2_ck<1>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)n_gran, (unsigned)((Co + 63) / 64));
