@@ -493,10 +493,45 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
                                   float(leakiness), N, C, ptr(temp), stream()))
 
 
+_IDENTITY_RB = {}  # (n, device index) -> _RuleBook with the single list {(i, i)}; tiny LRU
+NIN_USE_GATHER_MM = True
+
+
+def _identity_rulebook(n, device):
+    """1x1 convolution == the gather-mm kernels over the identity rulebook (what list 13 of every
+    submanifold rulebook is).  Lets NetworkInNetwork share the fp32-MFMA kernels; rocBLAS' x^T.dy
+    with a 600k-long reduction ran at ~19 TFLOP/s, the dWeight kernel here runs it at ~100."""
+    key = (n, device.index)
+    rb = _IDENTITY_RB.pop(key, None)
+    if rb is None:
+        idx = torch.arange(n, dtype=torch.int32, device=device)
+        rules = torch.stack([idx, idx], 1).reshape(1, n, 2).contiguous()
+        rb = _RuleBook(1, n, rules, torch.tensor([n], dtype=torch.int32, device=device))
+        n_gran = (n + GRANULE - 1) // GRANULE
+        bases = torch.clamp(torch.arange(n_gran + 1, dtype=torch.int32, device=device) * GRANULE, max=n)
+        rb.bases[0] = rb.bases[1] = bases.reshape(1, n_gran + 1).contiguous()
+        rb.total_pairs = n
+        while len(_IDENTITY_RB) >= 8:
+            _IDENTITY_RB.pop(next(iter(_IDENTITY_RB)))
+    _IDENTITY_RB[key] = rb
+    return rb
+
+
+def _nin_native(x, weight):
+    return (NIN_USE_GATHER_MM and x.is_cuda and x.dtype == torch.float32 and x.size(0) > 0
+            and weight.size(0) % 32 == 0 and weight.size(1) % 32 == 0)
+
+
 def NetworkInNetwork_updateOutput(input_features, output_features, weight, bias):
-    """sparseconvnet/SCN/CUDA/NetworkInNetwork.cpp:9-25: a plain library GEMM (rocBLAS through torch),
-    exactly as the reference calls cuBLAS through ATen."""
+    """sparseconvnet/SCN/CUDA/NetworkInNetwork.cpp:9-25 (addmm).  Planes that are multiples of 32 go through the
+    gather-mm kernel over the identity rulebook, anything else through a library GEMM (rocBLAS via torch),
+    as the reference calls cuBLAS through ATen."""
     n = input_features.size(0)
+    if _nin_native(input_features, weight):
+        rb = _identity_rulebook(n, input_features.device)
+        _conv(input_features.contiguous(), output_features, weight.view(1, weight.size(0), weight.size(1)), bias, rb,
+              0, 1, n)
+        return float(n) * weight.size(0) * weight.size(1)
     output_features.resize_(n, weight.size(1))
     if bias is not None and bias.numel():
         output_features.copy_(bias.expand_as(output_features))
@@ -510,6 +545,11 @@ def NetworkInNetwork_updateOutput(input_features, output_features, weight, bias)
 def NetworkInNetwork_updateGradInput(d_input_features, d_output_features, weight):
     """sparseconvnet/SCN/CUDA/NetworkInNetwork.cpp:27-37"""
     n = d_output_features.size(0)
+    if _nin_native(d_output_features, weight):
+        rb = _identity_rulebook(n, d_output_features.device)
+        _conv(d_output_features.contiguous(), d_input_features, weight.view(1, weight.size(0), weight.size(1)), None,
+              rb, 0, 1, n, w_transposed=True)
+        return
     d_input_features.resize_(n, weight.size(0))
     if n:
         torch.mm(d_output_features, weight.t(), out=d_input_features)
@@ -520,6 +560,16 @@ def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weig
     n = input_features.size(0)
     if n and d_bias is not None and d_bias.numel():
         torch.sum(d_output_features, 0, out=d_bias)
+    if _nin_native(input_features, d_weight):
+        rb = _identity_rulebook(n, input_features.device)
+        Ci, Co = d_weight.shape
+        d_weight.zero_()
+        ev = _prof_begin()
+        check(_lib_().scn_conv_dweight(ptr(input_features.contiguous()), ptr(d_output_features.contiguous()),
+                                       ptr(d_weight), ptr(rb.rules), ptr(rb.counts), 1, rb.stride, 0, 1, Ci, Co,
+                                       stream()))
+        _prof_end(ev, "dw_tile", 2.0 * n * Ci * Co, 4.0 * n * (Ci + Co) + 8.0 * n + 4.0 * Ci * Co, (1, n, Ci, Co, 0))
+        return
     if n:
         torch.mm(input_features.t(), d_output_features, out=d_weight)
 

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""A/B of whole train steps in ONE process (interleaved rounds): python tools/ab_step.py NAME=a,b ...
+where NAME is a module-level switch of occuseg_amd.SCN (e.g. NIN_USE_GATHER_MM=1,0 PREBUILD=1,0)
+or tuneK=v,w for scn_set_tuning(K, v)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+import occuseg_amd
+from occuseg_amd import SCN, _lib, dp, scenes
+
+scn = occuseg_amd.install()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+net = bench.build_net(scn, 64).to(dev)
+bucket = dp.FlatGradBucket(net.parameters())
+opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+coords, feats = scenes.batch([1000, 1001, 1002, 1003], 150000)
+batch_in = [torch.from_numpy(coords).to(dev), torch.from_numpy(feats).to(dev), None, 4]
+
+
+def step():
+    bucket.zero()
+    net(batch_in).sum().backward()
+    opt.step()
+
+
+def apply(name, val):
+    if name.startswith("tune"):
+        _lib.load().scn_set_tuning(int(name[4:]), int(val))
+    else:
+        setattr(SCN, name, type(getattr(SCN, name))(int(val)))
+
+
+name, vals = sys.argv[1].split("=")
+vals = vals.split(",")
+for _ in range(3):
+    step()
+res = {v: [] for v in vals}
+for rnd in range(4):
+    for v in vals:
+        apply(name, v)
+        step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(4):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        res[v].append(e0.elapsed_time(e1) / 4)
+for v in vals:
+    print("%s=%s: %s  min %.2f ms" % (name, v, " ".join("%.2f" % t for t in res[v]), min(res[v])))
