@@ -912,7 +912,13 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_dweight: in_col/out_col must be 0/1 or 1/0");
   if (stride <= 0) return 0;
   if (Ci % 32 == 0 && Co % 32 == 0) {
-    const int chunk = 1024;
+    // pairs per workgroup: enough workgroups per (k, plane block) to fill the chip, few enough that the
+    // float atomics of the partial sums (one CIB x COB tile per workgroup) stay far below the ~1.3 TB/s
+    // atomic rate: ~512 chunks over the longest possible list, at least 1024 pairs
+    int chunk = (int)(((stride + 511) / 512 + 63) / 64 * 64);
+    if (chunk < 1024) chunk = 1024;
+    if (chunk > 8192) chunk = 8192;
+    if (g_conv_dbg == 101) chunk = 1024;  // A/B
     const unsigned gx = (unsigned)((stride + chunk - 1) / chunk);
     if (Ci % 64 == 0 && Co % 64 == 0) {
       dim3 grid(gx, K, (Ci / 64) * (Co / 64));

@@ -59,7 +59,7 @@ def main():
                     lib.scn_set_tuning(2, int(v) // 10000)
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                     line += "  v%s %.3f ms %.1f TF" % (v, ms, flops / ms / 1e9)
-                for dv in ([0, 100] if args.dw else []):
+                for dv in ([101, 0, 101, 0] if args.dw else []):
                     lib.scn_set_tuning(1, dv)
                     dy = torch.randn(n, co, device=dev)
                     dw = torch.zeros_like(w)
