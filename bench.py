@@ -110,6 +110,8 @@ def main():
     net = build_net(scn, args.m).to(dev)
     n_params = sum(p.numel() for p in net.parameters())
     bucket = dp.FlatGradBucket(net.parameters())
+    if world > 1:
+        bucket.enable_overlap()  # bucketed all-reduce launched from backward hooks
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
 
     all_seeds = [1000 + i for i in range(args.scenes_per_gpu * world)]

@@ -23,7 +23,10 @@ def _worker(rank, world, port, ret):
     from occuseg_amd import dp
     torch.manual_seed(0)  # identical replicas
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
-    bucket = dp.FlatGradBucket(net.parameters())
+    bucket = dp.FlatGradBucket(net.parameters(), n_buckets=2)
+    assert len(bucket.buckets) == 2 and bucket.buckets[0][0] == 0 and bucket.buckets[-1][1] == bucket.flat.numel()
+    if ret.get("overlap"):
+        bucket.enable_overlap()
     assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())
     seeds = dp.shard(list(range(100, 100 + 4 * world)), rank, world)
     assert seeds == list(range(100 + 4 * rank, 104 + 4 * rank))
@@ -31,7 +34,16 @@ def _worker(rank, world, port, ret):
     x = torch.randn(7, 6, generator=g)
     bucket.zero()
     net(x).sum().backward()
-    local = bucket.flat.clone()
+    if ret.get("overlap"):
+        assert len(bucket._launched) == 2  # both buckets were sent from backward hooks
+        local = None
+    else:
+        local = bucket.flat.clone()
+    if local is None:  # recompute the un-reduced gradient for the check
+        ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        ref.load_state_dict(net.state_dict())
+        ref(x).sum().backward()
+        local = torch.cat([p.grad.flatten() for p in ref.parameters()])
     bucket.all_reduce_mean()
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
@@ -43,12 +55,17 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_flat_gradient_allreduce_world2():
+import pytest
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_flat_gradient_allreduce_world2(overlap):
     world = 2
     with mp.Manager() as mgr:
         ret = mgr.dict()
+        ret["overlap"] = overlap
         mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-        assert dict(ret) == {0: True, 1: True}
+        assert ret[0] is True and ret[1] is True
 
 
 def test_bucket_is_a_noop_without_process_group():
