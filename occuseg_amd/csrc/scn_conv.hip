@@ -219,8 +219,9 @@ __global__ void __launch_bounds__(64 * NW * NWM)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = (tid >> 6) % NW;   // plane slice of this wave
-  const int wm = (tid >> 6) / NW;  // which share of the pair groups
+  // wave index: uniform, but derived from threadIdx -> divergent to the compiler unless made scalar
+  const int w = __builtin_amdgcn_readfirstlane((tid >> 6) % NW);   // plane slice of this wave
+  const int wm = __builtin_amdgcn_readfirstlane((tid >> 6) / NW);  // which share of the pair groups
   const int li = lane & 15, lq = lane >> 4;
   // Gathered rows and weight fragments are fetched with buffer loads: the per-lane part of the address
   // is ONE 32-bit add (row byte offsets are precomputed once per pair into LDS), everything else is scalar.
@@ -267,20 +268,23 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     if (tid == 0) nk_s = __popcll(m);
   }
   __syncthreads();
-  const int nk = nk_s;
+  // values read back from LDS are wave-uniform but hipcc cannot know: without readfirstlane every buffer
+  // load whose scalar offset derives from them is wrapped in a waterfall loop (readfirstlane + saveexec)
+  auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+  const int nk = uni(nk_s);
   const int nch = Ci / CK;
   const int nphase = nk * nch;
 
   // Branch-free staging: rows past the end of a segment re-read its last pair (same cache lines) and
   // scatter into the sink row M, so no lane ever diverges inside a phase.
   auto load_indices = [&](int kk, int2 (&pr)[NIDX]) __attribute__((always_inline)) {
-    const int2 *rk = rules + (int64_t)klist[kk] * stride + kseg[kk][0];
-    const int c = kseg[kk][1];
+    const int2 *rk = rules + (int64_t)uni(klist[kk]) * stride + uni(kseg[kk][0]);
+    const int c = uni(kseg[kk][1]);
 #pragma unroll
     for (int j = 0; j < NIDX; ++j) pr[j] = rk[min(tid + j * NT, c - 1)];
   };
   auto store_indices = [&](int kk, const int2 (&pr)[NIDX]) __attribute__((always_inline)) {
-    const int c = kseg[kk][1];
+    const int c = uni(kseg[kk][1]);
     const int b = kk & 3;
 #pragma unroll
     for (int j = 0; j < NIDX; ++j) {
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     unsigned off[NSLOT];
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) off[j] = sb[j];
-    const int ng = (kseg[kk][1] + 15) >> 4;
+    const int ng = (uni(kseg[kk][1]) + 15) >> 4;
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       if (SLOT_IS_GROUP && j >= ng) continue;  // wave-uniform: slot j stages pair group j
@@ -315,7 +319,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     }
   };
   auto store_rows = [&](int p, const floatx4 (&pre)[NSLOT]) __attribute__((always_inline)) {
-    const int ng = (kseg[p / nch][1] + 15) >> 4;
+    const int ng = (uni(kseg[p / nch][1]) + 15) >> 4;
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       const int idx = tid + j * NT;
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   floatx4 wcur[COS][NS16], wnext[COS][NS16];
   auto issue_weights = [&](int p, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
     const int kk = p / nch, c0 = (p - kk * nch) * CK;
-    const int k = klist[kk];
+    const int k = uni(klist[kk]);
     // Wp[k][r/16][c/16][lane][4] floats: scalar block offset + lane * 16 bytes
     const int blk0 = (k * (Ci / 16) + c0 / 16) * (Co / 16) + co0 / 16 + w * COS;
 #pragma unroll
@@ -427,7 +431,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     auto phase = [&](int p, floatx4 (&pre)[NSLOT]) __attribute__((always_inline)) {
       const int kk = p / nch, chn = p - kk * nch;
-      const int ngroups = (kseg[kk][1] + 15) >> 4;
+      const int ngroups = (uni(kseg[kk][1]) + 15) >> 4;
       if (DBG & 256) t0 = stamp();
       store_rows(p, pre);  // waits for the row loads issued one phase ago
       if (DBG & 256) { t1 = stamp(); seg[0] += t1 - t0; t0 = t1; }
@@ -799,6 +803,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 256) SCN_LAUNCH_T2(256);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 4) SCN_LAUNCH_T2(4);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 260) SCN_LAUNCH_T2(260);
+  else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 258) SCN_LAUNCH_T2(258);
   else SCN_LAUNCH_T2(0);
 #undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();

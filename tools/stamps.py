@@ -14,7 +14,7 @@ for lv in range(2):
     rb = md.getSubmanifoldRuleBook(size, f3); n = md.getNActive(size); p = 64 * (lv + 1)
     for ci, co in ((p, p), (2 * p, p)):
         x = torch.randn(n, ci, device=dev); w = torch.randn(27, ci, co, device=dev) * .05; out = torch.empty(0, device=dev)
-        lib.scn_set_tuning(1, 256)
+        lib.scn_set_tuning(1, int(os.environ.get('STAMP_DBG', '256')))
         buf = (ctypes.c_ulonglong * 8)()
         SCN._conv(x, out, w, None, rb, 0, 1, n); torch.cuda.synchronize(); lib.scn_debug_stamps(buf)
         SCN._conv(x, out, w, None, rb, 0, 1, n); torch.cuda.synchronize(); lib.scn_debug_stamps(buf)
