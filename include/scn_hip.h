@@ -138,7 +138,7 @@ int scn_debug_stamps(unsigned long long *out_host);
  * Replaces dConvolution_KMxKN_backward_dW_* (sparseconvnet/SCN/CUDA/Convolution.cu:265-442,:695-753). */
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, int K, int64_t stride, int in_col, int out_col,
-                     int Ci, int Co, void *stream);
+                     int64_t n_in, int64_t n_dout, int Ci, int Co, void *stream);
 
 /* column sums: d_bias[c] = sum_rows dOut[r][c] (sparseconvnet/SCN/CUDA/Convolution.cu:52-75) */
 int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream);

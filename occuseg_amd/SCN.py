@@ -336,7 +336,7 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
     if d_weight is not None and d_weight.numel():
         ev = _prof_begin()
         check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts), K,
-                                   rb.stride, in_col, out_col, Ci, Co, stream()))
+                                   rb.stride, in_col, out_col, inp.size(0), d_out.size(0), Ci, Co, stream()))
         R = rb.total_pairs
         _prof_end(ev, "dw_tile", 2.0 * R * Ci * Co, 4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co,
                   (K, inp.size(0), Ci, Co, 0))
@@ -566,7 +566,7 @@ def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weig
         d_weight.zero_()
         ev = _prof_begin()
         check(_lib_().scn_conv_dweight(ptr(input_features.contiguous()), ptr(d_output_features.contiguous()),
-                                       ptr(d_weight), ptr(rb.rules), ptr(rb.counts), 1, rb.stride, 0, 1, Ci, Co,
+                                       ptr(d_weight), ptr(rb.rules), ptr(rb.counts), 1, rb.stride, 0, 1, n, n, Ci, Co,
                                        stream()))
         _prof_end(ev, "dw_tile", 2.0 * n * Ci * Co, 4.0 * n * (Ci + Co) + 8.0 * n + 4.0 * Ci * Co, (1, n, Ci, Co, 0))
         return

@@ -624,7 +624,7 @@ template <int TI, int TJ, int PS = 32>
 __global__ void __launch_bounds__(256)
     k_dw_tile(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
               const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
-              int in_col, int Ci, int Co, int chunk) {
+              int in_col, int Ci, int Co, int chunk, unsigned in_bytes, unsigned do_bytes) {
   constexpr int CIB = 32 * TI, COB = 32 * TJ;
   constexpr int IS = CIB + 16, DS = COB + 16;  // row strides: (stride % 32) == 16 -> ds_read_b32 conflict-free
   __shared__ __attribute__((aligned(16))) float in_t[PS * IS];
@@ -636,8 +636,12 @@ __global__ void __launch_bounds__(256)
   const int p1 = min(count, p0 + chunk);
   const int nci = Ci / CIB;
   const int ci0 = (blockIdx.z % nci) * CIB, co0 = (blockIdx.z / nci) * COB;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = w & 1, wj = w >> 1;
+  // rows are fetched with buffer loads: 32-bit byte offsets (one mul + add per load), scalar plane offset
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t do_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dout, 0, (int)do_bytes, 0x00020000);
   const int li = lane & 15, lq = lane >> 4;
   const int2 *rk = rules + (int64_t)k * stride;
 
@@ -665,13 +669,15 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int idx = tid + j * 256, row = idx / (CIB / 4), ch = idx % (CIB / 4);
-      const floatx4 v = *(const floatx4 *)(in + (int64_t)(in_col ? pi_[j].y : pi_[j].x) * Ci + ci0 + ch * 4);
+      const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+          in_rsrc, (unsigned)(in_col ? pi_[j].y : pi_[j].x) * (unsigned)(Ci * 4) + (unsigned)(ch * 16), ci0 * 4, 0));
       ri[j] = v * ((pb + row < p1) ? 1.f : 0.f);
     }
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
       const int idx = tid + j * 256, row = idx / (COB / 4), ch = idx % (COB / 4);
-      const floatx4 v = *(const floatx4 *)(dout + (int64_t)(in_col ? pd_[j].x : pd_[j].y) * Co + co0 + ch * 4);
+      const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+          do_rsrc, (unsigned)(in_col ? pd_[j].x : pd_[j].y) * (unsigned)(Co * 4) + (unsigned)(ch * 16), co0 * 4, 0));
       rd[j] = v * ((pb + row < p1) ? 1.f : 0.f);
     }
   };
@@ -911,12 +917,14 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
 
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, int K, int64_t stride, int in_col, int out_col,
-                     int Ci, int Co, void *stream_) {
+                     int64_t n_in, int64_t n_dout, int Ci, int Co, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_dweight: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_dweight: in_col/out_col must be 0/1 or 1/0");
   if (stride <= 0) return 0;
-  if (Ci % 32 == 0 && Co % 32 == 0) {
+  const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 31) || n_dout * Co * 4 >= ((int64_t)1 << 31);
+  if (Ci % 32 == 0 && Co % 32 == 0 && !huge) {
+    const unsigned in_bytes = (unsigned)(n_in * Ci * 4), do_bytes = (unsigned)(n_dout * Co * 4);
     // pairs per workgroup: enough workgroups per (k, plane block) to fill the chip, few enough that the
     // float atomics of the partial sums (one CIB x COB tile per workgroup) stay far below the ~1.3 TB/s
     // atomic rate: ~512 chunks over the longest possible list, at least 1024 pairs
@@ -928,12 +936,12 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     if (Ci % 64 == 0 && Co % 64 == 0) {
       dim3 grid(gx, K, (Ci / 64) * (Co / 64));
       if (g_conv_dbg == 100)  // A/B: 32 pairs per step
-        k_dw_tile<2, 2, 32><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+        k_dw_tile<2, 2, 32><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk, in_bytes, do_bytes);
       else
-        k_dw_tile<2, 2, 64><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+        k_dw_tile<2, 2, 64><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk, in_bytes, do_bytes);
     } else {
       dim3 grid(gx, K, (Ci / 32) * (Co / 32));
-      k_dw_tile<1, 1, 64><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+      k_dw_tile<1, 1, 64><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk, in_bytes, do_bytes);
     }
     SCN_CHECK_LAUNCH();
     return 0;
