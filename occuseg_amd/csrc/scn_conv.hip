@@ -441,9 +441,12 @@ __global__ void __launch_bounds__(64 * NW * NWM)
       const bool fetch_idx = (chn == 0) && (kk + 4 < nk);
       const bool park_idx = (chn == 0) && prq_list == kk + 3;  // indices requested one list ago
       int2 prn[NIDX];
+      // program order = vmcnt order: the index load and the weight fragments are consumed at the end of
+      // this phase, the gathered rows only at the start of the next one -> request the rows LAST, so the
+      // waits for the first two leave the 8 row loads in flight
+      if (fetch_idx) load_indices(kk + 4, prn);
       if (more) issue_weights(p + 1, wnext);
       if (more) issue_rows(p + 1, pre);  // this register set was just written to LDS
-      if (fetch_idx) load_indices(kk + 4, prn);
       if (DBG & 256) { t1 = stamp(); seg[2] += t1 - t0; t0 = t1; }
 
       // software pipeline over the pair groups: fragments of group g+1 are read while the MFMAs of
