@@ -26,6 +26,7 @@ namespace scn {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KMAX = 27;
 
@@ -560,6 +561,265 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   }
 }
 
+// ------------------------------------ forward, barrier-free wave-private (v4) ---
+// Same tile (128 output rows x 64 planes kept in LDS), different division of labour: a workgroup is
+// TWO waves, each owning 32 output planes (two 16-plane slices) and walking the offsets on its own.
+// The MFMA B operand (gathered rows) is loaded straight from global memory in fragment shape -- lane
+// (pair li, k-quad lq) fetches 16 bytes of ITS pair's row -- so there is no LDS staging tile, no
+// ds_write, and, because each wave only ever touches its own planes of the output tile, NO barrier
+// after the tile set-up.  Price: every row is fetched by both waves (2x L1 traffic, 64-byte segments).
+// Three-stage register pipeline over passes (a pass = two 16-pair groups): pass p computes, rows and weight
+// fragments of pass p+1 and pair indices of pass p+2 are in flight; the loads are inline asm with hand-counted
+// s_waitcnt (see the comment at load_idx).  Measured (tools/bench_conv.py, tools/stamps.py): 80-89 TF, i.e. +4-8 %
+// over k_conv_tile2 for C_o = 64 and -2 % for 256->128; a wave spends ~1900 cycles of a ~5400-cycle pass ISSUING
+// its 18 loads (850 when they are all out of range), so the kernel is bound by the vector-memory issue path, not
+// by latency.  Opt-in: scn_set_tuning(0, 4).
+template <int DBG = 0>
+__global__ void __launch_bounds__(128)
+    k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
+                 const float *__restrict__ bias, const int2 *__restrict__ rules,
+                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
+                 unsigned in_bytes, unsigned wp_bytes) {
+  constexpr int M = 128, COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
+  __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
+  __shared__ __attribute__((aligned(16))) int kinfo[KMAX + 4][4];  // {offset k, first pair, #pairs, 0}; #pairs 0 past the end
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ru_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)rules, 0, (int)(K * stride * 8), 0x00020000);
+
+  int lin;
+  {
+    const int total = ntiles * ncb;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile = lin / ncb;
+  const int co0 = (lin % ncb) * COB;
+  const int64_t o0 = (int64_t)tile * M;
+  const int g0 = tile * (M / SCN_TILE_GRANULE);
+  const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
+
+  // each wave initialises ITS 32 planes of the output tile
+  for (int i = lane; i < (M + 1) * 8; i += 64) {
+    const int r = i >> 3, c4 = (i & 7) * 4;
+    floatx4 v = {0.f, 0.f, 0.f, 0.f};
+    if (bias) v = *(const floatx4 *)(bias + co0 + 32 * w + c4);
+    *(floatx4 *)(o_tile + r * OS + 32 * w + c4) = v;
+  }
+  if (tid < 64) {
+    int s = 0, e = 0;
+    if (tid < K) {
+      s = bases[(int64_t)tid * (n_gran + 1) + g0];
+      e = bases[(int64_t)tid * (n_gran + 1) + g1];
+    }
+    if (tid < KMAX + 4) *(int4 *)kinfo[tid] = int4{0, 0, 0, 0};
+    const unsigned long long m = __ballot(e > s);
+    if (e > s) {
+      const int pos = __popcll(m & ((1ull << tid) - 1ull));
+      *(int4 *)kinfo[pos] = int4{tid, s, e - s, 0};
+    }
+  }
+  __syncthreads();  // the only barrier
+  auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+  struct Info { int k, s, c; };
+  auto info = [&](int kk) __attribute__((always_inline)) {
+    const int4 v = *(const int4 *)kinfo[kk];
+    return Info{uni(v.x), uni(v.y), uni(v.z)};
+  };
+  const int nch = Ci / CK;
+
+  // Software pipeline over PASSES (a pass = up to two 16-pair groups of one (offset, C_i chunk) phase):
+  //   pass p computes;  rows + weight fragments of pass p+1 are in flight;  pair indices of pass p+2 are in flight.
+  // Every pass issues the SAME vector loads in the same order (2 index, 8 row, 8 weight) so that the
+  // compiler's s_waitcnt counters stay exact across the loop; loads that are not needed are pointed past
+  // the end of their buffer (the range check returns 0 without touching memory).
+  constexpr unsigned OOB = 0x80000000u;
+  struct Desc { int k, chn, g, c, s; };  // pass descriptor; c == 0: no such pass
+  // generator state: position of the pass two ahead
+  Info G0 = info(0), G1 = info(1);
+  int gkk = 0, gchn = 0, gg = 0;
+  auto gen = [&]() __attribute__((always_inline)) {
+    const Desc d = {G0.k, gchn, gg, G0.c, G0.s};
+    const int ng = (G0.c + 15) >> 4;
+    const bool endp = gg + 2 >= ng;            // last pass of the phase
+    const bool endl = endp && gchn + 1 >= nch;  // ... and of the list
+    gg = uni(endp ? 0 : gg + 2);
+    gchn = uni(endl ? 0 : gchn + (endp ? 1 : 0));
+    const Info nx = info(gkk + 2);
+    gkk = uni(gkk + (endl ? 1 : 0));
+    G0.k = uni(endl ? G1.k : G0.k); G0.s = uni(endl ? G1.s : G0.s); G0.c = uni(endl ? G1.c : G0.c);
+    G1.k = uni(endl ? nx.k : G1.k); G1.s = uni(endl ? nx.s : G1.s); G1.c = uni(endl ? nx.c : G1.c);
+    return d;
+  };
+  // The loads are inline asm with hand-placed s_waitcnt: hipcc's own counters cannot follow loads that
+  // stay in flight across the loop back edge and the two unrolled halves (it emitted vmcnt(7..8) at the top
+  // of every pass, i.e. "next pass's rows have arrived", which left nothing in flight during the MFMAs).
+  // Each wait statement names the registers it makes valid ("+v"), so no use can be scheduled above it.
+  auto load_idx = [&](const Desc &d, u32x2 (&pr)[2]) __attribute__((always_inline)) {
+    const int base = uni((int)(((int64_t)d.k * stride + d.s) * 8));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = (d.g + i) * 16 + li;
+      const unsigned off = ((d.g + i) * 16 < d.c) ? (unsigned)min(p, d.c - 1) * 8u : OOB;
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[i]) : "v"(off), "s"(ru_rsrc), "s"(base) : "memory");
+    }
+  };
+  // row byte offsets / output-tile rows of a pass from its pair indices
+  auto addr = [&](const Desc &d, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = (d.g + i) * 16 + li;
+      const bool grp = (d.g + i) * 16 < d.c;
+      const unsigned src = in_col ? pr[i].y : pr[i].x;
+      const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
+      off[i] = (grp && !(DBG & 2)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
+      orow[i] = (p < d.c) ? dst * OS : M * OS;
+    }
+  };
+  auto issue_rows = [&](const Desc &d, const unsigned (&off)[2], floatx4 (&rows)[2][NS16]) __attribute__((always_inline)) {
+    const int so = uni(d.chn * (CK * 4));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rows[i][0]) : "v"(off[i]), "s"(in_rsrc), "s"(so) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rows[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(so) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rows[i][2]) : "v"(off[i]), "s"(in_rsrc), "s"(so) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rows[i][3]) : "v"(off[i]), "s"(in_rsrc), "s"(so) : "memory");
+    }
+  };
+  auto issue_weights = [&](const Desc &d, bool real, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
+    const int blk0 = uni((d.k * (Ci / 16) + d.chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS);
+    const unsigned off = (real && !(DBG & 8)) ? (unsigned)lane * 16u : OOB;
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp) {
+      const int so = uni((blk0 + sp * (Co / 16)) * 1024);
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wr[0][sp]) : "v"(off), "s"(wp_rsrc), "s"(so) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(wr[1][sp]) : "v"(off), "s"(wp_rsrc), "s"(so) : "memory");
+    }
+  };
+#define SCN_WAIT_ROWS(N, R, W)                                                                                      \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                            \
+               : "+v"(R[0][0]), "+v"(R[0][1]), "+v"(R[0][2]), "+v"(R[0][3]), "+v"(R[1][0]), "+v"(R[1][1]),          \
+                 "+v"(R[1][2]), "+v"(R[1][3]), "+v"(W[0][0]), "+v"(W[0][1]), "+v"(W[0][2]), "+v"(W[0][3]),          \
+                 "+v"(W[1][0]), "+v"(W[1][1]), "+v"(W[1][2]), "+v"(W[1][3])::"memory")
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+  auto compute = [&](bool two, const floatx4 (&rows)[2][NS16], const int (&orow)[2],
+                     const floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
+    floatx4 acc[2][COS], old[2][COS];
+    // output-tile values are requested before the MFMAs so that the read-add-write tail does not wait
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < COS; ++q) {
+        acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (!(DBG & 1)) old[i][q] = *(const floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq);
+      }
+    if (DBG & 256) { t1 = stamp(); seg[1] += t1 - t0; t0 = t1; }
+    if (!(DBG & 16))
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].x, rows[0][sp].x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].x, rows[0][sp].x, acc[0][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].y, rows[0][sp].y, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].y, rows[0][sp].y, acc[0][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].z, rows[0][sp].z, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].z, rows[0][sp].z, acc[0][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].w, rows[0][sp].w, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].w, rows[0][sp].w, acc[0][1], 0, 0, 0);
+    }
+    if (two && !(DBG & 16)) {
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp) {
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].x, rows[1][sp].x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].x, rows[1][sp].x, acc[1][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].y, rows[1][sp].y, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].y, rows[1][sp].y, acc[1][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].z, rows[1][sp].z, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].z, rows[1][sp].z, acc[1][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].w, rows[1][sp].w, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].w, rows[1][sp].w, acc[1][1], 0, 0, 0);
+      }
+    }
+    if (DBG & 256) { asm volatile("s_nop 7\n\ts_nop 7" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1])); t1 = stamp(); seg[3] += t1 - t0; t0 = t1; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < COS; ++q) {
+        if (DBG & 1) {
+          asm volatile("" ::"v"(acc[i][q]));
+        } else {  // absent group / padded pair: sink row, += 0 or garbage nobody reads
+          *(floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq) = old[i][q] + acc[i][q];
+        }
+      }
+  };
+
+  if (G0.c > 0) {
+    u32x2 pr[2];
+    unsigned off[2];
+    floatx4 rA[2][NS16], rB[2][NS16], wc[COS][NS16], wn[COS][NS16];
+    int oA[2], oB[2];
+    // prologue: pass 0 fully requested, pass 1 indices requested
+    Desc D0 = gen();
+    load_idx(D0, pr);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
+    addr(D0, pr, off, oA);
+    Desc D1 = gen();
+    issue_weights(D0, true, wc);
+    issue_rows(D0, off, rA);
+    load_idx(D1, pr);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
+    SCN_WAIT_ROWS(0, rA, wc);
+    // steady state, at the top of a pass: rows/weights of THIS pass and indices of the NEXT pass have arrived or
+    // are the only loads in flight (see the waits below); per pass: 2 index + 8 weight + 8 row loads, in this order.
+    auto body = [&](floatx4 (&rc)[2][NS16], int (&oc)[2], floatx4 (&rn)[2][NS16], int (&on)[2]) __attribute__((always_inline)) {
+      if (DBG & 256) { t0 = stamp(); }
+      addr(D1, pr, off, on);
+      const Desc D2 = gen();
+      load_idx(D2, pr);
+      const bool new_phase = D1.c > 0 && (D1.k != D0.k || D1.chn != D0.chn);
+      issue_weights(D1, new_phase, wn);
+      issue_rows(D1, off, rn);
+      if (DBG & 256) { t1 = stamp(); seg[0] += t1 - t0; t0 = t1; }
+      SCN_WAIT_ROWS(18, rc, wc);  // everything older than this pass's 18 loads: the rows being consumed now
+      if (DBG & 256) { t1 = stamp(); seg[2] += t1 - t0; t0 = t1; }
+      compute((D0.g + 1) * 16 < D0.c, rc, oc, wc);
+      // indices of pass p+2 and weights of pass p+1 (issued before the rows, half a pass ago); rows stay in flight
+      asm volatile("s_waitcnt vmcnt(8)"
+                   : "+v"(pr[0]), "+v"(pr[1]), "+v"(wn[0][0]), "+v"(wn[0][1]), "+v"(wn[0][2]), "+v"(wn[0][3]),
+                     "+v"(wn[1][0]), "+v"(wn[1][1]), "+v"(wn[1][2]), "+v"(wn[1][3])::"memory");
+      if (DBG & 256) { t1 = stamp(); seg[4] += t1 - t0; t0 = t1; seg[5] += 1; }
+      if (new_phase) {
+#pragma unroll
+        for (int q = 0; q < COS; ++q)
+#pragma unroll
+          for (int sp = 0; sp < NS16; ++sp) wc[q][sp] = wn[q][sp];
+      }
+      D0 = D1;
+      D1 = D2;
+    };
+    do {  // single exit: a mid-loop break makes hipcc read "undefined" scalars out of a row register
+      body(rA, oA, rB, oB);
+      if (D0.c != 0) body(rB, oB, rA, oA);
+    } while (D0.c != 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last pass's (out-of-range) prefetches
+  }
+  if ((DBG & 256) && lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], seg[i]);
+  // each wave stores its own 32 planes: no barrier needed
+  const int rows = (int)min((int64_t)M, n_out - o0);
+  for (int i = lane; i < rows * 8; i += 64) {
+    const int r = i >> 3, c4 = (i & 7) * 4;
+    *(floatx4 *)(out + (o0 + r) * Co + co0 + 32 * w + c4) = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
+  }
+}
+
 // generic fallback (any Ci, Co; scalar FMA; used by the 3 -> m stem): 32 output rows x 64 planes per
 // block.  The tile's segments of all K lists are first inverted into an LDS table src[k][row] (one
 // barrier), then thread (row, 8 planes) walks the offsets on its own: no per-offset barrier, the
@@ -838,6 +1098,32 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
 
 static int g_conv_wide = 0;  // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
+static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const int32_t *rules,
+                        const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
+                        int Ci, int Co, hipStream_t stream) {
+  constexpr int M = 128;
+  const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+  const int ntiles = (int)((n_out + M - 1) / M);
+  const int ncb = Co / 64;
+  const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
+#define SCN_LAUNCH_TILE4(D)                                                                                         \
+  k_conv_tile4<D><<<(unsigned)(ntiles * ncb), 128, 0, stream>>>(in, out, Wp, bias, (const int2 *)rules, bases, K,   \
+                                                                stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, \
+                                                                in_bytes, wp_bytes)
+  switch (g_conv_dbg) {  // ablation builds for tools/bench_conv.py and tools/stamps.py; 0 in production
+    case 1: SCN_LAUNCH_TILE4(1); break;     // no scatter
+    case 2: SCN_LAUNCH_TILE4(3); break;     // + no gather
+    case 8: SCN_LAUNCH_TILE4(11); break;    // + no weights: loop skeleton + MFMAs
+    case 16: SCN_LAUNCH_TILE4(27); break;   // skeleton without MFMAs
+    case 17: SCN_LAUNCH_TILE4(16); break;   // everything but the MFMAs
+    case 256: SCN_LAUNCH_TILE4(256); break;  // stamps
+    default: SCN_LAUNCH_TILE4(0);
+  }
+#undef SCN_LAUNCH_TILE4
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int NW>
 static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias,
                            const int32_t *rules, const int32_t *bases, int K, int64_t stride,
@@ -860,7 +1146,7 @@ int scn_debug_stamps(unsigned long long *out_host) {
 }
 
 int scn_set_tuning(int key, int value) {
-  if (key == 0 && (value == 1 || value == 2)) {
+  if (key == 0 && (value == 1 || value == 2 || value == 4)) {
     g_conv_variant = value;
     return 0;
   }
@@ -914,6 +1200,9 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     // that all 256 CUs have work (their features and weights are L2 resident, the re-gather is free).
     auto blocks = [&](int nw) { return ((n_out + 32 * nw - 1) / (32 * nw)) * (int64_t)(Co / (16 * nw)); };
     const int64_t want = 512;
+    if (g_conv_variant == 4 && s16 % 4 == 0 && Ci % 64 == 0 && blocks(4) >= want && n_in < (1 << 24) &&
+        (int64_t)K * stride * 8 < (int64_t)0x7fffffff)
+      return launch_tile4(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
     if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off))
       return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
     if (s16 % 3 == 0 && s16 % 2 != 0)

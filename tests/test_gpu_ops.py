@@ -205,3 +205,33 @@ def test_network_in_network(gpu, ci, co):
     SCN.NetworkInNetwork_accGradParameters(_t(x, gpu), _t(dy, gpu), gw, e)
     assert_close(gi.cpu().numpy(), d_in, "NiN dInput")
     assert_close(gw.cpu().numpy(), d_w, "NiN dWeight")
+
+
+@pytest.mark.parametrize("ci,co", [(64, 64), (128, 64), (64, 128)])
+def test_submanifold_forward_variant4(gpu, ci, co):
+    """The opt-in barrier-free forward kernel (scn_set_tuning(0, 4)) against the float64 oracle.
+    It is only chosen when the launch has >= 512 tiles, hence the larger grid."""
+    from occuseg_amd import SCN, _lib
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu, seed=11, n=72000, batch=2, extent=60)
+    assert grid.n > 66000
+    rules, _ = R.submanifold_rules(grid)
+    rng = np.random.default_rng(ci + co)
+    x = rng.normal(size=(grid.n, ci)).astype(np.float32)
+    w = (rng.normal(size=(27, ci, co)) * (2.0 / ci / 27) ** 0.5).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    want, macs = A.conv_forward(x, w, rules, grid.n, b, dtype=np.float64)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for variant in (4, 2):
+            lib.scn_set_tuning(0, variant)
+            out = torch.empty(0, device=gpu)
+            got = SCN.SubmanifoldConvolution_updateOutput(size, F3, m, _t(x, gpu), out, _t(w, gpu), _t(b, gpu), 1)
+            assert got == macs
+            outs[variant] = out.cpu().numpy()
+    finally:
+        lib.scn_set_tuning(0, 2)
+    assert_close(outs[4], want, "variant 4 forward %d->%d" % (ci, co))
+    # same per-(offset, chunk) summation order as the default kernel: bit-identical
+    assert np.array_equal(outs[4], outs[2])

@@ -10,6 +10,9 @@ md = SCN.Metadata_3(); size = torch.tensor([4096] * 3)
 md.inputLayer(size, torch.from_numpy(coords), 0, 4, dev)
 f3, f2 = torch.tensor([3, 3, 3]), torch.tensor([2, 2, 2])
 names = ["store_rows(+vmcnt)", "barrier1", "issue loads", "group passes", "tail", "barrier2"]
+if os.environ.get("STAMP_VARIANT") == "4":
+    names = ["bookkeeping+issue", "tile reads", "wait rows", "MFMAs", "scatter tail", "#passes"]
+    lib.scn_set_tuning(0, 4)
 for lv in range(2):
     rb = md.getSubmanifoldRuleBook(size, f3); n = md.getNActive(size); p = 64 * (lv + 1)
     for ci, co in ((p, p), (2 * p, p)):
@@ -19,6 +22,10 @@ for lv in range(2):
         SCN._conv(x, out, w, None, rb, 0, 1, n); torch.cuda.synchronize(); lib.scn_debug_stamps(buf)
         SCN._conv(x, out, w, None, rb, 0, 1, n); torch.cuda.synchronize(); lib.scn_debug_stamps(buf)
         lib.scn_set_tuning(1, 0)
+        if os.environ.get("STAMP_VARIANT") == "4":
+            np_ = buf[5]
+            print("L%d %d->%d: passes/wave-total %d; cycles per pass: " % (lv, ci, co, np_) + "  ".join("%s %.0f" % (nm, buf[i] / np_) for i, nm in enumerate(names[:5])))
+            continue
         tot = sum(buf[:6])
         print("L%d %d->%d: " % (lv, ci, co) + "  ".join("%s %.1f%%" % (nm, 100.0 * buf[i] / tot) for i, nm in enumerate(names)))
     md.getRuleBook(size, size // 2, f2, f2); size = size // 2
