@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=4)
     ap.add_argument("--sites", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
+                    help="build each step's rulebooks inside the step instead of one step ahead on a side stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,20 +123,27 @@ def main():
     feats_d = torch.from_numpy(feats).to(dev)
     batch_in = [coords_d, feats_d, None, len(seeds)]
 
+    with torch.no_grad():
+        md = SCN.Metadata_3()
+        md.inputLayer(torch.tensor([4096] * 3), coords_d, 0, 4, dev)
+        n_sites = md.nActive[md.inputSpatialSize]
+        del md
+    input_layer = next(mod for mod in net.modules() if isinstance(mod, scn.InputLayer))
+
     def step():
         bucket.zero()
         out = net(batch_in)
         out.sum().backward()
         bucket.all_reduce_mean()
         opt.step()
+        if args.prefetch:
+            # software pipelining across steps: the NEXT batch's voxel hash + rulebooks are built on a side stream
+            # while this step's kernels drain (every step still builds its own)
+            input_layer.prefetch(batch_in, wait_for_current_stream=False)
         return out
 
     for _ in range(args.warmup):
         step()
-    with torch.no_grad():
-        md = SCN.Metadata_3()
-        md.inputLayer(torch.tensor([4096] * 3), coords_d, 0, 4, dev)
-        n_sites = md.nActive[md.inputSpatialSize]
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,7 +215,8 @@ def main():
                                    "batch=%d synthetic scenes x ~%dk active voxels per GPU, rulebooks rebuilt "
                                    "every step" % (args.m, args.scenes_per_gpu, args.sites // 1000),
                        "active_voxels_per_step": total_sites, "parameters": n_params,
-                       "parallelism": "dp%d" % world, "allreduce_bytes": 4 * n_params if world > 1 else 0},
+                       "parallelism": "dp%d" % world, "allreduce_bytes": 4 * n_params if world > 1 else 0,
+                       "rulebook_prefetch": bool(args.prefetch)},
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -65,6 +65,11 @@ def _need_cuda(t, what):
 _PLANS = {}
 PREBUILD = True
 
+# Grids + rulebooks built AHEAD of the InputLayer call that will use them (prefetch_input below), keyed by the
+# identity of the coordinate tensor.  Pipelining across steps only: what is built is what inputLayer would build.
+_PREFETCHED = {}
+_SIDE_STREAMS = {}
+
 
 class _Grid(object):
     """Active sites of one scale (device resident)."""
@@ -166,9 +171,13 @@ class Metadata_3(object):
                                       "(sparseconvnet/SCN/Metadata/IOLayersRules.h:141)")
         assert coords.dim() == 2 and coords.size(1) in (3, 4)
         assert coords.dtype == torch.int64
+        key = _size_key(spatialSize)
+        pre = _PREFETCHED.pop(id(coords), None)
+        if pre is not None and pre[0] is coords and pre[1] == (key, int(mode), _norm_device(device)):
+            self._adopt(pre[2], pre[3])
+            return
         self.clear()
         self.device = device
-        key = _size_key(spatialSize)
         self.inputSpatialSize = key
         c = coords.to(device, non_blocking=True).contiguous()
         P = c.size(0)
@@ -193,6 +202,30 @@ class Metadata_3(object):
                 totals = torch.stack([rb.counts.sum() for rb in pending]).cpu().tolist()
                 for rb, t in zip(pending, totals):
                     rb.total_pairs = int(t)
+
+    def _tensors(self):
+        for g in self.grids.values():
+            for t in (g.coords, g.keys, g.hash_keys, g.hash_vals):
+                if t is not None:
+                    yield t
+        for rb in list(self.submanifoldRuleBooks.values()) + list(self.ruleBooks.values()):
+            for t in [rb.rules, rb.counts, rb.nbr] + list(rb.bases.values()):
+                if t is not None:
+                    yield t
+        for t in (self.input_order, self.input_site_of_row, self.input_site_start):
+            if t is not None:
+                yield t
+
+    def _adopt(self, other, done):
+        """take over a Metadata_3 that prefetch_input built on the side stream"""
+        scale = self.normal_guide_scale
+        self.__dict__.update(other.__dict__)
+        self.normal_guide_scale = scale
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        for t in self._tensors():  # allocated on the side stream, consumed on this one
+            t.record_stream(cur)
+        _PLANS[self.inputSpatialSize] = self._plan
 
     def _record(self, req):
         if req not in self._plan:
@@ -296,6 +329,37 @@ class Metadata_3(object):
                                         ptr(table), stream()))
         header = np.array([self.input_mode, ma.value, self.input_P, N], np.int32)
         return header, table.cpu().numpy()
+
+
+def _norm_device(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=True):
+    """Build the grids and (replaying the previous forward pass's requests) the rulebooks that the next
+    ``InputLayer`` call on exactly this ``coords`` tensor will need, on a high-priority side stream, so that
+    the build and its data-dependent host synchronisations overlap the current step's queued kernels.  The
+    InputLayer call then adopts the result instead of building (it waits on an event, not on the host).
+    ``coords`` must not be modified in between.  ``wait_for_current_stream=False`` may be passed when a CUDA
+    ``coords`` tensor was produced long ago (otherwise the side stream first waits for the current one, which
+    serialises the build behind the queued step)."""
+    device = _norm_device(device)
+    assert coords.dtype == torch.int64 and coords.dim() == 2
+    side = _SIDE_STREAMS.get(device)
+    if side is None:
+        side = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device, priority=-1)
+    if coords.is_cuda and wait_for_current_stream:
+        side.wait_stream(torch.cuda.current_stream(device))
+    m = Metadata_3()
+    with torch.cuda.stream(side):
+        m.inputLayer(spatialSize, coords, 0, mode, device)
+        done = torch.cuda.Event()
+        done.record(side)
+    _PREFETCHED.clear()  # one batch ahead is all a training loop needs; never keep stale grids alive
+    _PREFETCHED[id(coords)] = (coords, (_size_key(spatialSize), int(mode), device), m, done)
 
 
 # ----------------------------------------------------------------- helpers ---

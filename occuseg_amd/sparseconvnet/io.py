@@ -66,6 +66,15 @@ class InputLayer(Module):
         return output
 
 
+    def prefetch(self, input, device=None, wait_for_current_stream=True):
+        """Not in the reference: start building the grids/rulebooks of a FUTURE ``forward(input)`` on a side
+        stream (occuseg_amd.SCN.prefetch_input).  ``input[0]`` must be the same int64 tensor object that will be
+        passed to ``forward`` and must not change in between."""
+        coords, features = input[0], input[1]
+        SCN.prefetch_input(self.spatial_size, coords, self.mode, device if device is not None else features.device,
+                           wait_for_current_stream)
+
+
 class OutputLayer(Module):
     def __init__(self, dimension):
         Module.__init__(self)

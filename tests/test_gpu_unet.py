@@ -52,3 +52,52 @@ def test_unet_forward_backward(gpu, m, levels, leak):
             mean, var = stats["bn"][id(mod)]
             assert_close(mod.running_mean.cpu().numpy(), (0.1 * mean).numpy(), "running_mean")
             assert_close(mod.running_var.cpu().numpy(), (0.9 + 0.1 * var).numpy(), "running_var")
+
+
+def test_rulebook_prefetch_is_equivalent(gpu):
+    """InputLayer.prefetch (grids + rulebooks built one step ahead on a side stream) must give the same
+    rulebooks, outputs and gradients as building inside the step; a different coords object must not adopt."""
+    import occuseg_amd
+    from occuseg_amd import SCN, scenes
+    scn = occuseg_amd.install()
+    torch.manual_seed(3)
+    net = _net(scn, 16, 3, 0.0).to(gpu)
+    inp = next(mod for mod in net.modules() if isinstance(mod, scn.InputLayer))
+    coords_a, feats_a = scenes.batch([1000, 1001], target_sites=6000)
+    coords_b, feats_b = scenes.batch([1002, 1003], target_sites=7000)
+    batches = [[torch.from_numpy(c).to(gpu), torch.from_numpy(f).to(gpu), None, 2]
+               for c, f in ((coords_a, feats_a), (coords_b, feats_b))]
+
+    def run(batch):
+        for p in net.parameters():
+            p.grad = None
+        out = net(batch)
+        out.sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()]
+
+    run(batches[0])  # records the rulebook requests (the plan) of this architecture
+    plain = [run(b) for b in batches]
+    piped = []
+    inp.prefetch(batches[0])
+    for i, b in enumerate(batches):
+        assert id(b[0]) in SCN._PREFETCHED
+        res = run(b)
+        assert not SCN._PREFETCHED  # adopted
+        if i + 1 < len(batches):
+            inp.prefetch(batches[i + 1], wait_for_current_stream=False)
+        piped.append(res)
+    torch.cuda.synchronize()
+    for (o0, g0), (o1, g1) in zip(plain, piped):
+        # small levels split the offsets over workgroups and dWeight accumulates with float atomics: tolerance
+        assert_close(o1.cpu().numpy(), o0.cpu().numpy(), "prefetch output", rel=1e-5)
+        for a, b in zip(g0, g1):
+            assert_close(b.cpu().numpy(), a.cpu().numpy(), "prefetch grads", rel=1e-5)
+    # a prefetch for another tensor object is ignored, and dropped by the next prefetch
+    inp.prefetch(batches[0])
+    clone = [batches[0][0].clone()] + batches[0][1:]
+    o, _ = run(clone)
+    assert_close(o.cpu().numpy(), plain[0][0].cpu().numpy(), "no adoption", rel=1e-5)
+    assert id(batches[0][0]) in SCN._PREFETCHED
+    inp.prefetch(batches[1])
+    assert list(SCN._PREFETCHED) == [id(batches[1][0])]
+    SCN._PREFETCHED.clear()
