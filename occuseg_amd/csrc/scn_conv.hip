@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(128)
     const bool endl = endp && gchn + 1 >= nch;  // ... and of the list
     gg = uni(endp ? 0 : gg + 2);
     gchn = uni(endl ? 0 : gchn + (endp ? 1 : 0));
-    const Info nx = info(gkk + 2);
+    const Info nx = info(min(gkk + 2, KMAX + 3));
     gkk = uni(gkk + (endl ? 1 : 0));
     G0.k = uni(endl ? G1.k : G0.k); G0.s = uni(endl ? G1.s : G0.s); G0.c = uni(endl ? G1.c : G0.c);
     G1.k = uni(endl ? nx.k : G1.k); G1.s = uni(endl ? nx.s : G1.s); G1.c = uni(endl ? nx.c : G1.c);
@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(128)
     for (int i = 0; i < 2; ++i) {
       const int p = (d.g + i) * 16 + li;
       const unsigned off = ((d.g + i) * 16 < d.c) ? (unsigned)min(p, d.c - 1) * 8u : OOB;
-      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[i]) : "v"(off), "s"(ru_rsrc), "s"(base) : "memory");
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(pr[i]) : "v"(off), "s"(ru_rsrc), "s"(base) : "memory");
     }
   };
   // row byte offsets / output-tile rows of a pass from its pair indices
@@ -710,105 +710,193 @@ __global__ void __launch_bounds__(128)
                  "+v"(R[1][2]), "+v"(R[1][3]), "+v"(W[0][0]), "+v"(W[0][1]), "+v"(W[0][2]), "+v"(W[0][3]),          \
                  "+v"(W[1][0]), "+v"(W[1][1]), "+v"(W[1][2]), "+v"(W[1][3])::"memory")
   unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
-  auto compute = [&](bool two, const floatx4 (&rows)[2][NS16], const int (&orow)[2],
-                     const floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
-    floatx4 acc[2][COS], old[2][COS];
-    // output-tile values are requested before the MFMAs so that the read-add-write tail does not wait
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < COS; ++q) {
-        acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (!(DBG & 1)) old[i][q] = *(const floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq);
-      }
-    if (DBG & 256) { t1 = stamp(); seg[1] += t1 - t0; t0 = t1; }
-    if (!(DBG & 16))
-#pragma unroll
-    for (int sp = 0; sp < NS16; ++sp) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].x, rows[0][sp].x, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].x, rows[0][sp].x, acc[0][1], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].y, rows[0][sp].y, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].y, rows[0][sp].y, acc[0][1], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].z, rows[0][sp].z, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].z, rows[0][sp].z, acc[0][1], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].w, rows[0][sp].w, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].w, rows[0][sp].w, acc[0][1], 0, 0, 0);
-    }
-    if (two && !(DBG & 16)) {
-#pragma unroll
-      for (int sp = 0; sp < NS16; ++sp) {
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].x, rows[1][sp].x, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].x, rows[1][sp].x, acc[1][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].y, rows[1][sp].y, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].y, rows[1][sp].y, acc[1][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].z, rows[1][sp].z, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].z, rows[1][sp].z, acc[1][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0][sp].w, rows[1][sp].w, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1][sp].w, rows[1][sp].w, acc[1][1], 0, 0, 0);
-      }
-    }
-    if (DBG & 256) { asm volatile("s_nop 7\n\ts_nop 7" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1])); t1 = stamp(); seg[3] += t1 - t0; t0 = t1; }
+  auto scatter = [&](const floatx4 (&a)[2][COS], const floatx4 (&old)[2][COS], const int (&orow)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < COS; ++q) {
         if (DBG & 1) {
-          asm volatile("" ::"v"(acc[i][q]));
+          asm volatile("" ::"v"(a[i][q]));
         } else {  // absent group / padded pair: sink row, += 0 or garbage nobody reads
-          *(floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq) = old[i][q] + acc[i][q];
+          *(floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq) = old[i][q] + a[i][q];
         }
       }
   };
+  auto tile_rows = [&](floatx4 (&old)[2][COS], const int (&orow)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < COS; ++q)
+        if (!(DBG & 1)) old[i][q] = *(const floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq);
+  };
 
   if (G0.c > 0) {
-    u32x2 pr[2];
-    unsigned off[2];
-    floatx4 rA[2][NS16], rB[2][NS16], wc[COS][NS16], wn[COS][NS16];
-    int oA[2], oB[2];
-    // prologue: pass 0 fully requested, pass 1 indices requested
+    // ---- pipeline state.  At the top of pass p: rows(p), weights(p) and the pair indices of pass p+1 are in
+    // registers, nothing is in flight; D0..D2 describe passes p..p+2; the weight-load scalars of pass p+1 (w_*) and the
+    // index-load offsets of pass p+2 (ioff, ibase) are known.  Every load is issued AND waited for inside one pass, so
+    // no register with a load in flight lives across the loop back edge, where hipcc is free to insert copies
+    // (it did: v_mov of the index registers in front of the wait; tools/check_asm_loads.py now guards the build).
+    u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
+    unsigned off[2], ioff[2];
+    int ibase;
+    floatx4 rA[2][NS16], rB[2][NS16], wc[COS][NS16], wn[COS][NS16], prev[2][COS];
+    int o0r[2], o1r[2], op[2] = {M * OS, M * OS};  // output-tile rows of pass p, p+1, p-1
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < COS; ++q) prev[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto weight_scalars = [&](const Desc &d, const Desc &before, int (&so)[NS16], unsigned &voff, bool &np) __attribute__((always_inline)) {
+      np = d.c > 0 && (d.k != before.k || d.chn != before.chn);
+      const int blk = uni((d.k * (Ci / 16) + d.chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS);
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp) so[sp] = uni((blk + sp * (Co / 16)) * 1024);
+      voff = (np && !(DBG & 8)) ? (unsigned)lane * 16u : OOB;
+    };
+    auto index_scalars = [&](const Desc &d, unsigned (&vo)[2], int &base) __attribute__((always_inline)) {
+      base = uni((int)(((int64_t)d.k * stride + d.s) * 8));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        vo[i] = ((d.g + i) * 16 < d.c) ? (unsigned)min((d.g + i) * 16 + li, d.c - 1) * 8u : OOB;
+    };
     Desc D0 = gen();
     load_idx(D0, pr);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
-    addr(D0, pr, off, oA);
-    Desc D1 = gen();
+    addr(D0, pr, off, o0r);
     issue_weights(D0, true, wc);
     issue_rows(D0, off, rA);
+    Desc D1 = gen();
     load_idx(D1, pr);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
     SCN_WAIT_ROWS(0, rA, wc);
-    // steady state, at the top of a pass: rows/weights of THIS pass and indices of the NEXT pass have arrived or
-    // are the only loads in flight (see the waits below); per pass: 2 index + 8 weight + 8 row loads, in this order.
-    auto body = [&](floatx4 (&rc)[2][NS16], int (&oc)[2], floatx4 (&rn)[2][NS16], int (&on)[2]) __attribute__((always_inline)) {
+    int w_so[NS16];
+    unsigned w_off;
+    bool w_new;
+    weight_scalars(D1, D0, w_so, w_off, w_new);
+    Desc D2 = gen();
+    index_scalars(D2, ioff, ibase);
+
+    // One pass: the MFMAs of pass p and, between groups of four of them, everything else:
+    //   slot 0     row offsets / output rows of pass p+1 from its indices; index loads of pass p+2
+    //   slots 1-2  row loads of pass p+1            slot 5  read-add-write of pass p-1 into the output tile
+    //   slots 3-4  weight loads of pass p+1         slot 6  descriptor of pass p+3, load scalars of pass p+2
+    // A wave that stalls on the vector-memory issue path or on scalar bookkeeping then still has MFMAs queued.
+    auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rn)[2][NS16]) __attribute__((always_inline)) {
       if (DBG & 256) { t0 = stamp(); }
-      addr(D1, pr, off, on);
-      const Desc D2 = gen();
-      load_idx(D2, pr);
-      const bool new_phase = D1.c > 0 && (D1.k != D0.k || D1.chn != D0.chn);
-      issue_weights(D1, new_phase, wn);
-      issue_rows(D1, off, rn);
+      const bool two = (D0.g + 1) * 16 < D0.c;
+      floatx4 acc[2][COS], old[2][COS];
+      Desc D3 = D2;
+      int n_so[NS16], n_ibase = 0, rso = 0;
+      unsigned n_off = OOB, n_ioff[2] = {OOB, OOB};
+      bool n_new = false;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < COS; ++q) acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      auto slot = [&](int j) __attribute__((always_inline)) {
+        if (j == 0) {
+          addr(D1, pr, off, o1r);
+          rso = uni(D1.chn * (CK * 4));
+          __builtin_amdgcn_sched_barrier(0);  // pr is consumed above, reloaded below
+          asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[0]) : "v"(ioff[0]), "s"(ru_rsrc), "s"(ibase) : "memory");
+          asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[1]) : "v"(ioff[1]), "s"(ru_rsrc), "s"(ibase) : "memory");
+        } else if (j == 1 || j == 2) {
+          const int i = j - 1;
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rn[i][0]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rn[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rn[i][2]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rn[i][3]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+          if (j == 2) tile_rows(old, op);
+        } else if (j == 3 || j == 4) {
+#pragma unroll
+          for (int sp = 2 * (j - 3); sp < 2 * (j - 3) + 2; ++sp) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wn[0][sp]) : "v"(w_off), "s"(wp_rsrc), "s"(w_so[sp]) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(wn[1][sp]) : "v"(w_off), "s"(wp_rsrc), "s"(w_so[sp]) : "memory");
+          }
+        } else if (j == 5) {
+          scatter(prev, old, op);
+        } else if (j == 6) {
+          D3 = gen();
+          weight_scalars(D2, D1, n_so, n_off, n_new);
+          index_scalars(D3, n_ioff, n_ibase);
+        }
+      };
       if (DBG & 256) { t1 = stamp(); seg[0] += t1 - t0; t0 = t1; }
-      SCN_WAIT_ROWS(18, rc, wc);  // everything older than this pass's 18 loads: the rows being consumed now
-      if (DBG & 256) { t1 = stamp(); seg[2] += t1 - t0; t0 = t1; }
-      compute((D0.g + 1) * 16 < D0.c, rc, oc, wc);
-      // indices of pass p+2 and weights of pass p+1 (issued before the rows, half a pass ago); rows stay in flight
-      asm volatile("s_waitcnt vmcnt(8)"
-                   : "+v"(pr[0]), "+v"(pr[1]), "+v"(wn[0][0]), "+v"(wn[0][1]), "+v"(wn[0][2]), "+v"(wn[0][3]),
-                     "+v"(wn[1][0]), "+v"(wn[1][1]), "+v"(wn[1][2]), "+v"(wn[1][3])::"memory");
+      if (!(DBG & 16)) {
+#pragma unroll
+        for (int sp = 0; sp < NS16; ++sp) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].x, rc[0][sp].x, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].x, rc[0][sp].x, acc[0][1], 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].y, rc[0][sp].y, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].y, rc[0][sp].y, acc[0][1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          slot(2 * sp);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].z, rc[0][sp].z, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].z, rc[0][sp].z, acc[0][1], 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].w, rc[0][sp].w, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].w, rc[0][sp].w, acc[0][1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          slot(2 * sp + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slot(j);
+      }
+      if (two && !(DBG & 16)) {
+#pragma unroll
+        for (int sp = 0; sp < NS16; ++sp) {
+          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].x, rc[1][sp].x, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].x, rc[1][sp].x, acc[1][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].y, rc[1][sp].y, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].y, rc[1][sp].y, acc[1][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].z, rc[1][sp].z, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].z, rc[1][sp].z, acc[1][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].w, rc[1][sp].w, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].w, rc[1][sp].w, acc[1][1], 0, 0, 0);
+        }
+      }
+      if (DBG & 256) { asm volatile("s_nop 7\n\ts_nop 7" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1])); t1 = stamp(); seg[3] += t1 - t0; t0 = t1; }
+      // everything this pass requested: rows and weights of pass p+1, indices of pass p+2
+      // (the destinations are named as INPUTS: that keeps them allocated until here even where nothing reads them,
+      //  and unlike a "+v" tie it gives hipcc no reason to copy them in front of the wait)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(rn[0][0]), "v"(rn[0][1]), "v"(rn[0][2]), "v"(rn[0][3]), "v"(rn[1][0]),
+                   "v"(rn[1][1]), "v"(rn[1][2]), "v"(rn[1][3]), "v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]),
+                   "v"(wn[0][3]), "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]), "v"(pr[0]), "v"(pr[1])
+                   : "memory");
+      __builtin_amdgcn_sched_barrier(0);
       if (DBG & 256) { t1 = stamp(); seg[4] += t1 - t0; t0 = t1; seg[5] += 1; }
-      if (new_phase) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int q = 0; q < COS; ++q) prev[i][q] = acc[i][q];
+        op[i] = o0r[i]; o0r[i] = o1r[i];
+        ioff[i] = n_ioff[i];
+      }
+      ibase = n_ibase;
+      if (w_new) {
 #pragma unroll
         for (int q = 0; q < COS; ++q)
 #pragma unroll
           for (int sp = 0; sp < NS16; ++sp) wc[q][sp] = wn[q][sp];
       }
-      D0 = D1;
-      D1 = D2;
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp) w_so[sp] = n_so[sp];
+      w_off = n_off;
+      w_new = n_new;
+      D0 = D1; D1 = D2; D2 = D3;
     };
-    do {  // single exit: a mid-loop break makes hipcc read "undefined" scalars out of a row register
-      body(rA, oA, rB, oB);
-      if (D0.c != 0) body(rB, oB, rA, oA);
+    do {  // single exit: a mid-loop break makes hipcc read "undefined" scalars out of a row register.  A pass past the
+          // end is an empty one (all loads out of range, rows zero, output rows = sink) that only flushes `prev`.
+      body(rA, rB);
+      body(rB, rA);
     } while (D0.c != 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last pass's (out-of-range) prefetches
+    {  // result of the last pass
+      floatx4 old[2][COS];
+      tile_rows(old, op);
+      scatter(prev, old, op);
+    }
   }
   if ((DBG & 256) && lane == 0)
     for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], seg[i]);

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Static check of the hand-scheduled loads of k_conv_tile4 (run by occuseg_amd/build.py).
+
+The kernel issues its buffer loads from inline asm and waits for them with inline-asm s_waitcnt vmcnt(N),
+so hipcc does not know that a destination register is not valid yet.  This script compiles scn_conv.hip to
+assembly, walks every k_conv_tile4 instantiation in layout order (the pass loop twice, to cover the back edge)
+with a FIFO model of the outstanding asm loads, and fails if ANY instruction outside the asm blocks reads or
+writes a register that an in-flight load is still going to write.
+usage: python tools/check_asm_loads.py [file.s]"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "occuseg_amd", "csrc", "scn_conv.hip")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+
+
+def regs(tok):
+    """VGPR numbers named by an operand like v12 or v[12:15]"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def operands(line):
+    line = line.split(";")[0]
+    parts = line.strip().split(None, 1)
+    if len(parts) < 2:
+        return parts[0] if parts else "", []
+    return parts[0], [t.strip() for t in re.split(r",\s*", parts[1])]
+
+
+def check_kernel(name, lines):
+    # locate the pass loop: the loop that contains asm buffer loads
+    in_asm = False
+    fifo = []      # list of (dest register set, line number)
+    errors = []
+    seq = []
+    for no, ln in enumerate(lines):
+        if "#ASMSTART" in ln:
+            in_asm = True
+            continue
+        if "#ASMEND" in ln:
+            in_asm = False
+            continue
+        s = ln.strip()
+        if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
+            continue
+        seq.append((no, in_asm, s))
+    # find loop extent: first and last asm load after the first label that is a loop header with asm loads
+    headers = [i for i, (no, a, s) in enumerate(seq)]
+    def run(seq_part):
+        for no, is_asm, s in seq_part:
+            op, ops = operands(s)
+            if is_asm:
+                if op.startswith("buffer_load"):
+                    fifo.append((regs(ops[0]), no))
+                elif op == "s_waitcnt":
+                    m = re.search(r"vmcnt\((\d+)\)", s)
+                    if m:
+                        keep = int(m.group(1))
+                        while len(fifo) > keep:
+                            fifo.pop(0)
+                continue
+            touched = set()
+            for t in ops:
+                touched |= regs(t.split(" ")[0])
+            for dst, lno in fifo:
+                if touched & dst:
+                    errors.append("%s: line %d `%s` touches v%s, target of the asm load at line %d still in flight"
+                                  % (name, no + 1, s, sorted(touched & dst), lno + 1))
+    # loop body = from the loop header label line to the backward branch; approximate by label positions
+    label_line = None
+    for no, ln in enumerate(lines):
+        if "Loop Header" in ln and label_line is None:
+            # choose the loop header after which asm loads appear before the next header
+            label_line = no
+    hdrs = [no for no, ln in enumerate(lines) if "Loop Header" in ln]
+    loop = None
+    for h in hdrs:
+        nxt = min([x for x in hdrs if x > h] + [len(lines)])
+        if any("buffer_load" in lines[i] for i in range(h, nxt)) and any("#ASMSTART" in lines[i] for i in range(h, nxt)):
+            loop = h
+            break
+    if loop is None:
+        return ["%s: pass loop not found" % name]
+    # loop end: last line that branches back to the header label
+    label = lines[loop].split(":")[0].strip()
+    back = max(i for i, ln in enumerate(lines) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\b", ln))
+    pre = [x for x in seq if x[0] < loop]
+    body = [x for x in seq if loop <= x[0] <= back]
+    post = [x for x in seq if x[0] > back]
+    run(pre)
+    run(body)
+    run(body)
+    run(post)
+    if fifo:
+        errors.append("%s: %d asm loads never waited for" % (name, len(fifo)))
+    return errors
+
+
+def main():
+    if len(sys.argv) > 1:
+        text = open(sys.argv[1]).read()
+    else:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "conv.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-S", "--cuda-device-only", SRC, "-o", out],
+                                  stderr=subprocess.DEVNULL)
+            text = open(out).read()
+    lines = text.split("\n")
+    starts = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3scn12k_conv_tile4\S*:", ln)]
+    errors = []
+    n = 0
+    for st in starts:
+        name = lines[st].split(":")[0]
+        end = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i])
+        errors += check_kernel(name, lines[st:end + 1])
+        n += 1
+    for e in errors[:40]:
+        print("check_asm_loads:", e)
+    print("check_asm_loads: %d kernels, %d violations" % (n, len(errors)))
+    return 1 if errors or n == 0 else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

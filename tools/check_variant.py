@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", default="2,4")
     ap.add_argument("--sites", type=int, default=40000)
+    ap.add_argument("--dbg", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -33,6 +34,7 @@ def main():
         outs = []
         for v in vs:
             lib.scn_set_tuning(0, v)
+            lib.scn_set_tuning(1, args.dbg if v == 4 else 0)
             out = torch.empty(0, device=dev)
             SCN._conv(x, out, w, b, rb, 0, 1, n)
             outs.append(out.clone())
@@ -41,6 +43,7 @@ def main():
             err = (o - ref).abs().max().item() / ref.abs().max().item()
             print("N=%d %d->%d v%d vs v%d: rel err %.3g %s" % (n, ci, co, v, vs[0], err, "OK" if err < 1e-5 else "MISMATCH"), flush=True)
     lib.scn_set_tuning(0, 2)
+    lib.scn_set_tuning(1, 0)
 
 
 if __name__ == "__main__":
