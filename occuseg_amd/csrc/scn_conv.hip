@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     issue_rows(0, preA);
     issue_weights(0, wcur);
 
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     auto phase = [&](int p, floatx4 (&pre)[NSLOT]) __attribute__((always_inline)) {
       const int kk = p / nch, chn = p - kk * nch;
       const int ngroups = (uni(kseg[kk][1]) + 15) >> 4;
@@ -709,7 +709,7 @@ __global__ void __launch_bounds__(128)
                : "+v"(R[0][0]), "+v"(R[0][1]), "+v"(R[0][2]), "+v"(R[0][3]), "+v"(R[1][0]), "+v"(R[1][1]),          \
                  "+v"(R[1][2]), "+v"(R[1][3]), "+v"(W[0][0]), "+v"(W[0][1]), "+v"(W[0][2]), "+v"(W[0][3]),          \
                  "+v"(W[1][0]), "+v"(W[1][1]), "+v"(W[1][2]), "+v"(W[1][3])::"memory")
-  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
   auto scatter = [&](const floatx4 (&a)[2][COS], const floatx4 (&old)[2][COS], const int (&orow)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -739,8 +739,8 @@ __global__ void __launch_bounds__(128)
     u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
     unsigned off[2], ioff[2];
     int ibase;
-    floatx4 rA[2][NS16], rB[2][NS16], wc[COS][NS16], wn[COS][NS16], prev[2][COS];
-    int o0r[2], o1r[2], op[2] = {M * OS, M * OS};  // output-tile rows of pass p, p+1, p-1
+    floatx4 rA[2][NS16], rB[2][NS16], rC[2][NS16], wc[COS][NS16], wn[COS][NS16], prev[2][COS];
+    int o0r[2], o1r[2], o2r[2], op[2] = {M * OS, M * OS};  // output-tile rows of pass p, p+1, p+2, p-1
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -767,24 +767,30 @@ __global__ void __launch_bounds__(128)
     Desc D1 = gen();
     load_idx(D1, pr);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
-    SCN_WAIT_ROWS(0, rA, wc);
+    addr(D1, pr, off, o1r);
+    issue_rows(D1, off, rB);
     int w_so[NS16];
     unsigned w_off;
     bool w_new;
     weight_scalars(D1, D0, w_so, w_off, w_new);
     Desc D2 = gen();
-    index_scalars(D2, ioff, ibase);
+    load_idx(D2, pr);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
+    SCN_WAIT_ROWS(0, rA, wc);
+    SCN_WAIT_ROWS(0, rB, wc);
+    Desc D3 = gen();
+    index_scalars(D3, ioff, ibase);
 
     // One pass: the MFMAs of pass p and, between groups of four of them, everything else:
-    //   slot 0     row offsets / output rows of pass p+1 from its indices; index loads of pass p+2
-    //   slots 1-2  row loads of pass p+1            slot 5  read-add-write of pass p-1 into the output tile
-    //   slots 3-4  weight loads of pass p+1         slot 6  descriptor of pass p+3, load scalars of pass p+2
+    //   slot 0     row offsets / output rows of pass p+2 from its indices (in registers since the previous pass)
+    //   slots 1-2  weight loads of pass p+1         slot 3  index loads of pass p+3
+    //   slots 4-5  row loads of pass p+2 (they stay in flight over the NEXT pass: the gathers are the long-latency loads)
+    //   slot 2/5   read-add-write of pass p-1 into the output tile      slot 6  descriptor of pass p+4, load scalars
     // A wave that stalls on the vector-memory issue path or on scalar bookkeeping then still has MFMAs queued.
-    auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rn)[2][NS16]) __attribute__((always_inline)) {
-      if (DBG & 256) { t0 = stamp(); }
+    auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rm)[2][NS16], floatx4 (&rn)[2][NS16]) __attribute__((always_inline)) {
       const bool two = (D0.g + 1) * 16 < D0.c;
       floatx4 acc[2][COS], old[2][COS];
-      Desc D3 = D2;
+      Desc D4 = D3;
       int n_so[NS16], n_ibase = 0, rso = 0;
       unsigned n_off = OOB, n_ioff[2] = {OOB, OOB};
       bool n_new = false;
@@ -794,33 +800,31 @@ __global__ void __launch_bounds__(128)
         for (int q = 0; q < COS; ++q) acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
       auto slot = [&](int j) __attribute__((always_inline)) {
         if (j == 0) {
-          addr(D1, pr, off, o1r);
-          rso = uni(D1.chn * (CK * 4));
-          __builtin_amdgcn_sched_barrier(0);  // pr is consumed above, reloaded below
+          addr(D2, pr, off, o2r);
+          rso = uni(D2.chn * (CK * 4));
+        } else if (j == 1 || j == 2) {
+#pragma unroll
+          for (int sp = 2 * (j - 1); sp < 2 * (j - 1) + 2; ++sp) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wn[0][sp]) : "v"(w_off), "s"(wp_rsrc), "s"(w_so[sp]) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(wn[1][sp]) : "v"(w_off), "s"(wp_rsrc), "s"(w_so[sp]) : "memory");
+          }
+          if (j == 2) tile_rows(old, op);
+        } else if (j == 3) {
           asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[0]) : "v"(ioff[0]), "s"(ru_rsrc), "s"(ibase) : "memory");
           asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[1]) : "v"(ioff[1]), "s"(ru_rsrc), "s"(ibase) : "memory");
-        } else if (j == 1 || j == 2) {
-          const int i = j - 1;
+        } else if (j == 4 || j == 5) {
+          const int i = j - 4;
           asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rn[i][0]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
           asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rn[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
           asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rn[i][2]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
           asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rn[i][3]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
-          if (j == 2) tile_rows(old, op);
-        } else if (j == 3 || j == 4) {
-#pragma unroll
-          for (int sp = 2 * (j - 3); sp < 2 * (j - 3) + 2; ++sp) {
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wn[0][sp]) : "v"(w_off), "s"(wp_rsrc), "s"(w_so[sp]) : "memory");
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(wn[1][sp]) : "v"(w_off), "s"(wp_rsrc), "s"(w_so[sp]) : "memory");
-          }
-        } else if (j == 5) {
-          scatter(prev, old, op);
+          if (j == 5) scatter(prev, old, op);
         } else if (j == 6) {
-          D3 = gen();
+          D4 = gen();
           weight_scalars(D2, D1, n_so, n_off, n_new);
-          index_scalars(D3, n_ioff, n_ibase);
+          index_scalars(D4, n_ioff, n_ibase);
         }
       };
-      if (DBG & 256) { t1 = stamp(); seg[0] += t1 - t0; t0 = t1; }
       if (!(DBG & 16)) {
 #pragma unroll
         for (int sp = 0; sp < NS16; ++sp) {
@@ -829,14 +833,18 @@ __global__ void __launch_bounds__(128)
           acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].y, rc[0][sp].y, acc[0][0], 0, 0, 0);
           acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].y, rc[0][sp].y, acc[0][1], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+          if (DBG & 256) t0 = stamp();
           slot(2 * sp);
+          if (DBG & 256) { t1 = stamp(); seg[sp == 0 ? 0 : sp == 1 ? 1 : sp == 2 ? 3 : 0] += t1 - t0; }
           __builtin_amdgcn_sched_barrier(0);
           acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].z, rc[0][sp].z, acc[0][0], 0, 0, 0);
           acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].z, rc[0][sp].z, acc[0][1], 0, 0, 0);
           acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].w, rc[0][sp].w, acc[0][0], 0, 0, 0);
           acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].w, rc[0][sp].w, acc[0][1], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+          if (DBG & 256) t0 = stamp();
           slot(2 * sp + 1);
+          if (DBG & 256) { t1 = stamp(); if (sp < 3) seg[sp == 0 ? 1 : sp == 1 ? 2 : 3] += t1 - t0; }
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -856,22 +864,21 @@ __global__ void __launch_bounds__(128)
           acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].w, rc[1][sp].w, acc[1][1], 0, 0, 0);
         }
       }
-      if (DBG & 256) { asm volatile("s_nop 7\n\ts_nop 7" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1])); t1 = stamp(); seg[3] += t1 - t0; t0 = t1; }
-      // everything this pass requested: rows and weights of pass p+1, indices of pass p+2
-      // (the destinations are named as INPUTS: that keeps them allocated until here even where nothing reads them,
-      //  and unlike a "+v" tie it gives hipcc no reason to copy them in front of the wait)
+      // rows of pass p+1 (requested one pass ago: `rm`), weights of pass p+1 and indices of pass p+3 (this pass); the
+      // 8 row loads of pass p+2 stay in flight.  Destinations are named as INPUTS: that keeps them allocated until here
+      // even where nothing reads them, and unlike a "+v" tie it gives hipcc no reason to copy them in front of the wait.
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::"v"(rn[0][0]), "v"(rn[0][1]), "v"(rn[0][2]), "v"(rn[0][3]), "v"(rn[1][0]),
-                   "v"(rn[1][1]), "v"(rn[1][2]), "v"(rn[1][3]), "v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]),
+      asm volatile("s_waitcnt vmcnt(8)" ::"v"(rm[0][0]), "v"(rm[0][1]), "v"(rm[0][2]), "v"(rm[0][3]), "v"(rm[1][0]),
+                   "v"(rm[1][1]), "v"(rm[1][2]), "v"(rm[1][3]), "v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]),
                    "v"(wn[0][3]), "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]), "v"(pr[0]), "v"(pr[1])
                    : "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (DBG & 256) { t1 = stamp(); seg[4] += t1 - t0; t0 = t1; seg[5] += 1; }
+      if (DBG & 256) seg[4] += 1;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int q = 0; q < COS; ++q) prev[i][q] = acc[i][q];
-        op[i] = o0r[i]; o0r[i] = o1r[i];
+        op[i] = o0r[i]; o0r[i] = o1r[i]; o1r[i] = o2r[i];
         ioff[i] = n_ioff[i];
       }
       ibase = n_ibase;
@@ -885,13 +892,19 @@ __global__ void __launch_bounds__(128)
       for (int sp = 0; sp < NS16; ++sp) w_so[sp] = n_so[sp];
       w_off = n_off;
       w_new = n_new;
-      D0 = D1; D1 = D2; D2 = D3;
+      D0 = D1; D1 = D2; D2 = D3; D3 = D4;
     };
     do {  // single exit: a mid-loop break makes hipcc read "undefined" scalars out of a row register.  A pass past the
           // end is an empty one (all loads out of range, rows zero, output rows = sink) that only flushes `prev`.
-      body(rA, rB);
-      body(rB, rA);
+      body(rA, rB, rC);
+      body(rB, rC, rA);
+      body(rC, rA, rB);
     } while (D0.c != 0);
+    // the (out-of-range) row prefetches of the passes past the end; they target rA..rC
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(rA[0][0]), "v"(rA[0][1]), "v"(rA[0][2]), "v"(rA[0][3]), "v"(rA[1][0]), "v"(rA[1][1]),
+                 "v"(rA[1][2]), "v"(rA[1][3]), "v"(rB[0][0]), "v"(rB[0][1]), "v"(rB[0][2]), "v"(rB[0][3]), "v"(rB[1][0]),
+                 "v"(rB[1][1]), "v"(rB[1][2]), "v"(rB[1][3]), "v"(rC[0][0]), "v"(rC[0][1]), "v"(rC[0][2]), "v"(rC[0][3]),
+                 "v"(rC[1][0]), "v"(rC[1][1]), "v"(rC[1][2]), "v"(rC[1][3]) : "memory");
     {  // result of the last pass
       floatx4 old[2][COS];
       tile_rows(old, op);
@@ -899,7 +912,7 @@ __global__ void __launch_bounds__(128)
     }
   }
   if ((DBG & 256) && lane == 0)
-    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], seg[i]);
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
   // each wave stores its own 32 planes: no barrier needed
   const int rows = (int)min((int64_t)M, n_out - o0);
   for (int i = lane; i < rows * 8; i += 64) {
