@@ -128,7 +128,8 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
                      int64_t stride, int in_col, int out_col, int64_t n_in, int64_t n_out, int Ci,
                      int Co, void *wpack, void *stream);
 
-/* debugging aid for A/B runs: key 0 = gather-mm kernel variant (1 synchronous, 2 pipelined [default]) */
+/* debugging aid for A/B runs: key 0 = gather-mm kernel variant (1 synchronous, 2 LDS-staged pipelined for all
+ * shapes, 4 [default] barrier-free two-wave kernel where it applies); key 1 = ablation/stamp build of that kernel */
 int scn_set_tuning(int key, int value);
 /* debugging aid: cycle sums per pipeline segment of the diagnostic kernel build (8 x u64, host) */
 int scn_debug_stamps(unsigned long long *out_host);

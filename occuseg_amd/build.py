@@ -22,6 +22,7 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, "scn_common.h"), os.path.join(HERE, "..", "include", "scn_hip.h")]
     objs = []
     procs = []
+    checker = None
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
@@ -31,9 +32,21 @@ def build(force=False, verbose=True):
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))
+            if s == "scn_conv.hip":
+                # k_conv_tile4 schedules its loads by hand (inline asm + counted s_waitcnt): prove on the emitted
+                # assembly that no instruction touches a register whose load is still in flight
+                chk = [sys.executable, os.path.join(HERE, "..", "tools", "check_asm_loads.py")]
+                checker = (chk, subprocess.Popen(chk, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    if checker is not None:
+        out = checker[1].communicate()[0].decode()
+        if verbose:
+            print(out.strip().split("\n")[-1], flush=True)
+        if checker[1].returncode != 0:
+            os.remove(os.path.join(CSRC, "scn_conv.o"))
+            raise RuntimeError("check_asm_loads failed:\n" + out)
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
         if verbose:

@@ -29,6 +29,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KMAX = 27;
+constexpr int SCN_TILE4_MAX_CHUNKS = 5;  // k_conv_tile4: C_i <= 320 (pass table in LDS)
 
 // diagnostic build only (DBG bit 8 = 256): per-segment cycle sums of the pipelined kernel, added from
 // lane 0 of every wave at kernel end into a buffer nothing else reads (scn_debug_stamps copies it out).
@@ -442,7 +443,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     issue_rows(0, preA);
     issue_weights(0, wcur);
 
-    unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     auto phase = [&](int p, floatx4 (&pre)[NSLOT]) __attribute__((always_inline)) {
       const int kk = p / nch, chn = p - kk * nch;
       const int ngroups = (uni(kseg[kk][1]) + 15) >> 4;
@@ -562,18 +563,29 @@ __global__ void __launch_bounds__(64 * NW * NWM)
 }
 
 // ------------------------------------ forward, barrier-free wave-private (v4) ---
-// Same tile (128 output rows x 64 planes kept in LDS), different division of labour: a workgroup is
-// TWO waves, each owning 32 output planes (two 16-plane slices) and walking the offsets on its own.
-// The MFMA B operand (gathered rows) is loaded straight from global memory in fragment shape -- lane
-// (pair li, k-quad lq) fetches 16 bytes of ITS pair's row -- so there is no LDS staging tile, no
-// ds_write, and, because each wave only ever touches its own planes of the output tile, NO barrier
-// after the tile set-up.  Price: every row is fetched by both waves (2x L1 traffic, 64-byte segments).
-// Three-stage register pipeline over passes (a pass = two 16-pair groups): pass p computes, rows and weight
-// fragments of pass p+1 and pair indices of pass p+2 are in flight; the loads are inline asm with hand-counted
-// s_waitcnt (see the comment at load_idx).  Measured (tools/bench_conv.py, tools/stamps.py): 80-89 TF, i.e. +4-8 %
-// over k_conv_tile2 for C_o = 64 and -2 % for 256->128; a wave spends ~1900 cycles of a ~5400-cycle pass ISSUING
-// its 18 loads (850 when they are all out of range), so the kernel is bound by the vector-memory issue path, not
-// by latency.  Opt-in: scn_set_tuning(0, 4).
+// Same tile (128 output rows x 64 planes kept in LDS) as k_conv_tile2, different division of labour: a workgroup
+// is TWO waves, each owning 32 output planes (two 16-plane slices) and walking the offsets on its own.  The MFMA B
+// operand (gathered rows) is loaded straight from global memory in fragment shape -- lane (pair li, k-quad lq)
+// fetches 16 bytes of ITS pair's row -- so there is no LDS staging tile, no ds_write, and, because a wave only ever
+// touches its own planes of the output tile, NO barrier after the tile set-up.  Price: every row is fetched by both
+// waves (64-byte segments).
+//
+// The unit of work is a PASS: up to two 16-pair groups of one (offset, C_i chunk) phase, 32 or 64 MFMAs per wave.  All
+// passes of the tile are tabulated in LDS during set-up (8 bytes each), so the loop itself carries almost no scalar
+// bookkeeping (the first version generated the pass sequence on the fly: ~1100 of ~4800 cycles per pass).  Everything
+// that is not an MFMA is issued in "slots" between groups of four MFMAs, so that a wave stalled on the vector-memory
+// issue path still has MFMAs queued:
+//   pass p computes | its rows and weights are in registers | rows of pass p+1 were requested during pass p-1 |
+//   during pass p: row offsets of pass p+2 from its (arrived) indices, weight loads of pass p+1, index loads of
+//   pass p+3, row loads of pass p+2, read-add-write of pass p-1's result into the output tile, table entry p+4.
+// The loads are inline asm with hand-counted s_waitcnt: hipcc's own counters collapse to vmcnt(0..8) at the top of
+// every pass once loads stay in flight over the back edge of the unrolled loop.  Every pass issues the same loads in
+// the same order (8 weight, 2 index, 8 row); the ones a pass does not need point past the end of their buffer (the
+// range check returns 0 without touching memory).  hipcc does not know that an asm load's destination is not valid
+// until the wait, so: the waits name the destinations as INPUTS (keeps them allocated; a "+v" tie made hipcc copy
+// them in FRONT of the wait), nothing but row registers (fixed variables of a 3-way unrolled loop) is in flight over
+// the back edge, and tools/check_asm_loads.py (run by build.py) proves on the emitted assembly that no instruction
+// touches a register with a load in flight.
 template <int DBG = 0>
 __global__ void __launch_bounds__(128)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
@@ -582,9 +594,10 @@ __global__ void __launch_bounds__(128)
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes) {
   constexpr int M = 128, COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
+  constexpr int TMAX = KMAX * 4 * SCN_TILE4_MAX_CHUNKS + 8;  // passes per tile: <= 4 per (offset, chunk); + sentinels
   __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
-  __shared__ __attribute__((aligned(16))) int kinfo[KMAX + 4][4];  // {offset k, first pair, #pairs, 0}; #pairs 0 past the end
-
+  __shared__ __attribute__((aligned(8))) unsigned ptab[TMAX][2];  // {byte offset of the pass's first pair in `rules`,
+                                                                  //  pairs left in the list | chunk<<8 | k<<12 | first<<20}
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -606,6 +619,7 @@ __global__ void __launch_bounds__(128)
   const int64_t o0 = (int64_t)tile * M;
   const int g0 = tile * (M / SCN_TILE_GRANULE);
   const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
+  const int nch = Ci / CK;
 
   // each wave initialises ITS 32 planes of the output tile
   for (int i = lane; i < (M + 1) * 8; i += 64) {
@@ -614,102 +628,82 @@ __global__ void __launch_bounds__(128)
     if (bias) v = *(const floatx4 *)(bias + co0 + 32 * w + c4);
     *(floatx4 *)(o_tile + r * OS + 32 * w + c4) = v;
   }
-  if (tid < 64) {
-    int s = 0, e = 0;
+  if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
+    int s = 0, c = 0;
     if (tid < K) {
       s = bases[(int64_t)tid * (n_gran + 1) + g0];
-      e = bases[(int64_t)tid * (n_gran + 1) + g1];
+      c = bases[(int64_t)tid * (n_gran + 1) + g1] - s;
     }
-    if (tid < KMAX + 4) *(int4 *)kinfo[tid] = int4{0, 0, 0, 0};
-    const unsigned long long m = __ballot(e > s);
-    if (e > s) {
-      const int pos = __popcll(m & ((1ull << tid) - 1ull));
-      *(int4 *)kinfo[pos] = int4{tid, s, e - s, 0};
+    const int npl = (c + 31) >> 5;  // passes per chunk
+    int pos = npl * nch;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(pos, o);
+      if (lane >= o) pos += y;
+    }
+    const int total = __shfl(pos, 63);
+    pos -= npl * nch;
+    const unsigned first = (unsigned)(((int64_t)tid * stride + s) * 8);
+    for (int chn = 0; chn < nch; ++chn)
+      for (int j = 0; j < npl; ++j) {
+        ptab[pos][0] = first + (unsigned)j * 256u;
+        ptab[pos][1] = (unsigned)(c - 32 * j) | (unsigned)chn << 8 | (unsigned)tid << 12 | (j == 0 ? 1u << 20 : 0u);
+        ++pos;
+      }
+    if (tid < 8) {  // sentinels: empty passes
+      ptab[total + tid][0] = 0u;
+      ptab[total + tid][1] = 0u;
     }
   }
   __syncthreads();  // the only barrier
   auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
-  struct Info { int k, s, c; };
-  auto info = [&](int kk) __attribute__((always_inline)) {
-    const int4 v = *(const int4 *)kinfo[kk];
-    return Info{uni(v.x), uni(v.y), uni(v.z)};
-  };
-  const int nch = Ci / CK;
-
-  // Software pipeline over PASSES (a pass = up to two 16-pair groups of one (offset, C_i chunk) phase):
-  //   pass p computes;  rows + weight fragments of pass p+1 are in flight;  pair indices of pass p+2 are in flight.
-  // Every pass issues the SAME vector loads in the same order (2 index, 8 row, 8 weight) so that the
-  // compiler's s_waitcnt counters stay exact across the loop; loads that are not needed are pointed past
-  // the end of their buffer (the range check returns 0 without touching memory).
   constexpr unsigned OOB = 0x80000000u;
-  struct Desc { int k, chn, g, c, s; };  // pass descriptor; c == 0: no such pass
-  // generator state: position of the pass two ahead
-  Info G0 = info(0), G1 = info(1);
-  int gkk = 0, gchn = 0, gg = 0;
-  auto gen = [&]() __attribute__((always_inline)) {
-    const Desc d = {G0.k, gchn, gg, G0.c, G0.s};
-    const int ng = (G0.c + 15) >> 4;
-    const bool endp = gg + 2 >= ng;            // last pass of the phase
-    const bool endl = endp && gchn + 1 >= nch;  // ... and of the list
-    gg = uni(endp ? 0 : gg + 2);
-    gchn = uni(endl ? 0 : gchn + (endp ? 1 : 0));
-    const Info nx = info(min(gkk + 2, KMAX + 3));
-    gkk = uni(gkk + (endl ? 1 : 0));
-    G0.k = uni(endl ? G1.k : G0.k); G0.s = uni(endl ? G1.s : G0.s); G0.c = uni(endl ? G1.c : G0.c);
-    G1.k = uni(endl ? nx.k : G1.k); G1.s = uni(endl ? nx.s : G1.s); G1.c = uni(endl ? nx.c : G1.c);
-    return d;
+  struct Ent { unsigned base, meta; };  // meta & 255: pairs left (0: no such pass)
+  auto entry = [&](int p) __attribute__((always_inline)) {
+    const uint2 v = *(const uint2 *)ptab[p];
+    return Ent{(unsigned)uni((int)v.x), (unsigned)uni((int)v.y)};
   };
-  // The loads are inline asm with hand-placed s_waitcnt: hipcc's own counters cannot follow loads that
-  // stay in flight across the loop back edge and the two unrolled halves (it emitted vmcnt(7..8) at the top
-  // of every pass, i.e. "next pass's rows have arrived", which left nothing in flight during the MFMAs).
-  // Each wait statement names the registers it makes valid ("+v"), so no use can be scheduled above it.
-  auto load_idx = [&](const Desc &d, u32x2 (&pr)[2]) __attribute__((always_inline)) {
-    const int base = uni((int)(((int64_t)d.k * stride + d.s) * 8));
+  auto rem = [](const Ent &e) __attribute__((always_inline)) { return (int)(e.meta & 255u); };
+  // per-lane byte offsets of a pass's two index loads
+  auto index_offsets = [&](const Ent &e, unsigned (&vo)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int p = (d.g + i) * 16 + li;
-      const unsigned off = ((d.g + i) * 16 < d.c) ? (unsigned)min(p, d.c - 1) * 8u : OOB;
-      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(pr[i]) : "v"(off), "s"(ru_rsrc), "s"(base) : "memory");
-    }
+    for (int i = 0; i < 2; ++i) vo[i] = (16 * i < rem(e)) ? (unsigned)min(16 * i + li, rem(e) - 1) * 8u : OOB;
   };
   // row byte offsets / output-tile rows of a pass from its pair indices
-  auto addr = [&](const Desc &d, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
+  auto addr = [&](const Ent &e, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int p = (d.g + i) * 16 + li;
-      const bool grp = (d.g + i) * 16 < d.c;
       const unsigned src = in_col ? pr[i].y : pr[i].x;
       const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
-      off[i] = (grp && !(DBG & 2)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
-      orow[i] = (p < d.c) ? dst * OS : M * OS;
+      off[i] = (16 * i < rem(e) && !(DBG & 2)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
+      orow[i] = (16 * i + li < rem(e)) ? dst * OS : M * OS;
     }
   };
-  auto issue_rows = [&](const Desc &d, const unsigned (&off)[2], floatx4 (&rows)[2][NS16]) __attribute__((always_inline)) {
-    const int so = uni(d.chn * (CK * 4));
+  auto weight_scalars = [&](const Ent &e, int (&so)[NS16], unsigned &voff, bool &fresh) __attribute__((always_inline)) {
+    const int k = (int)(e.meta >> 12) & 255, chn = (int)(e.meta >> 8) & 15;
+    fresh = (e.meta >> 20) & 1u;
+    const int blk = (k * (Ci / 16) + chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rows[i][0]) : "v"(off[i]), "s"(in_rsrc), "s"(so) : "memory");
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rows[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(so) : "memory");
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rows[i][2]) : "v"(off[i]), "s"(in_rsrc), "s"(so) : "memory");
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rows[i][3]) : "v"(off[i]), "s"(in_rsrc), "s"(so) : "memory");
-    }
+    for (int sp = 0; sp < NS16; ++sp) so[sp] = (blk + sp * (Co / 16)) * 1024;
+    voff = (fresh && !(DBG & 8)) ? (unsigned)lane * 16u : OOB;
   };
-  auto issue_weights = [&](const Desc &d, bool real, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
-    const int blk0 = uni((d.k * (Ci / 16) + d.chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS);
-    const unsigned off = (real && !(DBG & 8)) ? (unsigned)lane * 16u : OOB;
+  auto load_idx = [&](const Ent &e, const unsigned (&vo)[2], u32x2 (&pr)[2]) __attribute__((always_inline)) {
+    const int base = (int)e.base;
 #pragma unroll
-    for (int sp = 0; sp < NS16; ++sp) {
-      const int so = uni((blk0 + sp * (Co / 16)) * 1024);
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wr[0][sp]) : "v"(off), "s"(wp_rsrc), "s"(so) : "memory");
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(wr[1][sp]) : "v"(off), "s"(wp_rsrc), "s"(so) : "memory");
-    }
+    for (int i = 0; i < 2; ++i)
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[i]) : "v"(vo[i]), "s"(ru_rsrc), "s"(base) : "memory");
   };
-#define SCN_WAIT_ROWS(N, R, W)                                                                                      \
-  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                            \
-               : "+v"(R[0][0]), "+v"(R[0][1]), "+v"(R[0][2]), "+v"(R[0][3]), "+v"(R[1][0]), "+v"(R[1][1]),          \
-                 "+v"(R[1][2]), "+v"(R[1][3]), "+v"(W[0][0]), "+v"(W[0][1]), "+v"(W[0][2]), "+v"(W[0][3]),          \
-                 "+v"(W[1][0]), "+v"(W[1][1]), "+v"(W[1][2]), "+v"(W[1][3])::"memory")
-  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+  auto load_rows = [&](int i, unsigned voff, int so, floatx4 (&rows)[2][NS16]) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rows[i][0]) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rows[i][1]) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rows[i][2]) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rows[i][3]) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+  };
+  auto load_weights = [&](int sp, unsigned voff, int so, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wr[0][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(wr[1][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+  };
+#define SCN_ROWS(R) "v"(R[0][0]), "v"(R[0][1]), "v"(R[0][2]), "v"(R[0][3]), "v"(R[1][0]), "v"(R[1][1]), "v"(R[1][2]), "v"(R[1][3])
   auto scatter = [&](const floatx4 (&a)[2][COS], const floatx4 (&old)[2][COS], const int (&orow)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -729,100 +723,84 @@ __global__ void __launch_bounds__(128)
       for (int q = 0; q < COS; ++q)
         if (!(DBG & 1)) old[i][q] = *(const floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq);
   };
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 
-  if (G0.c > 0) {
-    // ---- pipeline state.  At the top of pass p: rows(p), weights(p) and the pair indices of pass p+1 are in
-    // registers, nothing is in flight; D0..D2 describe passes p..p+2; the weight-load scalars of pass p+1 (w_*) and the
-    // index-load offsets of pass p+2 (ioff, ibase) are known.  Every load is issued AND waited for inside one pass, so
-    // no register with a load in flight lives across the loop back edge, where hipcc is free to insert copies
-    // (it did: v_mov of the index registers in front of the wait; tools/check_asm_loads.py now guards the build).
+  Ent E0 = entry(0);
+  if (rem(E0) > 0) {
+    // ---- pipeline state at the top of pass p: rows(p) in rc, rows(p+1) in rm (arrived), weights(p) in wc, indices of
+    // pass p+2 in pr (arrived); E0..E3 = table entries p..p+3; `ioff` = index-load offsets of pass p+3.
     u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
     unsigned off[2], ioff[2];
-    int ibase;
     floatx4 rA[2][NS16], rB[2][NS16], rC[2][NS16], wc[COS][NS16], wn[COS][NS16], prev[2][COS];
     int o0r[2], o1r[2], o2r[2], op[2] = {M * OS, M * OS};  // output-tile rows of pass p, p+1, p+2, p-1
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < COS; ++q) prev[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
-    auto weight_scalars = [&](const Desc &d, const Desc &before, int (&so)[NS16], unsigned &voff, bool &np) __attribute__((always_inline)) {
-      np = d.c > 0 && (d.k != before.k || d.chn != before.chn);
-      const int blk = uni((d.k * (Ci / 16) + d.chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS);
+    Ent E1 = entry(1), E2 = entry(2), E3 = entry(3);
+    int pnext = 4;  // table index of the entry read during the current pass
+    {  // prologue (not overlapped; once per tile)
+      int so[NS16];
+      unsigned voff;
+      bool fresh;
+      index_offsets(E0, ioff);
+      load_idx(E0, ioff, pr);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      addr(E0, pr, off, o0r);
+      weight_scalars(E0, so, voff, fresh);
 #pragma unroll
-      for (int sp = 0; sp < NS16; ++sp) so[sp] = uni((blk + sp * (Co / 16)) * 1024);
-      voff = (np && !(DBG & 8)) ? (unsigned)lane * 16u : OOB;
-    };
-    auto index_scalars = [&](const Desc &d, unsigned (&vo)[2], int &base) __attribute__((always_inline)) {
-      base = uni((int)(((int64_t)d.k * stride + d.s) * 8));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        vo[i] = ((d.g + i) * 16 < d.c) ? (unsigned)min((d.g + i) * 16 + li, d.c - 1) * 8u : OOB;
-    };
-    Desc D0 = gen();
-    load_idx(D0, pr);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
-    addr(D0, pr, off, o0r);
-    issue_weights(D0, true, wc);
-    issue_rows(D0, off, rA);
-    Desc D1 = gen();
-    load_idx(D1, pr);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
-    addr(D1, pr, off, o1r);
-    issue_rows(D1, off, rB);
-    int w_so[NS16];
-    unsigned w_off;
-    bool w_new;
-    weight_scalars(D1, D0, w_so, w_off, w_new);
-    Desc D2 = gen();
-    load_idx(D2, pr);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pr[0]), "+v"(pr[1])::"memory");
-    SCN_WAIT_ROWS(0, rA, wc);
-    SCN_WAIT_ROWS(0, rB, wc);
-    Desc D3 = gen();
-    index_scalars(D3, ioff, ibase);
+      for (int sp = 0; sp < NS16; ++sp) load_weights(sp, (DBG & 8) ? OOB : (unsigned)lane * 16u, so[sp], wc);
+      load_rows(0, off[0], (int)((E0.meta >> 8) & 15u) * (CK * 4), rA);
+      load_rows(1, off[1], (int)((E0.meta >> 8) & 15u) * (CK * 4), rA);
+      __builtin_amdgcn_sched_barrier(0);
+      index_offsets(E1, ioff);
+      load_idx(E1, ioff, pr);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]), SCN_ROWS(rA), SCN_ROWS(wc) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      addr(E1, pr, off, o1r);
+      load_rows(0, off[0], (int)((E1.meta >> 8) & 15u) * (CK * 4), rB);
+      load_rows(1, off[1], (int)((E1.meta >> 8) & 15u) * (CK * 4), rB);
+      __builtin_amdgcn_sched_barrier(0);
+      index_offsets(E2, ioff);
+      load_idx(E2, ioff, pr);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]), SCN_ROWS(rB) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      index_offsets(E3, ioff);
+    }
 
-    // One pass: the MFMAs of pass p and, between groups of four of them, everything else:
-    //   slot 0     row offsets / output rows of pass p+2 from its indices (in registers since the previous pass)
-    //   slots 1-2  weight loads of pass p+1         slot 3  index loads of pass p+3
-    //   slots 4-5  row loads of pass p+2 (they stay in flight over the NEXT pass: the gathers are the long-latency loads)
-    //   slot 2/5   read-add-write of pass p-1 into the output tile      slot 6  descriptor of pass p+4, load scalars
-    // A wave that stalls on the vector-memory issue path or on scalar bookkeeping then still has MFMAs queued.
     auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rm)[2][NS16], floatx4 (&rn)[2][NS16]) __attribute__((always_inline)) {
-      const bool two = (D0.g + 1) * 16 < D0.c;
+      const bool two = rem(E0) > 16;
       floatx4 acc[2][COS], old[2][COS];
-      Desc D4 = D3;
-      int n_so[NS16], n_ibase = 0, rso = 0;
-      unsigned n_off = OOB, n_ioff[2] = {OOB, OOB};
-      bool n_new = false;
+      Ent E4 = E3;
+      int w_so[NS16], rso = 0;
+      unsigned w_off = OOB;
+      bool w_new = false;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int q = 0; q < COS; ++q) acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
       auto slot = [&](int j) __attribute__((always_inline)) {
-        if (j == 0) {
-          addr(D2, pr, off, o2r);
-          rso = uni(D2.chn * (CK * 4));
-        } else if (j == 1 || j == 2) {
-#pragma unroll
-          for (int sp = 2 * (j - 1); sp < 2 * (j - 1) + 2; ++sp) {
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wn[0][sp]) : "v"(w_off), "s"(wp_rsrc), "s"(w_so[sp]) : "memory");
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(wn[1][sp]) : "v"(w_off), "s"(wp_rsrc), "s"(w_so[sp]) : "memory");
-          }
-          if (j == 2) tile_rows(old, op);
-        } else if (j == 3) {
-          asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[0]) : "v"(ioff[0]), "s"(ru_rsrc), "s"(ibase) : "memory");
-          asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[1]) : "v"(ioff[1]), "s"(ru_rsrc), "s"(ibase) : "memory");
-        } else if (j == 4 || j == 5) {
-          const int i = j - 4;
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rn[i][0]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rn[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rn[i][2]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rn[i][3]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
-          if (j == 5) scatter(prev, old, op);
-        } else if (j == 6) {
-          D4 = gen();
-          weight_scalars(D2, D1, n_so, n_off, n_new);
-          index_scalars(D4, n_ioff, n_ibase);
+        if (j == 0) {         // row offsets / output rows of pass p+2; weight-load scalars of pass p+1
+          addr(E2, pr, off, o2r);
+          rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
+          weight_scalars(E1, w_so, w_off, w_new);
+        } else if (j == 1) {  // weights of pass p+1
+          load_weights(0, w_off, w_so[0], wn);
+          load_weights(1, w_off, w_so[1], wn);
+        } else if (j == 2) {
+          load_weights(2, w_off, w_so[2], wn);
+          load_weights(3, w_off, w_so[3], wn);
+          tile_rows(old, op);
+        } else if (j == 3) {  // indices of pass p+3 (pr was consumed in slot 0)
+          load_idx(E3, ioff, pr);
+        } else if (j == 4) {  // rows of pass p+2: the long-latency gathers, in flight until the end of pass p+1
+          load_rows(0, off[0], rso, rn);
+        } else if (j == 5) {
+          load_rows(1, off[1], rso, rn);
+          scatter(prev, old, op);
+        } else if (j == 6) {  // table entry p+4
+          E4 = entry(pnext);
         }
       };
       if (!(DBG & 16)) {
@@ -864,14 +842,10 @@ __global__ void __launch_bounds__(128)
           acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].w, rc[1][sp].w, acc[1][1], 0, 0, 0);
         }
       }
-      // rows of pass p+1 (requested one pass ago: `rm`), weights of pass p+1 and indices of pass p+3 (this pass); the
-      // 8 row loads of pass p+2 stay in flight.  Destinations are named as INPUTS: that keeps them allocated until here
-      // even where nothing reads them, and unlike a "+v" tie it gives hipcc no reason to copy them in front of the wait.
+      // rows of pass p+1 (requested one pass ago: rm), weights of pass p+1 and indices of pass p+3 (this pass); the 8 row
+      // loads of pass p+2 stay in flight.
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(8)" ::"v"(rm[0][0]), "v"(rm[0][1]), "v"(rm[0][2]), "v"(rm[0][3]), "v"(rm[1][0]),
-                   "v"(rm[1][1]), "v"(rm[1][2]), "v"(rm[1][3]), "v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]),
-                   "v"(wn[0][3]), "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]), "v"(pr[0]), "v"(pr[1])
-                   : "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::SCN_ROWS(rm), SCN_ROWS(wn), "v"(pr[0]), "v"(pr[1]) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (DBG & 256) seg[4] += 1;
 #pragma unroll
@@ -879,38 +853,32 @@ __global__ void __launch_bounds__(128)
 #pragma unroll
         for (int q = 0; q < COS; ++q) prev[i][q] = acc[i][q];
         op[i] = o0r[i]; o0r[i] = o1r[i]; o1r[i] = o2r[i];
-        ioff[i] = n_ioff[i];
       }
-      ibase = n_ibase;
       if (w_new) {
 #pragma unroll
         for (int q = 0; q < COS; ++q)
 #pragma unroll
           for (int sp = 0; sp < NS16; ++sp) wc[q][sp] = wn[q][sp];
       }
-#pragma unroll
-      for (int sp = 0; sp < NS16; ++sp) w_so[sp] = n_so[sp];
-      w_off = n_off;
-      w_new = n_new;
-      D0 = D1; D1 = D2; D2 = D3; D3 = D4;
+      E0 = E1; E1 = E2; E2 = E3; E3 = E4;
+      index_offsets(E3, ioff);
+      ++pnext;
     };
     do {  // single exit: a mid-loop break makes hipcc read "undefined" scalars out of a row register.  A pass past the
           // end is an empty one (all loads out of range, rows zero, output rows = sink) that only flushes `prev`.
       body(rA, rB, rC);
       body(rB, rC, rA);
       body(rC, rA, rB);
-    } while (D0.c != 0);
-    // the (out-of-range) row prefetches of the passes past the end; they target rA..rC
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(rA[0][0]), "v"(rA[0][1]), "v"(rA[0][2]), "v"(rA[0][3]), "v"(rA[1][0]), "v"(rA[1][1]),
-                 "v"(rA[1][2]), "v"(rA[1][3]), "v"(rB[0][0]), "v"(rB[0][1]), "v"(rB[0][2]), "v"(rB[0][3]), "v"(rB[1][0]),
-                 "v"(rB[1][1]), "v"(rB[1][2]), "v"(rB[1][3]), "v"(rC[0][0]), "v"(rC[0][1]), "v"(rC[0][2]), "v"(rC[0][3]),
-                 "v"(rC[1][0]), "v"(rC[1][1]), "v"(rC[1][2]), "v"(rC[1][3]) : "memory");
+    } while (rem(E0) > 0);
+    // the (out-of-range) row prefetches of the passes past the end
+    asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS(rA), SCN_ROWS(rB), SCN_ROWS(rC) : "memory");
     {  // result of the last pass
       floatx4 old[2][COS];
       tile_rows(old, op);
       scatter(prev, old, op);
     }
   }
+#undef SCN_ROWS
   if ((DBG & 256) && lane == 0)
     for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
   // each wave stores its own 32 planes: no barrier needed
@@ -1143,7 +1111,8 @@ using namespace scn;
 
 static int g_conv_dbg = 0;
 static int g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile, never split offsets (A/B runs)
-static int g_conv_variant = 2;  // 1 = first synchronous kernel (kept for A/B runs), 2 = pipelined
+static int g_conv_variant = 4;  // 1 = first synchronous kernel (kept for A/B runs), 2 = LDS-staged pipelined kernel for
+                                // every shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
 
 template <int NW, int COS, int M, int CK>
 static int launch_tile(const float *in, float *out, const float *W, const float *bias,
@@ -1301,7 +1270,7 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     // that all 256 CUs have work (their features and weights are L2 resident, the re-gather is free).
     auto blocks = [&](int nw) { return ((n_out + 32 * nw - 1) / (32 * nw)) * (int64_t)(Co / (16 * nw)); };
     const int64_t want = 512;
-    if (g_conv_variant == 4 && s16 % 4 == 0 && Ci % 64 == 0 && blocks(4) >= want && n_in < (1 << 24) &&
+    if (g_conv_variant == 4 && s16 % 4 == 0 && Ci % 64 == 0 && Ci / 64 <= SCN_TILE4_MAX_CHUNKS && blocks(4) >= want && n_in < (1 << 24) &&
         (int64_t)K * stride * 8 < (int64_t)0x7fffffff)
       return launch_tile4(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
     if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off))

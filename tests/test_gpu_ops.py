@@ -207,10 +207,11 @@ def test_network_in_network(gpu, ci, co):
     assert_close(gw.cpu().numpy(), d_w, "NiN dWeight")
 
 
-@pytest.mark.parametrize("ci,co", [(64, 64), (128, 64), (64, 128)])
-def test_submanifold_forward_variant4(gpu, ci, co):
-    """The opt-in barrier-free forward kernel (scn_set_tuning(0, 4)) against the float64 oracle.
-    It is only chosen when the launch has >= 512 tiles, hence the larger grid."""
+@pytest.mark.parametrize("ci,co", [(64, 64), (128, 64), (64, 128), (320, 64)])
+def test_submanifold_forward_variants(gpu, ci, co):
+    """The barrier-free two-wave forward kernel (default where it applies: >= 512 tiles, C_i a multiple of 64 up to
+    320, C_o a multiple of 64 -- hence the larger grid) and the LDS-staged kernel (scn_set_tuning(0, 2)) against
+    the float64 oracle and against each other."""
     from occuseg_amd import SCN, _lib
     from oracle import arith as A, rules as R
     m, size, grid, _, _ = _setup(gpu, seed=11, n=72000, batch=2, extent=60)
@@ -231,7 +232,8 @@ def test_submanifold_forward_variant4(gpu, ci, co):
             assert got == macs
             outs[variant] = out.cpu().numpy()
     finally:
-        lib.scn_set_tuning(0, 2)
+        lib.scn_set_tuning(0, 4)
     assert_close(outs[4], want, "variant 4 forward %d->%d" % (ci, co))
-    # same per-(offset, chunk) summation order as the default kernel: bit-identical
+    assert_close(outs[2], want, "variant 2 forward %d->%d" % (ci, co))
+    # same per-(offset, chunk) summation order in both kernels: bit-identical
     assert np.array_equal(outs[4], outs[2])

@@ -76,24 +76,22 @@ def check_kernel(name, lines):
                 if touched & dst:
                     errors.append("%s: line %d `%s` touches v%s, target of the asm load at line %d still in flight"
                                   % (name, no + 1, s, sorted(touched & dst), lno + 1))
-    # loop body = from the loop header label line to the backward branch; approximate by label positions
-    label_line = None
-    for no, ln in enumerate(lines):
-        if "Loop Header" in ln and label_line is None:
-            # choose the loop header after which asm loads appear before the next header
-            label_line = no
-    hdrs = [no for no, ln in enumerate(lines) if "Loop Header" in ln]
-    loop = None
-    for h in hdrs:
-        nxt = min([x for x in hdrs if x > h] + [len(lines)])
-        if any("buffer_load" in lines[i] for i in range(h, nxt)) and any("#ASMSTART" in lines[i] for i in range(h, nxt)):
-            loop = h
+    # the pass loop: the loop (header label .. last branch back to it) that contains asm buffer loads
+    loop = back = None
+    for h, ln in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):.*Loop Header", ln)
+        if not m:
+            continue
+        label = m.group(1)
+        br = [i for i, l2 in enumerate(lines) if i > h and re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\b", l2)]
+        if not br:
+            continue
+        inside = lines[h:max(br) + 1]
+        if any("#ASMSTART" in l2 for l2 in inside) and any("buffer_load" in l2 for l2 in inside):
+            loop, back = h, max(br)
             break
     if loop is None:
         return ["%s: pass loop not found" % name]
-    # loop end: last line that branches back to the header label
-    label = lines[loop].split(":")[0].strip()
-    back = max(i for i, ln in enumerate(lines) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\b", ln))
     pre = [x for x in seq if x[0] < loop]
     body = [x for x in seq if loop <= x[0] <= back]
     post = [x for x in seq if x[0] > back]

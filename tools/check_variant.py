@@ -42,7 +42,7 @@ def main():
         for v, o in zip(vs[1:], outs[1:]):
             err = (o - ref).abs().max().item() / ref.abs().max().item()
             print("N=%d %d->%d v%d vs v%d: rel err %.3g %s" % (n, ci, co, v, vs[0], err, "OK" if err < 1e-5 else "MISMATCH"), flush=True)
-    lib.scn_set_tuning(0, 2)
+    lib.scn_set_tuning(0, 4)
     lib.scn_set_tuning(1, 0)
 
 
