@@ -970,18 +970,37 @@ template <int TI, int TJ, int PS = 32>
 __global__ void __launch_bounds__(256)
     k_dw_tile(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
               const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
-              int in_col, int Ci, int Co, int chunk, unsigned in_bytes, unsigned do_bytes) {
+              int in_col, int Ci, int Co, int chunk, unsigned in_bytes, unsigned do_bytes, int K) {
   constexpr int CIB = 32 * TI, COB = 32 * TJ;
   constexpr int IS = CIB + 16, DS = COB + 16;  // row strides: (stride % 32) == 16 -> ds_read_b32 conflict-free
   __shared__ __attribute__((aligned(16))) float in_t[PS * IS];
   __shared__ __attribute__((aligned(16))) float do_t[PS * DS];
-  const int k = blockIdx.y;
+  // Work item = (slice c of the pair lists, offset k, plane block t), t fastest, then k, then c, and each XCD takes a
+  // contiguous range of them.  Slice c is the same FRACTION [c/gx, (c+1)/gx) of every list; the lists are sorted by
+  // output row, so the 27 offsets of one slice gather the same neighbourhood of `in` and exactly the same rows of
+  // `dout` at the same time and meet in the XCD's L2.  (With slices of the longest list as the fast grid index whole
+  // lists streamed through the chip one after the other: 2.0-2.3 GB of HBM reads per launch for 0.37 GB of operands.)
+  const int gx = chunk;  // number of slices
+  int lin;
+  {
+    const int total = gridDim.x;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int nci = Ci / CIB, nt = nci * (Co / COB);
+  int t = lin % nt, k = (lin / nt) % K, c = lin / (nt * K);
+  if (K < 0) {  // A/B (scn_set_tuning(1, 101)): slices of the longest list, slice index fastest, no XCD mapping
+    K = -K;
+    c = blockIdx.x % gx; k = (blockIdx.x / gx) % K; t = blockIdx.x / (gx * K);
+  }
   const int count = counts[k];
-  const int p0 = blockIdx.x * chunk;
+  int per = ((count + gx - 1) / gx + PS - 1) / PS * PS;  // pairs per slice of THIS list, whole steps
+  if (in_col >= 2) { per = (int)((stride + gx - 1) / gx + PS - 1) / PS * PS; in_col -= 2; }
+  const int p0 = c * per;
   if (p0 >= count) return;
-  const int p1 = min(count, p0 + chunk);
-  const int nci = Ci / CIB;
-  const int ci0 = (blockIdx.z % nci) * CIB, co0 = (blockIdx.z / nci) * COB;
+  const int p1 = min(count, p0 + per);
+  const int ci0 = (t % nci) * CIB, co0 = (t / nci) * COB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = w & 1, wj = w >> 1;
@@ -1304,23 +1323,24 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
   const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 31) || n_dout * Co * 4 >= ((int64_t)1 << 31);
   if (Ci % 32 == 0 && Co % 32 == 0 && !huge) {
     const unsigned in_bytes = (unsigned)(n_in * Ci * 4), do_bytes = (unsigned)(n_dout * Co * 4);
-    // pairs per workgroup: enough workgroups per (k, plane block) to fill the chip, few enough that the
-    // float atomics of the partial sums (one CIB x COB tile per workgroup) stay far below the ~1.3 TB/s
-    // atomic rate: ~512 chunks over the longest possible list, at least 1024 pairs
-    int chunk = (int)(((stride + 511) / 512 + 63) / 64 * 64);
-    if (chunk < 1024) chunk = 1024;
-    if (chunk > 8192) chunk = 8192;
-    if (g_conv_dbg == 101) chunk = 1024;  // A/B
-    const unsigned gx = (unsigned)((stride + chunk - 1) / chunk);
+    // slices per list: enough workgroups per (k, plane block) to fill the chip, few enough that the float atomics of
+    // the partial sums (one CIB x COB tile per workgroup) stay far below the ~1.3 TB/s atomic rate.  The longest list
+    // (the centre offset: one pair per site) gets ~2400 pairs per workgroup, an average one about half of that.
+    int per = (int)(((stride + 255) / 256 + 63) / 64 * 64);
+    if (per < 2048) per = 2048;
+    if (per > 16384) per = 16384;
+    const int gx = (int)((stride + per - 1) / per);
     if (Ci % 64 == 0 && Co % 64 == 0) {
-      dim3 grid(gx, K, (Ci / 64) * (Co / 64));
+      const unsigned nblk = (unsigned)(gx * K * (Ci / 64) * (Co / 64));
       if (g_conv_dbg == 100)  // A/B: 32 pairs per step
-        k_dw_tile<2, 2, 32><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk, in_bytes, do_bytes);
+        k_dw_tile<2, 2, 32><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+      else if (g_conv_dbg == 101)
+        k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col + 2, Ci, Co, gx, in_bytes, do_bytes, -K);
       else
-        k_dw_tile<2, 2, 64><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk, in_bytes, do_bytes);
+        k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
     } else {
-      dim3 grid(gx, K, (Ci / 32) * (Co / 32));
-      k_dw_tile<1, 1, 64><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk, in_bytes, do_bytes);
+      const unsigned nblk = (unsigned)(gx * K * (Ci / 32) * (Co / 32));
+      k_dw_tile<1, 1, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
     }
     SCN_CHECK_LAUNCH();
     return 0;
