@@ -148,7 +148,9 @@ int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream
  * Replaces cuda_BatchNormalization_updateOutput / _backward
  * (sparseconvnet/SCN/CUDA/BatchNormalization.cpp:21-76, kernels sparseconvnet/SCN/CUDA/BatchNormalization.cu:14-199);
  * arithmetic of sparseconvnet/SCN/CPU/BatchNormalization.cpp:12-107.  weight/bias/d_weight/d_bias may be NULL.
- * temp: scn_bn_temp_bytes(C) bytes.  Backward rewrites d_out in place (BatchNormalization.cu:151-153). */
+ * temp: scn_bn_temp_bytes(C) bytes.  Backward with rewrite_d_out = 1 rewrites d_out in place with the gradient
+ * masked by the (leaky) ReLU, as the reference does (BatchNormalization.cu:151-153); with 0 d_out is left untouched
+ * and the masked gradient is staged in d_x instead (same traffic, and an autograd caller needs no private copy). */
 size_t scn_bn_temp_bytes(int C);
 int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invstd,
                    float *running_mean, float *running_var, const float *weight,
@@ -157,7 +159,7 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
                     const float *save_mean, const float *save_invstd, const float *weight,
                     float *d_weight, float *d_bias, double leakiness, int64_t N, int C,
-                    void *temp, void *stream);
+                    int rewrite_d_out, void *temp, void *stream);
 
 /* ------------------------------------------------------ input / output ---
  * Replaces InputLayer_fp/bp (sparseconvnet/SCN/CUDA/IOLayers.cu:17-76) and the four wrappers of

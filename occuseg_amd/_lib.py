@@ -39,7 +39,7 @@ SIGNATURES = {
     "scn_bn_temp_bytes": (c_size_t, [c_int]),
     "scn_bn_forward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_int, c_double,
                                c_int64, c_int, _P, _P]),
-    "scn_bn_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, _P, _P]),
+    "scn_bn_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P]),
     "scn_input_forward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_input_backward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_output_forward": (c_int, [_P, _P, _P, c_int64, c_int, _P]),

@@ -147,12 +147,12 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// backward pass 1: mask d_out in place, reduce sum(d) and sum((x-mean) d)
-// (sparseconvnet/SCN/CPU/BatchNormalization.cpp:75-87)
+// backward pass 1: masked gradient -> d_masked (d_out itself = the reference's in-place rewrite, or d_x),
+// reduce sum(d) and sum((x-mean) d)   (sparseconvnet/SCN/CPU/BatchNormalization.cpp:75-87)
 template <int VEC>
 __global__ void __launch_bounds__(256)
-    k_bn_bwd_stats(const float *x, const float *y, float *d_out, const float *save_mean, int64_t N,
-                   int C, float leak, float *partial) {
+    k_bn_bwd_stats(const float *x, const float *y, const float *d_out, float *d_masked, const float *save_mean,
+                   int64_t N, int C, float leak, float *partial) {
   bn_reduce_rows<VEC>(N, C, partial, [&](int64_t r, int c, float *a, float *b) {
     const int64_t o = r * C + c;
     if (VEC == 4) {
@@ -162,13 +162,13 @@ __global__ void __launch_bounds__(256)
       const float4 m = *(const float4 *)(save_mean + c);
       d.x *= yv.x > 0 ? 1.f : leak; d.y *= yv.y > 0 ? 1.f : leak;
       d.z *= yv.z > 0 ? 1.f : leak; d.w *= yv.w > 0 ? 1.f : leak;
-      *(float4 *)(d_out + o) = d;
+      *(float4 *)(d_masked + o) = d;
       a[0] += d.x; a[1 % VEC] += d.y; a[2 % VEC] += d.z; a[3 % VEC] += d.w;
       b[0] += (xv.x - m.x) * d.x; b[1 % VEC] += (xv.y - m.y) * d.y;
       b[2 % VEC] += (xv.z - m.z) * d.z; b[3 % VEC] += (xv.w - m.w) * d.w;
     } else {
       float d = d_out[o] * (y[o] > 0 ? 1.f : leak);
-      d_out[o] = d;
+      d_masked[o] = d;
       a[0] += d;
       b[0] += (x[o] - save_mean[c]) * d;
     }
@@ -350,7 +350,7 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
                     const float *save_mean, const float *save_invstd, const float *weight,
                     float *d_weight, float *d_bias, double leakiness, int64_t N, int C,
-                    void *temp, void *stream_) {
+                    int rewrite_d_out, void *temp, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(C > 0 && N > 0, "scn_bn_backward: bad shape");
   float *partial = (float *)temp;
@@ -359,15 +359,16 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
   const bool v4 = (C % 4) == 0;
   const int cg = v4 ? C / 4 : C;
   dim3 grid(nblk, (cg + 255) / 256);
-  if (v4) k_bn_bwd_stats<4><<<grid, 256, 0, stream>>>(x, y, d_out, save_mean, N, C, (float)leakiness, partial);
-  else k_bn_bwd_stats<1><<<grid, 256, 0, stream>>>(x, y, d_out, save_mean, N, C, (float)leakiness, partial);
+  float *d_masked = rewrite_d_out ? d_out : d_x;  // pass 2 reads element i of it before writing element i of d_x
+  if (v4) k_bn_bwd_stats<4><<<grid, 256, 0, stream>>>(x, y, d_out, d_masked, save_mean, N, C, (float)leakiness, partial);
+  else k_bn_bwd_stats<1><<<grid, 256, 0, stream>>>(x, y, d_out, d_masked, save_mean, N, C, (float)leakiness, partial);
   SCN_CHECK_LAUNCH();
   k_bn_bwd_finalize<<<(C + 15) / 16, 256, 0, stream>>>(partial, nblk, N, C, save_invstd, weight,
                                                         d_weight, d_bias, coef);
   SCN_CHECK_LAUNCH();
   const int64_t total = N * C;
-  if (v4) k_bn_bwd_apply<4><<<grid_for(total / 4), 256, 0, stream>>>(x, d_out, d_x, save_mean, total / 4, C, coef);
-  else k_bn_bwd_apply<1><<<grid_for(total), 256, 0, stream>>>(x, d_out, d_x, save_mean, total, C, coef);
+  if (v4) k_bn_bwd_apply<4><<<grid_for(total / 4), 256, 0, stream>>>(x, d_masked, d_x, save_mean, total / 4, C, coef);
+  else k_bn_bwd_apply<1><<<grid_for(total), 256, 0, stream>>>(x, d_masked, d_x, save_mean, total, C, coef);
   SCN_CHECK_LAUNCH();
   return 0;
 }

@@ -39,6 +39,17 @@ class FlatGradBucket(object):
         self._work = []
         self._hooks = []
         self._launched = set()
+        self._first_of = {}
+        # this object owns the (zeroed) gradient buffers: let the convolutions accumulate dWeight straight into them
+        from .sparseconvnet import conv as _conv
+        _conv.ACCUMULATE_INTO_GRAD = True
+        _conv.GRAD_WRITTEN = self._grad_written
+
+    def _grad_written(self, param):
+        """a convolution accumulated its weight gradient directly (no autograd hook fires for it)"""
+        b = self._first_of.get(id(param))
+        if b is not None:
+            self._launch(b)
 
     def _distributed(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -52,6 +63,7 @@ class FlatGradBucket(object):
             def hook(_param, b=b):
                 self._launch(b)
             self._hooks.append(self.params[first].register_post_accumulate_grad_hook(hook))
+            self._first_of[id(self.params[first])] = b
 
     def _launch(self, b):
         if b in self._launched or not self._distributed():

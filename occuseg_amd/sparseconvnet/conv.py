@@ -15,6 +15,12 @@ from . import counters
 from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTensorReturn, toLongTensor
 
 
+# Opt-in "fused weight-gradient accumulation" (see _RuleConvFunction.backward): set by the owner of the .grad
+# buffers; only valid when gradients are consumed through .grad (loss.backward()), not through torch.autograd.grad.
+ACCUMULATE_INTO_GRAD = False
+GRAD_WRITTEN = None  # optional callback(param) fired after a gradient was accumulated directly
+
+
 class _RuleConvFunction(Function):
     """kind: 'submanifold' | 'conv' | 'deconv'"""
 
@@ -44,7 +50,11 @@ class _RuleConvFunction(Function):
         grad_output = grad_output.contiguous()
         # the reference always computes dInput; it is skipped here when autograd does not ask for it
         grad_input = like_empty(grad_output) if ctx.needs_input_grad[0] else None
-        grad_weight = torch.zeros_like(weight)
+        # The dWeight kernel ACCUMULATES (float atomics into a zeroed buffer, as the reference's does).  When the
+        # owner of the gradients says so (occuseg_amd.dp.FlatGradBucket: .grad are views of one zeroed flat buffer)
+        # it accumulates straight into weight.grad: no zeros_like, no autograd add kernel per parameter.
+        direct = ACCUMULATE_INTO_GRAD and weight.grad is not None and weight.grad.is_contiguous()
+        grad_weight = weight.grad if direct else torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
         m = ctx.scn_meta
         if ctx.kind == "submanifold":
@@ -57,6 +67,10 @@ class _RuleConvFunction(Function):
             SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
                                        grad_output, weight, grad_weight, grad_bias)
         ctx.scn_meta = None
+        if direct:
+            if GRAD_WRITTEN is not None:
+                GRAD_WRITTEN(weight)
+            grad_weight = None
         return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7
 
 

@@ -29,15 +29,16 @@ class _BatchNormFunction(Function):
     def backward(ctx, grad_output):
         features, out, weight, bias, running_mean, running_var, save_mean, save_invstd = ctx.saved_tensors
         assert ctx.train
-        # the backend rewrites d_out in place (sparseconvnet/SCN/CUDA/BatchNormalization.cu:151-153):
-        # hand it a private contiguous copy so that autograd's buffer is never mutated
-        grad_output = grad_output.contiguous().clone()
+        # the reference backend rewrites d_out in place (sparseconvnet/SCN/CUDA/BatchNormalization.cu:151-153), and
+        # autograd's buffer must never be mutated: ask the backend to stage the masked gradient in grad_input
+        # instead (same traffic, no private copy of grad_output)
+        grad_output = grad_output.contiguous()
         grad_input = like_empty(grad_output)
         grad_weight = torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
         SCN.BatchNormalization_backward(features, grad_input, out, grad_output, save_mean, save_invstd,
                                         running_mean, running_var, weight, bias, grad_weight, grad_bias,
-                                        ctx.leakiness)
+                                        ctx.leakiness, _rewrite_d_output=False)
         return (grad_input, optionalTensorReturn(grad_weight), optionalTensorReturn(grad_bias)) + (None,) * 6
 
 

@@ -133,6 +133,13 @@ def test_batchnorm(gpu, n, c, leak):
             assert_close(gb.cpu().numpy(), d_b, "bn dBias")
             # the reference contract: d_output_features is rewritten in place (BatchNormalization.cu:151-153)
             assert_close(dyt.cpu().numpy(), d_masked, "bn masked dOut written back")
+            # the autograd module's mode: same results, d_output_features untouched
+            dyt2, gi2 = _t(dy, gpu), torch.empty(0, device=gpu)
+            gg2, gb2 = torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
+            SCN.BatchNormalization_backward(_t(x, gpu), gi2, out, dyt2, sm, si, rmt, rvt, _t(g, gpu), _t(b, gpu),
+                                            gg2, gb2, leak, _rewrite_d_output=False)
+            assert torch.equal(gi2, gi) and torch.equal(gg2, gg) and torch.equal(gb2, gb)
+            assert np.array_equal(dyt2.cpu().numpy(), dy)
 
 
 def test_batchnorm_no_affine(gpu):

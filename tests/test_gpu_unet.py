@@ -9,6 +9,15 @@ from helpers import assert_close
 pytestmark = pytest.mark.gpu
 
 
+def _deterministic_forward(on):
+    """Launches with few output tiles split the kernel offsets over workgroups and combine them with float atomics:
+    two forward passes then differ in the last bit, and once in ~50 runs that flips the ReLU mask of an element with
+    y ~ 0 at a coarse level, which moves every gradient upstream of it by up to a few per cent (measured with
+    tools: identical values each time it happens).  Tests that compare two RUNS switch that path off."""
+    from occuseg_amd import _lib
+    _lib.load().scn_set_tuning(3, 1 if on else 0)
+
+
 def _net(scn, m, levels, leak):
     planes = [m * (i + 1) for i in range(levels)]
     return scn.Sequential().add(scn.InputLayer(3, 4096, mode=4)).add(
@@ -60,6 +69,7 @@ def test_rulebook_prefetch_is_equivalent(gpu):
     import occuseg_amd
     from occuseg_amd import SCN, scenes
     scn = occuseg_amd.install()
+    _deterministic_forward(True)
     torch.manual_seed(3)
     net = _net(scn, 16, 3, 0.0).to(gpu)
     inp = next(mod for mod in net.modules() if isinstance(mod, scn.InputLayer))
@@ -88,16 +98,52 @@ def test_rulebook_prefetch_is_equivalent(gpu):
         piped.append(res)
     torch.cuda.synchronize()
     for (o0, g0), (o1, g1) in zip(plain, piped):
-        # small levels split the offsets over workgroups and dWeight accumulates with float atomics: tolerance
-        assert_close(o1.cpu().numpy(), o0.cpu().numpy(), "prefetch output", rel=1e-5)
+        assert torch.equal(o0, o1)  # the forward pass is deterministic here (see _deterministic_forward)
+        # dWeight accumulates with float atomics: two runs differ by summation order
         for a, b in zip(g0, g1):
-            assert_close(b.cpu().numpy(), a.cpu().numpy(), "prefetch grads", rel=1e-5)
+            assert_close(b.cpu().numpy(), a.cpu().numpy(), "prefetch grads", rel=1e-4)
     # a prefetch for another tensor object is ignored, and dropped by the next prefetch
     inp.prefetch(batches[0])
     clone = [batches[0][0].clone()] + batches[0][1:]
     o, _ = run(clone)
-    assert_close(o.cpu().numpy(), plain[0][0].cpu().numpy(), "no adoption", rel=1e-5)
+    assert torch.equal(o, plain[0][0])
     assert id(batches[0][0]) in SCN._PREFETCHED
     inp.prefetch(batches[1])
     assert list(SCN._PREFETCHED) == [id(batches[1][0])]
     SCN._PREFETCHED.clear()
+    _deterministic_forward(False)
+
+
+def test_direct_weight_gradient_accumulation(gpu):
+    """FlatGradBucket lets the convolutions accumulate dWeight straight into the flat gradient buffer
+    (no zeros_like + autograd add per parameter): same gradients as the plain autograd path, twice in a row
+    (accumulation over two backward passes included)."""
+    import occuseg_amd
+    from occuseg_amd import dp, scenes
+    from occuseg_amd.sparseconvnet import conv as conv_mod
+    scn = occuseg_amd.install()
+    _deterministic_forward(True)
+    torch.manual_seed(5)
+    net = _net(scn, 16, 3, 0.0).to(gpu)
+    coords, feats = scenes.batch([1000, 1001], target_sites=6000)
+    batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
+    assert not conv_mod.ACCUMULATE_INTO_GRAD
+    for p in net.parameters():
+        p.grad = None
+    net(batch).sum().backward()
+    net(batch).sum().backward()  # accumulate a second time
+    plain = [p.grad.clone() for p in net.parameters()]
+    try:
+        bucket = dp.FlatGradBucket(net.parameters())
+        assert conv_mod.ACCUMULATE_INTO_GRAD
+        bucket.zero()
+        net(batch).sum().backward()
+        net(batch).sum().backward()
+        bucket.all_reduce_mean()  # single process: no-op
+        for p, ref in zip(net.parameters(), plain):
+            assert p.grad.data_ptr() >= bucket.flat.data_ptr()  # still a view of the flat buffer
+            assert_close(p.grad.cpu().numpy(), ref.cpu().numpy(), "direct dW accumulation", rel=1e-4)
+    finally:
+        conv_mod.ACCUMULATE_INTO_GRAD = False
+        conv_mod.GRAD_WRITTEN = None
+        _deterministic_forward(False)
