@@ -784,13 +784,19 @@ __global__ void __launch_bounds__(128)
         if (j == 0) {         // row offsets / output rows of pass p+2; weight-load scalars of pass p+1
           addr(E2, pr, off, o2r);
           rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
-          weight_scalars(E1, w_so, w_off, w_new);
-        } else if (j == 1) {  // weights of pass p+1
-          load_weights(0, w_off, w_so[0], wn);
-          load_weights(1, w_off, w_so[1], wn);
+          w_new = (E1.meta >> 20) & 1u;
+        } else if (j == 1) {  // weights of pass p+1, only when it starts a new (offset, chunk) phase: they are OLDER than
+                              // the row loads below, so the vmcnt(8) at the end of the pass is right either way
+          if (w_new) {
+            weight_scalars(E1, w_so, w_off, w_new);
+            load_weights(0, w_off, w_so[0], wn);
+            load_weights(1, w_off, w_so[1], wn);
+          }
         } else if (j == 2) {
-          load_weights(2, w_off, w_so[2], wn);
-          load_weights(3, w_off, w_so[3], wn);
+          if (w_new) {
+            load_weights(2, w_off, w_so[2], wn);
+            load_weights(3, w_off, w_so[3], wn);
+          }
           tile_rows(old, op);
         } else if (j == 3) {  // indices of pass p+3 (pr was consumed in slot 0)
           load_idx(E3, ioff, pr);
@@ -1203,8 +1209,6 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 1: SCN_LAUNCH_TILE4(1); break;     // no scatter
     case 2: SCN_LAUNCH_TILE4(3); break;     // + no gather
     case 8: SCN_LAUNCH_TILE4(11); break;    // + no weights: loop skeleton + MFMAs
-    case 16: SCN_LAUNCH_TILE4(27); break;   // skeleton without MFMAs
-    case 17: SCN_LAUNCH_TILE4(16); break;   // everything but the MFMAs
     case 256: SCN_LAUNCH_TILE4(256); break;  // stamps
     default: SCN_LAUNCH_TILE4(0);
   }
