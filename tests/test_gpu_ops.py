@@ -55,12 +55,15 @@ def test_submanifold_fwd_bwd(gpu, ci, co):
     assert_close(gb.cpu().numpy(), d_b, "submanifold dBias")
 
 
-@pytest.mark.parametrize("ci,co", [(16, 32), (64, 128), (96, 64), (32, 48), (3, 8), (128, 192)])
-def test_conv_deconv_fwd_bwd(gpu, ci, co):
+# the last two run on a grid large enough (>= 512 output tiles on both scales) for the two-wave kernel k_conv_tile4
+@pytest.mark.parametrize("ci,co,big", [(16, 32, 0), (64, 128, 0), (96, 64, 0), (32, 48, 0), (3, 8, 0), (128, 192, 0),
+                                       (64, 64, 1), (64, 128, 1)])
+def test_conv_deconv_fwd_bwd(gpu, ci, co, big):
     from occuseg_amd import SCN
     from oracle import arith as A, rules as R
-    m, size, grid, _, _ = _setup(gpu, seed=1)
+    m, size, grid, _, _ = _setup(gpu, seed=1, n=100000, batch=2, extent=70) if big else _setup(gpu, seed=1)
     coarse, rules, _ = R.strided_rules(grid)
+    assert not big or coarse.n >= 512 * 128
     out_size = size // 2
     rng = np.random.default_rng(ci + co)
     x = rng.normal(size=(grid.n, ci)).astype(np.float32)
@@ -244,3 +247,11 @@ def test_submanifold_forward_variants(gpu, ci, co):
     assert_close(outs[2], want, "variant 2 forward %d->%d" % (ci, co))
     # same per-(offset, chunk) summation order in both kernels: bit-identical
     assert np.array_equal(outs[4], outs[2])
+    # dInput (transposed weights, offsets reversed) through the default kernel
+    if ci <= 128:
+        dy = rng.normal(size=(grid.n, co)).astype(np.float32)
+        d_in, d_w, _ = A.conv_backward(x, dy, w, rules, dtype=np.float64)
+        gi, gw, gb = torch.empty(0, device=gpu), torch.zeros(27, ci, co, device=gpu), torch.zeros(co, device=gpu)
+        SCN.SubmanifoldConvolution_backward(size, F3, m, _t(x, gpu), gi, _t(dy, gpu), _t(w, gpu), gw, gb, 1)
+        assert_close(gi.cpu().numpy(), d_in, "large submanifold dInput")
+        assert_close(gw.cpu().numpy(), d_w, "large submanifold dWeight")
