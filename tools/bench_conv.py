@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--sites", type=int, default=150000)
     ap.add_argument("--m", type=int, default=64)
     ap.add_argument("--dw", action="store_true")
+    ap.add_argument("--dw-variants", default="101,0,101,0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -59,7 +60,7 @@ def main():
                     lib.scn_set_tuning(2, int(v) // 10000)
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                     line += "  v%s %.3f ms %.1f TF" % (v, ms, flops / ms / 1e9)
-                for dv in ([101, 0, 101, 0] if args.dw else []):
+                for dv in ([int(v) for v in args.dw_variants.split(',')] if args.dw else []):
                     lib.scn_set_tuning(1, dv)
                     dy = torch.randn(n, co, device=dev)
                     dw = torch.zeros_like(w)
