@@ -148,9 +148,12 @@ int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream
  * Replaces cuda_BatchNormalization_updateOutput / _backward
  * (sparseconvnet/SCN/CUDA/BatchNormalization.cpp:21-76, kernels sparseconvnet/SCN/CUDA/BatchNormalization.cu:14-199);
  * arithmetic of sparseconvnet/SCN/CPU/BatchNormalization.cpp:12-107.  weight/bias/d_weight/d_bias may be NULL.
- * temp: scn_bn_temp_bytes(C) bytes.  Backward with rewrite_d_out = 1 rewrites d_out in place with the gradient
- * masked by the (leaky) ReLU, as the reference does (BatchNormalization.cu:151-153); with 0 d_out is left untouched
- * and the masked gradient is staged in d_x instead (same traffic, and an autograd caller needs no private copy). */
+ * temp: scn_bn_temp_bytes(C) bytes.  Backward flags: bit 0 (SCN_BN_REWRITE_D_OUT) = rewrite d_out in place with the
+ * gradient masked by the (leaky) ReLU, as the reference does (BatchNormalization.cu:151-153); without it d_out is left
+ * untouched and the masked gradient is staged in d_x instead (same traffic, and an autograd caller needs no private
+ * copy).  Bit 1 (SCN_BN_ACCUMULATE_DPARAMS) = d_weight / d_bias += instead of = (the reference assigns). */
+#define SCN_BN_REWRITE_D_OUT 1
+#define SCN_BN_ACCUMULATE_DPARAMS 2
 size_t scn_bn_temp_bytes(int C);
 int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invstd,
                    float *running_mean, float *running_var, const float *weight,
@@ -159,7 +162,7 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
                     const float *save_mean, const float *save_invstd, const float *weight,
                     float *d_weight, float *d_bias, double leakiness, int64_t N, int C,
-                    int rewrite_d_out, void *temp, void *stream);
+                    int flags, void *temp, void *stream);
 
 /* ------------------------------------------------------ input / output ---
  * Replaces InputLayer_fp/bp (sparseconvnet/SCN/CUDA/IOLayers.cu:17-76) and the four wrappers of

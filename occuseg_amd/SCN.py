@@ -543,11 +543,12 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
 
 def BatchNormalization_backward(input_features, d_input_features, output_features, d_output_features, saveMean,
                                 saveInvStd, runningMean, runningVar, weight, bias, d_weight, d_bias, leakiness,
-                                _rewrite_d_output=True):
+                                _rewrite_d_output=True, _accumulate=False):
     """sparseconvnet/SCN/sparseconvnet.h:27-32 -> sparseconvnet/SCN/CUDA/BatchNormalization.cpp:45-76.
     d_output_features must be contiguous: it is rewritten in place
     (sparseconvnet/SCN/CUDA/BatchNormalization.cu:151-153).  ``_rewrite_d_output=False`` (not in the reference;
-    used by the autograd module, which must not mutate autograd's buffer) leaves it untouched."""
+    used by the autograd module, which must not mutate autograd's buffer) leaves it untouched; ``_accumulate=True``
+    adds to d_weight / d_bias instead of assigning."""
     _need_cuda(d_output_features, "BatchNormalization_backward")
     assert d_output_features.is_contiguous()
     x = input_features.contiguous()
@@ -556,7 +557,8 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     temp = _bn_temp(C, x.device)
     check(_lib_().scn_bn_backward(ptr(x), ptr(d_input_features), ptr(output_features), ptr(d_output_features),
                                   ptr(saveMean), ptr(saveInvStd), ptr(weight), ptr(d_weight), ptr(d_bias),
-                                  float(leakiness), N, C, int(bool(_rewrite_d_output)), ptr(temp), stream()))
+                                  float(leakiness), N, C, int(bool(_rewrite_d_output)) | (2 if _accumulate else 0), ptr(temp),
+                                  stream()))
 
 
 _IDENTITY_RB = {}  # (n, device index) -> _RuleBook with the single list {(i, i)}; tiny LRU

@@ -178,13 +178,13 @@ __global__ void __launch_bounds__(256)
 // (sparseconvnet/SCN/CPU/BatchNormalization.cpp:88-93,:103-106); coef = [gradMean | k | invstd*gamma]
 __global__ void __launch_bounds__(256)
     k_bn_bwd_finalize(const float *partial, int nblk, int64_t N, int C, const float *save_invstd,
-                      const float *weight, float *d_weight, float *d_bias, float *coef) {
+                      const float *weight, float *d_weight, float *d_bias, float *coef, int accumulate) {
   int c;
   double s = 0, dp = 0;
   if (!bn_sum_partials(partial, nblk, C, c, s, dp)) return;
   const float invstd = save_invstd[c];
-  if (d_bias) d_bias[c] = (float)s;
-  if (d_weight) d_weight[c] = (float)(dp * (double)invstd);
+  if (d_bias) d_bias[c] = (accumulate ? d_bias[c] : 0.f) + (float)s;
+  if (d_weight) d_weight[c] = (accumulate ? d_weight[c] : 0.f) + (float)(dp * (double)invstd);
   coef[c] = (float)(s / (double)N);
   coef[C + c] = (float)(dp * (double)invstd * (double)invstd / (double)N);
   coef[2 * C + c] = invstd * (weight ? weight[c] : 1.f);
@@ -350,7 +350,8 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
                     const float *save_mean, const float *save_invstd, const float *weight,
                     float *d_weight, float *d_bias, double leakiness, int64_t N, int C,
-                    int rewrite_d_out, void *temp, void *stream_) {
+                    int flags, void *temp, void *stream_) {
+  const int rewrite_d_out = flags & 1, accumulate = (flags >> 1) & 1;
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(C > 0 && N > 0, "scn_bn_backward: bad shape");
   float *partial = (float *)temp;
@@ -364,7 +365,7 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
   else k_bn_bwd_stats<1><<<grid, 256, 0, stream>>>(x, y, d_out, d_masked, save_mean, N, C, (float)leakiness, partial);
   SCN_CHECK_LAUNCH();
   k_bn_bwd_finalize<<<(C + 15) / 16, 256, 0, stream>>>(partial, nblk, N, C, save_invstd, weight,
-                                                        d_weight, d_bias, coef);
+                                                        d_weight, d_bias, coef, accumulate);
   SCN_CHECK_LAUNCH();
   const int64_t total = N * C;
   if (v4) k_bn_bwd_apply<4><<<grid_for(total / 4), 256, 0, stream>>>(x, d_masked, d_x, save_mean, total / 4, C, coef);

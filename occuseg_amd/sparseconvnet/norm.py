@@ -10,6 +10,7 @@ from torch.autograd import Function
 from torch.nn import Module, Parameter
 
 from .. import SCN
+from . import conv
 from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTensorReturn
 
 
@@ -34,11 +35,19 @@ class _BatchNormFunction(Function):
         # instead (same traffic, no private copy of grad_output)
         grad_output = grad_output.contiguous()
         grad_input = like_empty(grad_output)
-        grad_weight = torch.zeros_like(weight)
-        grad_bias = torch.zeros_like(bias)
+        # fused parameter-gradient accumulation, as in conv.py (the owner of the .grad buffers opts in)
+        direct = (conv.ACCUMULATE_INTO_GRAD and weight.numel() > 0 and bias.numel() > 0
+                  and weight.grad is not None and bias.grad is not None)
+        grad_weight = weight.grad if direct else torch.zeros_like(weight)
+        grad_bias = bias.grad if direct else torch.zeros_like(bias)
         SCN.BatchNormalization_backward(features, grad_input, out, grad_output, save_mean, save_invstd,
                                         running_mean, running_var, weight, bias, grad_weight, grad_bias,
-                                        ctx.leakiness, _rewrite_d_output=False)
+                                        ctx.leakiness, _rewrite_d_output=False, _accumulate=direct)
+        if direct:
+            if conv.GRAD_WRITTEN is not None:
+                conv.GRAD_WRITTEN(weight)
+                conv.GRAD_WRITTEN(bias)
+            return (grad_input, None, None) + (None,) * 6
         return (grad_input, optionalTensorReturn(grad_weight), optionalTensorReturn(grad_bias)) + (None,) * 6
 
 
