@@ -1135,6 +1135,9 @@ __global__ void __launch_bounds__(256)
 using namespace scn;
 
 static int g_conv_dbg = 0;
+static int g_conv_small_policy = 1500;  // tuning key 4: launches with few tiles keep the 128 x 64 tile and split their
+                                        // offsets until there are this many workgroups (0 = the older rule, for A/B:
+                                        // 64 x 32 tiles first); +16-22 % on the three coarsest UNet levels
 static int g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile, never split offsets (A/B runs)
 static int g_conv_variant = 4;  // 1 = first synchronous kernel (kept for A/B runs), 2 = LDS-staged pipelined kernel for
                                 // every shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
@@ -1163,8 +1166,9 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   // coarse UNet levels: too few tiles to fill 256 CUs and every workgroup walks all K offsets one
   // after the other -> split the offsets over up to 27 workgroups per tile and combine with atomics
   int ksplit = 1;
+  const int64_t target = (g_conv_small_policy >= 1 && NW == 4) ? g_conv_small_policy : 4096;
   if (!g_conv_small_off && K > 1 && (NW < 4 || (int64_t)ntiles * ncb < 512))
-    while (ksplit < 27 && (int64_t)ntiles * ncb * ksplit < 4096) ksplit *= 3;
+    while (ksplit < 27 && (int64_t)ntiles * ncb * ksplit < target) ksplit *= 3;
   if (ksplit > K) ksplit = K;
   if (ksplit > 1) SCN_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)n_out * Co * sizeof(float), stream));
   const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
@@ -1251,6 +1255,10 @@ int scn_set_tuning(int key, int value) {
     g_conv_wide = value;
     return 0;
   }
+  if (key == 4) {
+    g_conv_small_policy = value;
+    return 0;
+  }
   if (key == 3) {
     g_conv_small_off = value;
     return 0;
@@ -1296,7 +1304,7 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     if (g_conv_variant == 4 && s16 % 4 == 0 && Ci % 64 == 0 && Ci / 64 <= SCN_TILE4_MAX_CHUNKS && blocks(4) >= want && n_in < (1 << 24) &&
         (int64_t)K * stride * 8 < (int64_t)0x7fffffff)
       return launch_tile4(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
-    if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off))
+    if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off || (g_conv_small_policy >= 1 && blocks(4) >= 8)))
       return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
     if (s16 % 3 == 0 && s16 % 2 != 0)
       return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);

@@ -57,7 +57,8 @@ def main():
                 for v in args.variants.split(","):
                     lib.scn_set_tuning(0, int(v) % 10)
                     lib.scn_set_tuning(1, (int(v) // 10) % 1000)
-                    lib.scn_set_tuning(2, int(v) // 10000)
+                    lib.scn_set_tuning(2, (int(v) // 10000) % 10)
+                    lib.scn_set_tuning(4, int(v) // 100000)
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                     line += "  v%s %.3f ms %.1f TF" % (v, ms, flops / ms / 1e9)
                 for dv in ([int(v) for v in args.dw_variants.split(',')] if args.dw else []):
