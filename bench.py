@@ -115,7 +115,8 @@ def main():
     bucket = dp.FlatGradBucket(net.parameters())
     if world > 1:
         bucket.enable_overlap()  # bucketed all-reduce launched from backward hooks
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    # torch's fused Adam kernel (same arithmetic as the default foreach implementation: 53.5 -> 51.9 ms per step)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=bool(int(os.environ.get("SCN_BENCH_FUSED_ADAM", "1"))))
 
     all_seeds = [1000 + i for i in range(args.scenes_per_gpu * world)]
     seeds = dp.shard(all_seeds, rank, world)

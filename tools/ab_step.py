@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = bench.build_net(scn, 64).to(dev)
 bucket = dp.FlatGradBucket(net.parameters())
-opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
 coords, feats = scenes.batch([1000, 1001, 1002, 1003], 150000)
 batch_in = [torch.from_numpy(coords).to(dev), torch.from_numpy(feats).to(dev), None, 4]
 
