@@ -1100,6 +1100,46 @@ __global__ void __launch_bounds__(256)
       }
 }
 
+// dW for narrow inputs (the 3 -> m stem, Ci <= 4): thread = one output plane, wave = every fourth pair of the chunk;
+// the pair and the Ci input values are wave-uniform, only the dOut row is a vector load
+template <int CI>
+__global__ void __launch_bounds__(256)
+    k_dw_narrow(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+                const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
+                int in_col, int Co, int chunk) {
+  const int k = blockIdx.y;
+  const int count = counts[k];
+  const int p0 = blockIdx.x * chunk;
+  if (p0 >= count) return;
+  const int p1 = min(count, p0 + chunk);
+  const int2 *rk = rules + (int64_t)k * stride;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int co = lane; co < Co; co += 64) {
+    float acc[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[c] = 0.f;
+    for (int p = p0 + w; p < p1; p += 16) {  // 4 independent pair -> row chains in flight per wave
+      int2 pr[4];
+      float d[4], x[4][CI];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pr[u] = rk[min(p + 4 * u, p1 - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *ip = in + (int64_t)(in_col ? pr[u].y : pr[u].x) * CI;
+#pragma unroll
+        for (int c = 0; c < CI; ++c) x[u][c] = ip[c];
+        d[u] = (p + 4 * u < p1) ? dout[(int64_t)(in_col ? pr[u].x : pr[u].y) * Co + co] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < CI; ++c) acc[c] += x[u][c] * d[u];
+    }
+#pragma unroll
+    for (int c = 0; c < CI; ++c) unsafeAtomicAdd(dW + ((int64_t)k * CI + c) * Co + co, acc[c]);
+  }
+}
+
 // generic dW (any Ci, Co): block = (pair chunk, k); threads stride over (ci, co)
 __global__ void __launch_bounds__(256)
     k_dw_generic(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
@@ -1353,6 +1393,18 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     } else {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 32) * (Co / 32));
       k_dw_tile<1, 1, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+    }
+    SCN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (Ci >= 1 && Ci <= 4) {
+    const int chunk = 2048;
+    dim3 grid((unsigned)((stride + chunk - 1) / chunk), K);
+    switch (Ci) {
+      case 1: k_dw_narrow<1><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
+      case 2: k_dw_narrow<2><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
+      case 3: k_dw_narrow<3><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
+      default: k_dw_narrow<4><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Co, chunk);
     }
     SCN_CHECK_LAUNCH();
     return 0;
