@@ -935,6 +935,31 @@ __global__ void __launch_bounds__(256)
   float acc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = (bias && cb + cg + c < Co) ? bias[cb + cg + c] : 0.f;
+  if (W_IN_LDS && Ci <= 4) {
+    // narrow inputs (the stem): the inputs of three offsets are fetched before their FMAs -- one dependent
+    // LDS -> global chain per offset made this loop pure latency
+    for (int k0 = 0; k0 < K; k0 += 3) {
+      float xs[3][4];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = k0 + u < K ? src[k0 + u][r] : -1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs[u][c] = (i >= 0 && c < Ci) ? in[(int64_t)i * Ci + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (k0 + u < K)
+#pragma unroll
+          for (int ci = 0; ci < 4; ++ci)
+            if (ci < Ci) {
+              const float x = xs[u][ci];
+              const float4 w0 = *(const float4 *)(wl + ((k0 + u) * Ci + ci) * 64 + cg);
+              const float4 w1 = *(const float4 *)(wl + ((k0 + u) * Ci + ci) * 64 + cg + 4);
+              acc[0] += x * w0.x; acc[1] += x * w0.y; acc[2] += x * w0.z; acc[3] += x * w0.w;
+              acc[4] += x * w1.x; acc[5] += x * w1.y; acc[6] += x * w1.z; acc[7] += x * w1.w;
+            }
+    }
+  } else
   for (int k = 0; k < K; ++k) {
     const int i = src[k][r];
     if (i < 0) continue;
