@@ -54,16 +54,19 @@ size_t scn_grid_build_temp_bytes(int64_t P);
  *   site_of_row [P] i32   global site id of each input row  (`_d_hash_idx`)
  *   site_start  [P+1] i32 first sorted position of each site; site_start[N] = P
  *   n_sites_host          N, written after ONE stream synchronisation
+ * coords_dtype: 0 = int32, 1 = int64, 2 = float32 [P,ncols] as the reference's collate functions produce them
+ * (examples/ScanNet/datasets/scannet.py:254-265), converted like sparseconvnet/ioLayers.py:56 does on the host
+ * (`.type(torch.LongTensor)`: truncation toward zero) -- no int64 copy, no host round trip.
  * error if a coordinate lies outside 0<=x<1024, 0<=y<2048, 0<=z<1024 (the
  * reference silently aliases there, sparseconvnet/SCN/CUDA/CUDPPWrapper.cu:80-81). */
-int scn_grid_build(const void *coords, int coords_are_i64, int ncols, int shift, int64_t P,
+int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
                    void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
                    int32_t *site_of_row, int32_t *site_start, int32_t *n_sites_host,
                    void *stream);
 
 /* site_coords [N,4] i32 = (x,y,z,b) of the first duplicate of each site
  * (sparseconvnet/SCN/CUDA/CUDPPWrapper.cu:224-226), site_keys [N] u64. */
-int scn_grid_finalize(const void *coords, int coords_are_i64, int ncols, int shift, int64_t P,
+int scn_grid_finalize(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
                       int64_t N, const uint64_t *keys_sorted, const int32_t *order,
                       const int32_t *site_start, int32_t *site_coords, uint64_t *site_keys,
                       void *stream);

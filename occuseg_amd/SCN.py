@@ -64,6 +64,7 @@ def _need_cuda(t, what):
 # for the rest of the step.  Purely a scheduling matter: the lazily built result is identical.
 _PLANS = {}
 PREBUILD = True
+_COORD_DTYPES = {torch.int32: 0, torch.int64: 1, torch.float32: 2}  # scn_grid_build coords_dtype
 
 # Grids + rulebooks built AHEAD of the InputLayer call that will use them (prefetch_input below), keyed by the
 # identity of the coordinate tensor.  Pipelining across steps only: what is built is what inputLayer would build.
@@ -132,7 +133,7 @@ class Metadata_3(object):
         self.normal_guide_scale = int(s)
 
     # -- grids ---------------------------------------------------------------
-    def _build_grid(self, coords_dev, is_i64, ncols, shift, P):
+    def _build_grid(self, coords_dev, dtype_code, ncols, shift, P):
         lib = _lib_()
         dev = coords_dev.device
         tb = lib.scn_grid_build_temp_bytes(P)
@@ -142,13 +143,13 @@ class Metadata_3(object):
         site_of_row = torch.empty(P, dtype=torch.int32, device=dev)
         site_start = torch.empty(P + 1, dtype=torch.int32, device=dev)
         n = ctypes.c_int32(0)
-        check(lib.scn_grid_build(ptr(coords_dev), int(is_i64), ncols, shift, P, ptr(temp), tb,
+        check(lib.scn_grid_build(ptr(coords_dev), int(dtype_code), ncols, shift, P, ptr(temp), tb,
                                  ptr(keys_sorted), ptr(order), ptr(site_of_row), ptr(site_start),
                                  ctypes.byref(n), stream()))
         N = int(n.value)
         site_coords = torch.empty((N, 4), dtype=torch.int32, device=dev)
         site_keys = torch.empty(N, dtype=torch.int64, device=dev)
-        check(lib.scn_grid_finalize(ptr(coords_dev), int(is_i64), ncols, shift, P, N, ptr(keys_sorted),
+        check(lib.scn_grid_finalize(ptr(coords_dev), int(dtype_code), ncols, shift, P, N, ptr(keys_sorted),
                                     ptr(order), ptr(site_start), ptr(site_coords), ptr(site_keys),
                                     stream()))
         return _Grid(N, site_coords, site_keys), order, site_of_row, site_start[:N + 1]
@@ -170,7 +171,9 @@ class Metadata_3(object):
             raise NotImplementedError("InputLayer: the reference GPU path supports mode 3 and 4 only "
                                       "(sparseconvnet/SCN/Metadata/IOLayersRules.h:141)")
         assert coords.dim() == 2 and coords.size(1) in (3, 4)
-        assert coords.dtype == torch.int64
+        # int64 as the reference passes them, or int32 / float32 straight from a collate function (converted on
+        # the GPU like the reference's `.type(torch.LongTensor)`, sparseconvnet/ioLayers.py:56)
+        assert coords.dtype in _COORD_DTYPES, coords.dtype
         key = _size_key(spatialSize)
         pre = _PREFETCHED.pop(id(coords), None)
         if pre is not None and pre[0] is coords and pre[1] == (key, int(mode), _norm_device(device)):
@@ -181,7 +184,7 @@ class Metadata_3(object):
         self.inputSpatialSize = key
         c = coords.to(device, non_blocking=True).contiguous()
         P = c.size(0)
-        g, order, site_of_row, site_start = self._build_grid(c, True, c.size(1), 0, P)
+        g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P)
         self.grids[key] = g
         self.nActive[key] = g.n
         self.input_mode = int(mode)
@@ -298,7 +301,7 @@ class Metadata_3(object):
             fine = self.grids[iS]
             dev = fine.coords.device
             Nf = fine.n
-            coarse, _order, coarse_of_fine, _start = self._build_grid(fine.coords, False, 4, 1, Nf)
+            coarse, _order, coarse_of_fine, _start = self._build_grid(fine.coords, 0, 4, 1, Nf)
             self.grids[oS] = coarse
             self.nActive[oS] = coarse.n
             rules = torch.empty((8, Nf, 2), dtype=torch.int32, device=dev)
@@ -347,7 +350,7 @@ def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=Tr
     ``coords`` tensor was produced long ago (otherwise the side stream first waits for the current one, which
     serialises the build behind the queued step)."""
     device = _norm_device(device)
-    assert coords.dtype == torch.int64 and coords.dim() == 2
+    assert coords.dtype in _COORD_DTYPES and coords.dim() == 2
     side = _SIDE_STREAMS.get(device)
     if side is None:
         side = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device, priority=-1)

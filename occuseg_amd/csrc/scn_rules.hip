@@ -14,19 +14,31 @@ namespace scn {
 thread_local char g_err[512] = "";
 
 // ------------------------------------------------------------------ keys ---
-template <bool I64>
+// coordinate element types: 0 = int32, 1 = int64, 2 = float32 (converted like torch's .long(): truncation toward 0)
+template <int DT>
+__device__ __forceinline__ void read_coords(const void *coords_, int64_t p, int ncols, int64_t &x, int64_t &y,
+                                            int64_t &z, int64_t &b) {
+  if (DT == 1) {
+    const int64_t *c = (const int64_t *)coords_ + p * ncols;
+    x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
+  } else if (DT == 0) {
+    const int32_t *c = (const int32_t *)coords_ + p * ncols;
+    x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
+  } else {
+    const float *c = (const float *)coords_ + p * ncols;
+    // NaN / huge values land outside the key box and raise the error flag below
+    auto cv = [](float v) { return (v == v && fabsf(v) < 1e9f) ? (int64_t)v : (int64_t)-1; };
+    x = cv(c[0]); y = cv(c[1]); z = cv(c[2]); b = ncols > 3 ? cv(c[3]) : 0;
+  }
+}
+
+template <int DT>
 __global__ void k_make_keys(const void *coords_, int ncols, int shift, int64_t P,
                             uint64_t *keys, uint32_t *idx, int *err) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
        p += (int64_t)gridDim.x * blockDim.x) {
     int64_t x, y, z, b;
-    if (I64) {
-      const int64_t *c = (const int64_t *)coords_ + p * ncols;
-      x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
-    } else {
-      const int32_t *c = (const int32_t *)coords_ + p * ncols;
-      x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
-    }
+    read_coords<DT>(coords_, p, ncols, x, y, z, b);
     x >>= shift; y >>= shift; z >>= shift;
     if (x < 0 || x >= 1024 || y < 0 || y >= 2048 || z < 0 || z >= 1024 || b < 0 || b >= 65536) {
       atomicOr(err, 1);
@@ -94,7 +106,7 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <bool I64>
+template <int DT>
 __global__ void k_site_coords(const void *coords_, int ncols, int shift, int64_t N,
                               const uint64_t *keys_sorted, const int32_t *order,
                               const int32_t *site_start, int4 *site_coords, uint64_t *site_keys) {
@@ -103,13 +115,7 @@ __global__ void k_site_coords(const void *coords_, int ncols, int shift, int64_t
     const int q = site_start[s];
     const int64_t p = order[q];
     int64_t x, y, z, b;
-    if (I64) {
-      const int64_t *c = (const int64_t *)coords_ + p * ncols;
-      x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
-    } else {
-      const int32_t *c = (const int32_t *)coords_ + p * ncols;
-      x = c[0]; y = c[1]; z = c[2]; b = ncols > 3 ? c[3] : 0;
-    }
+    read_coords<DT>(coords_, p, ncols, x, y, z, b);
     site_coords[s] = make_int4((int)(x >> shift), (int)(y >> shift), (int)(z >> shift), (int)b);
     site_keys[s] = keys_sorted[q];
   }
@@ -349,13 +355,14 @@ size_t scn_grid_build_temp_bytes(int64_t P) {
   return t.total;
 }
 
-int scn_grid_build(const void *coords, int coords_are_i64, int ncols, int shift, int64_t P,
+int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
                    void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
                    int32_t *site_of_row, int32_t *site_start, int32_t *n_sites_host,
                    void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(P > 0 && P < (int64_t)1 << 31, "scn_grid_build: P out of range");
   SCN_REQUIRE(ncols == 3 || ncols == 4, "scn_grid_build: ncols must be 3 or 4");
+  SCN_REQUIRE(coords_dtype >= 0 && coords_dtype <= 2, "scn_grid_build: coords_dtype must be 0 (int32), 1 (int64) or 2 (float32)");
   GridTemp t;
   SCN_REQUIRE(grid_temp_layout(P, t) == 0, "scn_grid_build: rocprim size query failed");
   SCN_REQUIRE(temp_bytes >= t.total, "scn_grid_build: workspace too small");
@@ -366,10 +373,12 @@ int scn_grid_build(const void *coords, int coords_are_i64, int ncols, int shift,
   int *info = (int *)(base + t.info);  // [0]=N [1]=error flag
   const int nblk = (int)((P + 255) / 256);
   SCN_CHECK_HIP(hipMemsetAsync(info, 0, 16, stream));
-  if (coords_are_i64)
-    k_make_keys<true><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
+  if (coords_dtype == 1)
+    k_make_keys<1><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
+  else if (coords_dtype == 0)
+    k_make_keys<0><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
   else
-    k_make_keys<false><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
+    k_make_keys<2><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
   SCN_CHECK_LAUNCH();
   size_t sb = t.sort_bytes;
   SCN_CHECK_HIP((rocprim::radix_sort_pairs(base + t.sort, sb, keys_in, keys_sorted, idx_in,
@@ -390,19 +399,22 @@ int scn_grid_build(const void *coords, int coords_are_i64, int ncols, int shift,
   return 0;
 }
 
-int scn_grid_finalize(const void *coords, int coords_are_i64, int ncols, int shift, int64_t P,
+int scn_grid_finalize(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
                       int64_t N, const uint64_t *keys_sorted, const int32_t *order,
                       const int32_t *site_start, int32_t *site_coords, uint64_t *site_keys,
                       void *stream_) {
   hipStream_t stream = as_stream(stream_);
   (void)P;
   if (N <= 0) return 0;
-  if (coords_are_i64)
-    k_site_coords<true><<<grid_for(N), 256, 0, stream>>>(coords, ncols, shift, N, keys_sorted, order,
-                                                         site_start, (int4 *)site_coords, site_keys);
+  if (coords_dtype == 1)
+    k_site_coords<1><<<grid_for(N), 256, 0, stream>>>(coords, ncols, shift, N, keys_sorted, order,
+                                                      site_start, (int4 *)site_coords, site_keys);
+  else if (coords_dtype == 0)
+    k_site_coords<0><<<grid_for(N), 256, 0, stream>>>(coords, ncols, shift, N, keys_sorted, order,
+                                                      site_start, (int4 *)site_coords, site_keys);
   else
-    k_site_coords<false><<<grid_for(N), 256, 0, stream>>>(coords, ncols, shift, N, keys_sorted, order,
-                                                          site_start, (int4 *)site_coords, site_keys);
+    k_site_coords<2><<<grid_for(N), 256, 0, stream>>>(coords, ncols, shift, N, keys_sorted, order,
+                                                      site_start, (int4 *)site_coords, site_keys);
   SCN_CHECK_LAUNCH();
   return 0;
 }

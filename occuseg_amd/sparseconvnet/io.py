@@ -47,6 +47,13 @@ class _OutputLayerFunction(Function):
         return grad_input, None
 
 
+def _coords(c):
+    """The reference converts input[0] with `.type(torch.LongTensor)` on the host (sparseconvnet/ioLayers.py:56).
+    Here int64 / int32 / float32 coordinates are consumed as they are (float32 is truncated toward zero on the GPU,
+    like that conversion); anything else is converted to int64 first."""
+    return c if c.dtype in (torch.int64, torch.int32, torch.float32) else c.to(torch.int64)
+
+
 class InputLayer(Module):
     def __init__(self, dimension, spatial_size, mode=3, normal_guide_scale=10240):
         Module.__init__(self)
@@ -61,14 +68,14 @@ class InputLayer(Module):
         batch_size = input[3] if len(input) > 3 else 0
         output = SparseConvNetTensor(metadata=Metadata(self.dimension), spatial_size=self.spatial_size)
         output.features = _InputLayerFunction.apply(features, output.metadata, self.spatial_size,
-                                                    coords.to(torch.int64), batch_size, self.mode, normals,
+                                                    _coords(coords), batch_size, self.mode, normals,
                                                     self.normal_guide_scale)
         return output
 
 
     def prefetch(self, input, device=None, wait_for_current_stream=True):
         """Not in the reference: start building the grids/rulebooks of a FUTURE ``forward(input)`` on a side
-        stream (occuseg_amd.SCN.prefetch_input).  ``input[0]`` must be the same int64 tensor object that will be
+        stream (occuseg_amd.SCN.prefetch_input).  ``input[0]`` must be the same (int64 / int32 / float32) tensor object that will be
         passed to ``forward`` and must not change in between."""
         coords, features = input[0], input[1]
         SCN.prefetch_input(self.spatial_size, coords, self.mode, device if device is not None else features.device,

@@ -74,3 +74,40 @@ def test_out_of_box_is_an_error(gpu):
     neg = torch.tensor([[0, -1, 0, 0]], dtype=torch.int64)
     with pytest.raises(RuntimeError):
         m.inputLayer(torch.tensor([4096] * 3), neg, 0, 4, gpu)
+
+
+def test_float_and_int32_coordinates(gpu):
+    """the collate functions hand over float (or int) coordinates and the reference's InputLayer converts
+    them with `.type(torch.LongTensor)` on the host.  Here float32 / int32 device tensors are consumed directly:
+    same sites, same order, same input rules as the int64 path on the truncated values; NaN / out-of-box raise."""
+    from occuseg_amd import SCN, scenes
+    c64, _ = scenes.batch([1000, 1001], target_sites=8000)
+    rng = np.random.default_rng(0)
+    frac = rng.uniform(0.0, 0.999, size=c64.shape).astype(np.float32)
+    frac[:, 3] = 0.0
+    cf = c64.astype(np.float32) + frac          # truncation toward zero gives c64 back (all coordinates >= 0)
+    assert np.array_equal(cf.astype(np.int64), c64)
+    size = torch.tensor([4096] * 3)
+    ref = SCN.Metadata_3()
+    ref.inputLayer(size, torch.from_numpy(c64).to(gpu), 0, 4, gpu)
+    for t in (torch.from_numpy(cf).to(gpu), torch.from_numpy(c64.astype(np.int32)).to(gpu), torch.from_numpy(cf)):
+        m = SCN.Metadata_3()
+        m.inputLayer(size, t, 0, 4, gpu)
+        assert m.getNActive(size) == ref.getNActive(size)
+        assert torch.equal(m.getSpatialLocations(size), ref.getSpatialLocations(size))
+        assert torch.equal(m.input_order, ref.input_order)
+        assert torch.equal(m.input_site_of_row, ref.input_site_of_row)
+        assert torch.equal(m.input_site_start, ref.input_site_start)
+    for bad in ([[float("nan"), 0, 0, 0]], [[0, 3e9, 0, 0]], [[0, 0, -1.5, 0]], [[1024.5, 0, 0, 0]]):
+        with pytest.raises(RuntimeError):
+            SCN.Metadata_3().inputLayer(size, torch.tensor(bad, dtype=torch.float32), 0, 4, gpu)
+    # -0.5 truncates to 0 (as .long() does): valid
+    SCN.Metadata_3().inputLayer(size, torch.tensor([[-0.5, 0.25, 0.75, 0]], dtype=torch.float32), 0, 4, gpu)
+    # through the module, float coordinates on the device
+    import occuseg_amd
+    scn = occuseg_amd.install()
+    layer = scn.InputLayer(3, 4096, mode=4)
+    feats = torch.randn(c64.shape[0], 3, device=gpu)
+    a = layer([torch.from_numpy(cf).to(gpu), feats, None, 2])
+    b = layer([torch.from_numpy(c64), feats, None, 2])
+    assert torch.equal(a.features, b.features)
