@@ -609,10 +609,20 @@ __global__ void __launch_bounds__(128)
 
   int lin;
   {
+    // Workgroup b runs on XCD b % 8.  Each XCD takes CHUNKS of consecutive tiles (neighbouring tiles gather
+    // overlapping rows: shared L2), dealt round robin so that density differences along the row order (whole scenes)
+    // do not leave some XCDs with more work than others; the ragged end falls back to one contiguous range each.
     const int total = ntiles * ncb;
     const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
-    const int q = total >> 3, r = total & 7;
-    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int CH = 64 * ncb;
+    const int full = (DBG & 512) ? 0 : (total / (8 * CH)) * (8 * CH);  // part that divides into rounds of 8 chunks
+    if (bid < full) {
+      lin = ((j / CH) * 8 + xcd) * CH + j % CH;
+    } else {
+      const int rest = total - full, b2 = bid - full, x2 = b2 & 7, j2 = b2 >> 3;
+      const int q = rest >> 3, r = rest & 7;
+      lin = full + (x2 < r ? x2 * (q + 1) : r * (q + 1) + (x2 - r) * q) + j2;
+    }
   }
   const int tile = lin / ncb;
   const int co0 = (lin % ncb) * COB;
@@ -1279,6 +1289,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 2: SCN_LAUNCH_TILE4(3); break;     // + no gather
     case 8: SCN_LAUNCH_TILE4(11); break;    // + no weights: loop skeleton + MFMAs
     case 256: SCN_LAUNCH_TILE4(256); break;  // stamps
+    case 512: SCN_LAUNCH_TILE4(512); break;  // A/B: one contiguous tile range per XCD
     default: SCN_LAUNCH_TILE4(0);
   }
 #undef SCN_LAUNCH_TILE4
