@@ -790,60 +790,74 @@ __global__ void __launch_bounds__(128)
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int q = 0; q < COS; ++q) acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
-      auto slot = [&](int j) __attribute__((always_inline)) {
-        if (j == 0) {         // row offsets / output rows of pass p+2; weight-load scalars of pass p+1
-          addr(E2, pr, off, o2r);
-          rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
-          w_new = (E1.meta >> 20) & 1u;
-        } else if (j == 1) {  // weights of pass p+1, only when it starts a new (offset, chunk) phase: they are OLDER than
-                              // the row loads below, so the vmcnt(8) at the end of the pass is right either way
-          if (w_new) {
-            weight_scalars(E1, w_so, w_off, w_new);
-            load_weights(0, w_off, w_so[0], wn);
-            load_weights(1, w_off, w_so[1], wn);
+      // Everything that is not an MFMA of this pass, cut into pieces of a few instructions; piece m is issued right
+      // after MFMA m of the first group (16 pieces).  Measured the same as seven larger slots between groups of four
+      // MFMAs (MFMA pipe busy 66 % either way, two waves per SIMD): the granularity of the interleave is not what
+      // limits the kernel, the vector-memory issue of the 10-18 loads per pass is.  Load order (vmcnt!): 8 weight,
+      // 2 index, 8 row.
+      auto piece = [&](int m) __attribute__((always_inline)) {
+        if (m == 0 || m == 1) {  // row offset / output row of group m of pass p+2 from its (arrived) pair indices
+          const int i = m;
+          const unsigned src = in_col ? pr[i].y : pr[i].x;
+          const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
+          off[i] = (16 * i < rem(E2) && !(DBG & 2)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
+          o2r[i] = (16 * i + li < rem(E2)) ? dst * OS : M * OS;
+          if (m == 1) {
+            rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
+            w_new = (E1.meta >> 20) & 1u;
           }
-        } else if (j == 2) {
-          if (w_new) {
-            load_weights(2, w_off, w_so[2], wn);
-            load_weights(3, w_off, w_so[3], wn);
-          }
+        } else if (m == 2) {     // weights of pass p+1 only when it starts a new (offset, chunk) phase: they are OLDER than
+          if (w_new) weight_scalars(E1, w_so, w_off, w_new);  // the row loads, so the vmcnt(8) below is right either way
+        } else if (m >= 3 && m <= 6) {
+          if (w_new) load_weights(m - 3, w_off, w_so[m - 3], wn);
+        } else if (m == 7) {
           tile_rows(old, op);
-        } else if (j == 3) {  // indices of pass p+3 (pr was consumed in slot 0)
+        } else if (m == 8) {     // indices of pass p+3 (pr was consumed by pieces 0-1)
           load_idx(E3, ioff, pr);
-        } else if (j == 4) {  // rows of pass p+2: the long-latency gathers, in flight until the end of pass p+1
-          load_rows(0, off[0], rso, rn);
-        } else if (j == 5) {
-          load_rows(1, off[1], rso, rn);
-          scatter(prev, old, op);
-        } else if (j == 6) {  // table entry p+4
+        } else if (m >= 9 && m <= 12) {  // rows of pass p+2: the long-latency gathers, in flight until the end of pass p+1
+          const int i = (m - 9) >> 1;
+          if ((m - 9) & 1) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rn[i][2]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rn[i][3]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+          } else {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rn[i][0]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rn[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+          }
+        } else if (m == 13 || m == 14) {  // read-add-write of pass p-1, one group per piece
+          const int i = m - 13;
+#pragma unroll
+          for (int q = 0; q < COS; ++q) {
+            if (DBG & 1) {
+              asm volatile("" ::"v"(prev[i][q]));
+            } else {
+              *(floatx4 *)(o_tile + op[i] + 32 * w + 16 * q + 4 * lq) = old[i][q] + prev[i][q];
+            }
+          }
+        } else if (m == 15) {    // table entry p+4
           E4 = entry(pnext);
         }
       };
       if (!(DBG & 16)) {
 #pragma unroll
         for (int sp = 0; sp < NS16; ++sp) {
-          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].x, rc[0][sp].x, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].x, rc[0][sp].x, acc[0][1], 0, 0, 0);
-          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].y, rc[0][sp].y, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].y, rc[0][sp].y, acc[0][1], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (DBG & 256) t0 = stamp();
-          slot(2 * sp);
-          if (DBG & 256) { t1 = stamp(); seg[sp == 0 ? 0 : sp == 1 ? 1 : sp == 2 ? 3 : 0] += t1 - t0; }
-          __builtin_amdgcn_sched_barrier(0);
-          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].z, rc[0][sp].z, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].z, rc[0][sp].z, acc[0][1], 0, 0, 0);
-          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].w, rc[0][sp].w, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].w, rc[0][sp].w, acc[0][1], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (DBG & 256) t0 = stamp();
-          slot(2 * sp + 1);
-          if (DBG & 256) { t1 = stamp(); if (sp < 3) seg[sp == 0 ? 1 : sp == 1 ? 2 : 3] += t1 - t0; }
-          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int h = 0; h < 8; ++h) {
+            const int q = h & 1;
+            const float a = (h >> 1) == 0 ? wc[q][sp].x : (h >> 1) == 1 ? wc[q][sp].y : (h >> 1) == 2 ? wc[q][sp].z : wc[q][sp].w;
+            const float bv = (h >> 1) == 0 ? rc[0][sp].x : (h >> 1) == 1 ? rc[0][sp].y : (h >> 1) == 2 ? rc[0][sp].z : rc[0][sp].w;
+            acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[0][q], 0, 0, 0);
+            if (sp * 8 + h < 16) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (DBG & 256) t0 = stamp();
+              piece(sp * 8 + h);
+              if (DBG & 256) { t1 = stamp(); seg[(sp * 8 + h) < 3 ? 0 : (sp * 8 + h) < 8 ? 1 : (sp * 8 + h) < 9 ? 2 : 3] += t1 - t0; }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) slot(j);
+        for (int m = 0; m < 16; ++m) piece(m);
       }
       if (two && !(DBG & 16)) {
 #pragma unroll
