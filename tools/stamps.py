@@ -11,7 +11,7 @@ md.inputLayer(size, torch.from_numpy(coords), 0, 4, dev)
 f3, f2 = torch.tensor([3, 3, 3]), torch.tensor([2, 2, 2])
 names = ["store_rows(+vmcnt)", "barrier1", "issue loads", "group passes", "tail", "barrier2"]
 if os.environ.get("STAMP_VARIANT") == "4":
-    names = ["row offsets + descriptors (slots 0,6)", "8 weight loads + tile reads (1,2)", "2 index loads (3)", "8 row loads + scatter (4,5)"]
+    names = ["row offsets + weight scalars (pieces 0-2)", "weight loads + tile reads (3-7)", "2 index loads (8)", "8 row loads + scatter + table entry (9-15)"]
     lib.scn_set_tuning(0, 4)
 for lv in range(2):
     rb = md.getSubmanifoldRuleBook(size, f3); n = md.getNActive(size); p = 64 * (lv + 1)
@@ -24,7 +24,7 @@ for lv in range(2):
         lib.scn_set_tuning(1, 0)
         if os.environ.get("STAMP_VARIANT") == "4":
             np_ = buf[4]
-            print("L%d %d->%d: cycles per pass in the slots between MFMA groups: " % (lv, ci, co) + "  ".join("%s %.0f" % (nm, buf[i] / np_) for i, nm in enumerate(names)))
+            print("L%d %d->%d: cycles per pass in the pieces between MFMAs: " % (lv, ci, co) + "  ".join("%s %.0f" % (nm, buf[i] / np_) for i, nm in enumerate(names)))
             continue
         tot = sum(buf[:6])
         print("L%d %d->%d: " % (lv, ci, co) + "  ".join("%s %.1f%%" % (nm, 100.0 * buf[i] / tot) for i, nm in enumerate(names)))
