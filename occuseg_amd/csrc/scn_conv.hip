@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(128)
           const int i = m;
           const unsigned src = in_col ? pr[i].y : pr[i].x;
           const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
-          off[i] = (16 * i < rem(E2) && !(DBG & 2)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
+          off[i] = (16 * i < rem(E2) && !(DBG & 2) && !((DBG & 2048) && w == 1)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
           o2r[i] = (16 * i + li < rem(E2)) ? dst * OS : M * OS;
           if (m == 1) {
             rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
@@ -1304,6 +1304,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 8: SCN_LAUNCH_TILE4(11); break;    // + no weights: loop skeleton + MFMAs
     case 256: SCN_LAUNCH_TILE4(256); break;  // stamps
     case 512: SCN_LAUNCH_TILE4(512); break;  // A/B: one contiguous tile range per XCD
+    case 2048: SCN_LAUNCH_TILE4(2048); break;  // timing only: wave 1 gathers nothing
     default: SCN_LAUNCH_TILE4(0);
   }
 #undef SCN_LAUNCH_TILE4
