@@ -580,8 +580,7 @@ __global__ void __launch_bounds__(64 * NW * NWM)
 //   pass p+3, row loads of pass p+2, read-add-write of pass p-1's result into the output tile, table entry p+4.
 // The loads are inline asm with hand-counted s_waitcnt: hipcc's own counters collapse to vmcnt(0..8) at the top of
 // every pass once loads stay in flight over the back edge of the unrolled loop.  Every pass issues the same loads in
-// the same order (8 weight, 2 index, 8 row); the ones a pass does not need point past the end of their buffer (the
-// range check returns 0 without touching memory).  hipcc does not know that an asm load's destination is not valid
+// the same order (8 weight, 2 index, 8 row); the ones a pass does not need read the first bytes of their buffer.  hipcc does not know that an asm load's destination is not valid
 // until the wait, so: the waits name the destinations as INPUTS (keeps them allocated; a "+v" tie made hipcc copy
 // them in FRONT of the wait), nothing but row registers (fixed variables of a 3-way unrolled loop) is in flight over
 // the back edge, and tools/check_asm_loads.py (run by build.py) proves on the emitted assembly that no instruction
@@ -667,7 +666,10 @@ __global__ void __launch_bounds__(128)
   }
   __syncthreads();  // the only barrier
   auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
-  constexpr unsigned OOB = 0x80000000u;
+  // offset of the loads a pass does not need (absent second group, passes past the end): the first bytes of the buffer
+  // (always valid; what they fetch is multiplied by nothing or lands in the sink row).  Pointing them past the end of the
+  // buffer instead (DBG & 8192: the range check returns 0 without touching memory) is 0.5-2 % SLOWER.
+  constexpr unsigned OOB = (DBG & 8192) ? 0x80000000u : 0u;
   struct Ent { unsigned base, meta; };  // meta & 255: pairs left (0: no such pass)
   auto entry = [&](int p) __attribute__((always_inline)) {
     const uint2 v = *(const uint2 *)ptab[p];
@@ -677,7 +679,7 @@ __global__ void __launch_bounds__(128)
   // per-lane byte offsets of a pass's two index loads
   auto index_offsets = [&](const Ent &e, unsigned (&vo)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) vo[i] = (16 * i < rem(e)) ? (unsigned)min(16 * i + li, rem(e) - 1) * 8u : OOB;
+    for (int i = 0; i < 2; ++i) vo[i] = (16 * i < rem(e) && !(DBG & 4096)) ? (unsigned)min(16 * i + li, rem(e) - 1) * 8u : OOB;
   };
   // row byte offsets / output-tile rows of a pass from its pair indices
   auto addr = [&](const Ent &e, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
@@ -895,12 +897,12 @@ __global__ void __launch_bounds__(128)
       ++pnext;
     };
     do {  // single exit: a mid-loop break makes hipcc read "undefined" scalars out of a row register.  A pass past the
-          // end is an empty one (all loads out of range, rows zero, output rows = sink) that only flushes `prev`.
+          // end is an empty one (dummy loads, output rows = sink) that only flushes `prev`.
       body(rA, rB, rC);
       body(rB, rC, rA);
       body(rC, rA, rB);
     } while (rem(E0) > 0);
-    // the (out-of-range) row prefetches of the passes past the end
+    // the (dummy) row prefetches of the passes past the end
     asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS(rA), SCN_ROWS(rB), SCN_ROWS(rC) : "memory");
     {  // result of the last pass
       floatx4 old[2][COS];
@@ -1305,6 +1307,9 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 256: SCN_LAUNCH_TILE4(256); break;  // stamps
     case 512: SCN_LAUNCH_TILE4(512); break;  // A/B: one contiguous tile range per XCD
     case 2048: SCN_LAUNCH_TILE4(2048); break;  // timing only: wave 1 gathers nothing
+    case 4096: SCN_LAUNCH_TILE4(4096 + 3); break;  // timing only: no gathers, no tile update, no index loads
+    case 4097: SCN_LAUNCH_TILE4(4096 + 11); break;  // ... and no weight loads
+    case 8192: SCN_LAUNCH_TILE4(8192); break;  // A/B: unneeded loads point out of range instead of reading offset 0
     default: SCN_LAUNCH_TILE4(0);
   }
 #undef SCN_LAUNCH_TILE4
