@@ -1226,6 +1226,7 @@ __global__ void __launch_bounds__(256)
 using namespace scn;
 
 static int g_conv_dbg = 0;
+static int g_dw_slices = 256;  // tuning key 5: dWeight slices over the longest list
 static int g_conv_small_policy = 1500;  // tuning key 4: launches with few tiles keep the 128 x 64 tile and split their
                                         // offsets until there are this many workgroups (0 = the older rule, for A/B:
                                         // 64 x 32 tiles first); +16-22 % on the three coarsest UNet levels
@@ -1355,6 +1356,10 @@ int scn_set_tuning(int key, int value) {
     g_conv_small_policy = value;
     return 0;
   }
+  if (key == 5 && value >= 1) {
+    g_dw_slices = value;
+    return 0;
+  }
   if (key == 3) {
     g_conv_small_off = value;
     return 0;
@@ -1434,7 +1439,7 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     // slices per list: enough workgroups per (k, plane block) to fill the chip, few enough that the float atomics of
     // the partial sums (one CIB x COB tile per workgroup) stay far below the ~1.3 TB/s atomic rate.  The longest list
     // (the centre offset: one pair per site) gets ~2400 pairs per workgroup, an average one about half of that.
-    int per = (int)(((stride + 255) / 256 + 63) / 64 * 64);
+    int per = (int)(((stride + g_dw_slices - 1) / g_dw_slices + 63) / 64 * 64);
     if (per < 2048) per = 2048;
     if (per > 16384) per = 16384;
     const int gx = (int)((stride + per - 1) / per);

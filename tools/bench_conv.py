@@ -62,7 +62,8 @@ def main():
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                     line += "  v%s %.3f ms %.1f TF" % (v, ms, flops / ms / 1e9)
                 for dv in ([int(v) for v in args.dw_variants.split(',')] if args.dw else []):
-                    lib.scn_set_tuning(1, dv)
+                    lib.scn_set_tuning(1, dv % 1000)
+                    lib.scn_set_tuning(5, dv // 1000 if dv >= 1000 else 256)
                     dy = torch.randn(n, co, device=dev)
                     dw = torch.zeros_like(w)
                     ms = timeit(lambda: _lib.check(lib.scn_conv_dweight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
