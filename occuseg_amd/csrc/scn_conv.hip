@@ -1023,7 +1023,7 @@ __global__ void __launch_bounds__(256)
 
 // ---------------------------------------------------------------- dWeight ---
 // block: 4 waves as 2x2; wave owns TI x TJ 16x16 tiles; block tile CIB x COB.
-template <int TI, int TJ, int PS = 32>
+template <int TI, int TJ, int PS = 32, int ABL = 0>
 __global__ void __launch_bounds__(256)
     k_dw_tile(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
               const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
@@ -1092,14 +1092,14 @@ __global__ void __launch_bounds__(256)
     for (int j = 0; j < NI; ++j) {
       const int idx = tid + j * 256, row = idx / (CIB / 4), ch = idx % (CIB / 4);
       const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-          in_rsrc, (unsigned)(in_col ? pi_[j].y : pi_[j].x) * (unsigned)(Ci * 4) + (unsigned)(ch * 16), ci0 * 4, 0));
+          in_rsrc, (ABL & 1) ? (unsigned)(ch * 16) : (unsigned)(in_col ? pi_[j].y : pi_[j].x) * (unsigned)(Ci * 4) + (unsigned)(ch * 16), ci0 * 4, 0));
       ri[j] = v * ((pb + row < p1) ? 1.f : 0.f);
     }
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
       const int idx = tid + j * 256, row = idx / (COB / 4), ch = idx % (COB / 4);
       const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-          do_rsrc, (unsigned)(in_col ? pd_[j].x : pd_[j].y) * (unsigned)(Co * 4) + (unsigned)(ch * 16), co0 * 4, 0));
+          do_rsrc, (ABL & 1) ? (unsigned)(ch * 16) : (unsigned)(in_col ? pd_[j].x : pd_[j].y) * (unsigned)(Co * 4) + (unsigned)(ch * 16), co0 * 4, 0));
       rd[j] = v * ((pb + row < p1) ? 1.f : 0.f);
     }
   };
@@ -1447,6 +1447,8 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
       const unsigned nblk = (unsigned)(gx * K * (Ci / 64) * (Co / 64));
       if (g_conv_dbg == 100)  // A/B: 32 pairs per step
         k_dw_tile<2, 2, 32><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+      else if (g_conv_dbg == 103)  // timing only: every row load reads row 0 (no gather traffic)
+        k_dw_tile<2, 2, 64, 1><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
       else if (g_conv_dbg == 101)
         k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col + 2, Ci, Co, gx, in_bytes, do_bytes, -K);
       else
