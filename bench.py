@@ -9,10 +9,15 @@ A step = one pass of the hot path over one batch: InputLayer (voxel hash + every
 rebuilt each step, as in real training) -> stem SC(3->m) -> scn.UNet(3,1,[m..6m],residual) ->
 BatchNormReLU -> OutputLayer -> sum loss -> backward -> (N>1: RCCL all-reduce of the flat
 gradient) -> Adam step.  Workload = BASELINE.json configs[2]: 4 synthetic ScanNet-like scenes of
-~150k active voxels per GPU (weak scaling: configs[3] is 8 x this).  Inputs are resident in HBM
-before the timed region.  Prints ONE JSON line on rank 0.
+~150k active voxels per GPU (weak scaling: configs[3] is 8 x this).  Every rank alternates between TWO
+different resident batches (different scenes, different site counts), so no step sees the coordinates of the
+step before it; while a step's kernels drain, the OTHER batch's voxel hash and rulebooks are built on a side
+stream (InputLayer.prefetch), as a data loader would do.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -22,12 +27,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def build_net(scn, m):
@@ -35,6 +41,17 @@ def build_net(scn, m):
         scn.SubmanifoldConvolution(3, 3, m, 3, False)).add(
         scn.UNet(3, 1, [m, 2 * m, 3 * m, 4 * m, 5 * m, 6 * m], residual_blocks=True)).add(
         scn.BatchNormReLU(m)).add(scn.OutputLayer(3))
+
+
+def source_hash():
+    """identity of the kernel sources a measurement belongs to (there is no .git on the GPU box)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "occuseg_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_cores():
@@ -81,6 +98,30 @@ def cpu_baseline(m, target_sites, seed, budget_s=20.0):
                       "mm + index_select/index_add_, rulebook build excluded" % (seed, n0, m, dt)}
 
 
+def measured_peaks(dev):
+    """f32-MFMA and HBM-stream microbenchmarks on THIS box (libscn_hip_tuning.so, outside the timed region)"""
+    from occuseg_amd import _lib
+    try:
+        lib = _lib._open(_lib.TUNING_LIB_PATH, _lib.TUNING_SIGNATURES)
+    except (RuntimeError, OSError, AttributeError):
+        return None
+    stream = torch.cuda.current_stream().cuda_stream
+    scratch = torch.zeros(64, device=dev)
+    tf = ctypes.c_double(0)
+    best_tf = 0.0
+    for wps in (1, 2):
+        _lib.check(lib.scn_peak_mfma_f32(scratch.data_ptr(), wps, ctypes.byref(tf), stream))
+        best_tf = max(best_tf, tf.value)
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).zero_()
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    gbs = ctypes.c_double(0)
+    _lib.check(lib.scn_peak_copy(src.data_ptr(), dst.data_ptr(), nbytes, 3, ctypes.byref(gbs), stream))
+    del src, dst
+    return {"f32_mfma_tflops": best_tf, "hbm_copy_GBs": gbs.value,
+            "how": "v_mfma_f32_16x16x4_f32 chains on every SIMD; float4 copy of 1 GiB (bytes read + written)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,16 +134,19 @@ def main():
     ap.add_argument("--event-every", type=int, default=4, help="time the kernels with HIP events on every n-th step")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="build each step's rulebooks inside the step instead of one step ahead on a side stream")
+    ap.add_argument("--same-batch", action="store_true", help="replay ONE batch (round-1 behaviour) instead of alternating two")
+    ap.add_argument("--dump-launches", default=None, help="write per-launch timings (kernel, shape, ms) to this JSON file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("SCN_BENCH_BACKEND", "nccl")  # tests: gloo (every rank on cuda:0 with SCN_BENCH_ONE_DEVICE=1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if os.environ.get("SCN_BENCH_ONE_DEVICE") else local_rank)
     torch.cuda.set_device(dev)
 
     import occuseg_amd
@@ -114,34 +158,38 @@ def main():
     n_params = sum(p.numel() for p in net.parameters())
     bucket = dp.FlatGradBucket(net.parameters())
     if world > 1:
-        bucket.enable_overlap()  # bucketed all-reduce launched from backward hooks
+        bucket.enable_overlap()  # bucketed all-reduce launched from backward as each bucket completes
     # torch's fused Adam kernel (same arithmetic as the default foreach implementation: 53.5 -> 51.9 ms per step)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=bool(int(os.environ.get("SCN_BENCH_FUSED_ADAM", "1"))))
 
-    all_seeds = [1000 + i for i in range(args.scenes_per_gpu * world)]
-    seeds = dp.shard(all_seeds, rank, world)
-    coords, feats = scenes.batch(seeds, args.sites)
-    coords_d = torch.from_numpy(coords).to(dev)
-    feats_d = torch.from_numpy(feats).to(dev)
-    batch_in = [coords_d, feats_d, None, len(seeds)]
-
-    with torch.no_grad():
-        md = SCN.Metadata_3()
-        md.inputLayer(torch.tensor([4096] * 3), coords_d, 0, 4, dev)
-        n_sites = md.nActive[md.inputSpatialSize]
-        del md
+    # two resident batches per rank: scenes 1000.. and 1100.. (different geometry, different site counts)
+    batches, n_sites = [], []
+    for base in ((1000,) if args.same_batch else (1000, 1100)):
+        all_seeds = [base + i for i in range(args.scenes_per_gpu * world)]
+        seeds = dp.shard(all_seeds, rank, world)
+        coords, feats = scenes.batch(seeds, args.sites)
+        b = [torch.from_numpy(coords).to(dev), torch.from_numpy(feats).to(dev), None, len(seeds)]
+        with torch.no_grad():
+            md = SCN.Metadata_3()
+            md.inputLayer(torch.tensor([4096] * 3), b[0], 0, 4, dev)
+            n_sites.append(md.nActive[md.inputSpatialSize])
+            del md
+        batches.append(b)
     input_layer = next(mod for mod in net.modules() if isinstance(mod, scn.InputLayer))
+    counter = [0]
 
     def step():
+        i = counter[0]
+        counter[0] += 1
         bucket.zero()
-        out = net(batch_in)
+        out = net(batches[i % len(batches)])
         out.sum().backward()
         bucket.all_reduce_mean()
         opt.step()
         if args.prefetch:
             # software pipelining across steps: the NEXT batch's voxel hash + rulebooks are built on a side stream
             # while this step's kernels drain (every step still builds its own)
-            input_layer.prefetch(batch_in, wait_for_current_stream=False)
+            input_layer.prefetch(batches[(i + 1) % len(batches)], wait_for_current_stream=False)
         return out
 
     for _ in range(args.warmup):
@@ -153,80 +201,137 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events around every gather-mm / dWeight launch, inside the timed region, on every EVENT_EVERY-th step: a
-    # timed event drains the queue between two kernels, and 226 of them per step cost 3-4 ms of a 57 ms step
-    # (measured back to back: 58.8 / 57.5 ms with events on every step, 54.7 / 54.3 ms with none).
+    # HIP events around every kernel of interest, inside the timed region, on every EVENT_EVERY-th step: a
+    # timed event drains the queue between two kernels, and hundreds of them per step cost 3-4 ms of a 55 ms step.
+    # One more event per step (end of step, main stream) gives the per-step durations for the median.
     prof = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    sites_done = 0
+    first = counter[0]
     barrier()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         SCN.PROFILE = prof if (i % args.event_every == 0 and rank == 0) else None
         step()
+        marks[i + 1].record()
+        sites_done += n_sites[(first + i) % len(batches)]
     SCN.PROFILE = None
     barrier()
     dt = time.perf_counter() - t0
 
-    t = torch.tensor([dt, float(n_sites)], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, float(sites_done)], dtype=torch.float64, device=dev)
     if world > 1:
-        tmax = t.clone()
+        tcpu = t.cpu() if backend == "gloo" else t
+        tmax = tcpu.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
+        tsum = tcpu.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, total_sites = float(tmax[0]), float(tsum[1])
     else:
-        total_sites = float(n_sites)
+        total_sites = float(sites_done)
 
     if rank == 0:
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         # per-kernel HIP-event timings over the timed region (events were recorded on the launch stream)
         agg = {}
-        for kernel, flops, nbytes, e0, e1, _shape in prof:
+        launches = []
+        for kernel, flops, nbytes, e0, e1, shape in prof:
+            nbytes = nbytes() if callable(nbytes) else nbytes
+            ms = e0.elapsed_time(e1)
             a = agg.setdefault(kernel, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += nbytes
-            a[3] += e0.elapsed_time(e1) * 1e-3
-        kernels = {}
+            a[3] += ms * 1e-3
+            launches.append((kernel, shape, ms, flops, nbytes))
         sampled = len(range(0, args.steps, args.event_every))  # steps whose launches carry events
-        for kname, (cnt, flops, nbytes, secs) in agg.items():
-            kernels[kname] = {"launches": cnt, "avg_ms": 1e3 * secs / cnt, "tflops": flops / secs / 1e12,
-                              "algo_GBs": nbytes / secs / 1e9, "share_of_step": secs / (dt * sampled / args.steps),
-                              "steps_with_events": sampled}
-        dom = max(agg, key=lambda k: agg[k][3]) if agg else None
-        # HBM bytes per launch of the dominant kernel: rocprofv3 PMC counters cannot be read from inside
-        # this process; they are collected by running THIS command under `rocprofv3 --pmc FETCH_SIZE` and
-        # `--pmc WRITE_SIZE` (separate passes) and summarised by tools/pmc_traffic.py into profiles/.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and args.m == 64 and args.scenes_per_gpu == 4 and args.sites == 150000:
+        peaks = measured_peaks(dev) if world == 1 else None
+        hbm_meas = peaks["hbm_copy_GBs"] if peaks else None
+        kernels = {}
+        for kname, (cnt, flops, nbytes, secs) in sorted(agg.items(), key=lambda kv: -kv[1][3]):
+            k = {"launches_per_step": cnt / sampled, "ms_per_step": 1e3 * secs / sampled, "avg_ms": 1e3 * secs / cnt,
+                 "algo_GBs": nbytes / secs / 1e9, "hbm_frac": nbytes / secs / 1e9 / HBM_PEAK_GBS}
+            if flops > 0:
+                k["tflops"] = flops / secs / 1e12
+                k["mfma_frac"] = flops / secs / 1e12 / F32_MFMA_PEAK_TFLOPS
+            if hbm_meas:
+                k["hbm_frac_of_measured"] = nbytes / secs / 1e9 / hbm_meas
+            kernels[kname] = k
+        groups = {"bn": ("bn_fwd", "bn_bwd"), "rules": ("grid_build", "sub_rules", "strided_rules"), "io": ("io",)}
+        for g, names in groups.items():  # the HBM-bound parts of the step, summed
+            sel = [agg[n] for n in names if n in agg]
+            if sel:
+                secs, nbytes = sum(a[3] for a in sel), sum(a[2] for a in sel)
+                kernels[g] = {"ms_per_step": 1e3 * secs / sampled, "algo_bytes_per_step": nbytes / sampled,
+                              "algo_GBs": nbytes / secs / 1e9, "hbm_frac": nbytes / secs / 1e9 / HBM_PEAK_GBS,
+                              "members": [n for n in names if n in agg]}
+        mm = [k for k in agg if k.startswith(("conv_", "dw_"))]
+        dom = max(mm, key=lambda k: agg[k][3]) if mm else None
+        # HBM bytes per launch of the dominant kernel: rocprofv3 PMC counters cannot be read from inside this process;
+        # they are collected by running THIS command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+        # (separate passes) and summarised by tools/pmc_traffic.py, which stamps the file with the hash of the kernel
+        # sources it measured.  A file measured on other sources is refused.
+        traffic, traffic_note = None, None
+        if os.path.exists(TRAFFIC_FILE) and args.m == 64 and args.scenes_per_gpu == 4 and args.sites == 150000:
             try:
-                traffic = json.load(open(tpath)).get(dom or "", {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(TRAFFIC_FILE))
+                if tj.get("source_hash") == source_hash():
+                    traffic = tj.get(dom or "", {}).get("hbm_bytes_per_launch")
+                    traffic_note = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
+                                    "separate passes; FETCH_SIZE x2 per the gfx950 note), same kernel sources")
+                else:
+                    traffic_note = "profiles/r02_traffic.json was measured on other kernel sources: refused"
             except (OSError, ValueError):
                 traffic = None
         roof = None
         if dom:
             cnt, flops, nbytes, secs = agg[dom]
-            achieved = (flops / cnt) / (secs / cnt) / 1e12
+            achieved = flops / secs / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this "
-                                      "command; FETCH_SIZE x2 per the gfx950 note)" if traffic else None,
-                    "launches": cnt, "avg_launch_ms": 1e3 * secs / cnt,
+                    "traffic_source": traffic_note,
+                    "launches_per_step": cnt / sampled, "avg_launch_ms": 1e3 * secs / cnt,
                     "algo_flops_per_launch": flops / cnt, "algo_bytes_per_launch": nbytes / cnt,
                     "algo_GBs": nbytes / secs / 1e9, "hbm_frac_of_8TBs": nbytes / secs / 1e9 / HBM_PEAK_GBS}
+            if peaks:
+                roof["peak_measured"] = peaks["f32_mfma_tflops"]
+                roof["frac_of_measured"] = achieved / peaks["f32_mfma_tflops"]
+                roof["hbm_peak_measured"] = peaks["hbm_copy_GBs"]
+            # all gather-mm + dWeight launches together (what round 1 reported as "conv_tile")
+            fl, se = sum(agg[k][1] for k in mm), sum(agg[k][3] for k in mm)
+            roof["all_matrix_kernels"] = {"tflops": fl / se / 1e12, "frac": fl / se / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                          "ms_per_step": 1e3 * se / sampled}
         res = {
             "metric": "active-voxels/s fwd+bwd, ScanNet m64 UNet, 1/2/4/8 MI355X",
-            "value": total_sites * args.steps / dt, "unit": "active-voxels/s", "n_gpus": world,
+            "value": total_sites / dt, "unit": "active-voxels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_min": step_ms[0],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: ScanNet m%d UNet train step (fwd+bwd+Adam), "
-                                   "batch=%d synthetic scenes x ~%dk active voxels per GPU, rulebooks rebuilt "
-                                   "every step" % (args.m, args.scenes_per_gpu, args.sites // 1000),
-                       "active_voxels_per_step": total_sites, "parameters": n_params,
+                                   "batch=%d synthetic scenes x ~%dk active voxels per GPU, %s, rulebooks rebuilt "
+                                   "every step" % (args.m, args.scenes_per_gpu, args.sites // 1000,
+                                                   "ONE batch replayed" if args.same_batch else
+                                                   "two different batches alternating"),
+                       "active_voxels_per_batch": n_sites, "parameters": n_params,
                        "parallelism": "dp%d" % world, "allreduce_bytes": 4 * n_params if world > 1 else 0,
-                       "rulebook_prefetch": bool(args.prefetch)},
-            "roofline": roof, "kernels": kernels,
+                       "backend": backend if world > 1 else None,
+                       "rulebook_prefetch": bool(args.prefetch), "source_hash": source_hash()},
+            "roofline": roof, "kernels": kernels, "peaks_measured": peaks,
         }
+        if args.dump_launches:
+            per_shape = {}
+            for kernel, shape, ms, flops, nbytes in launches:
+                d = per_shape.setdefault("%s %s" % (kernel, shape), [0, 0.0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += ms
+                d[2] += flops
+                d[3] += nbytes
+            rows = [{"launch": k, "per_step": v[0] / sampled, "ms_per_step": v[1] / sampled, "avg_ms": v[1] / v[0],
+                     "tflops": v[2] / v[1] / 1e9 if v[2] else None, "algo_GBs": v[3] / v[1] / 1e6}
+                    for k, v in sorted(per_shape.items(), key=lambda kv: -kv[1][1])]
+            json.dump(rows, open(args.dump_launches, "w"), indent=0)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.m, args.sites, 1000)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 1
+#define SCN_ABI_VERSION 2
 #define SCN_TILE_GRANULE 32 /* output-row granule of the tile-base tables */
 
 int scn_abi_version(void);
@@ -117,25 +117,38 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
  * cuda_Deconvolution_updateOutput (sparseconvnet/SCN/CUDA/Convolution.cpp:36-66,:105-162;
  * sparseconvnet/SCN/CUDA/Deconvolution.cpp:20-49) and the dInput half of the matching *_backward
  * (sparseconvnet/SCN/CUDA/Convolution.cpp:69-102,:165-210).  `out` is fully overwritten.
- *   Ci = planes of `in` (n_in rows, n_in*Ci*4 < 2 GiB), Co = planes of `out` (n_out rows).
+ *   Ci = planes of `in` (n_in rows; above 4 GiB of input rows a slower fallback kernel runs and says so on stderr), Co = planes of `out` (n_out rows).
  *   Wk[ci][co] = w_transposed ? W[ks][co][ci] : W[ks][ci][co],  ks = w_reverse ? K-1-k : k,
  *   where W is the module's weight [K][Ci][Co] (forward) or [K][Co][Ci] (dInput: w_transposed = 1;
  *   submanifold dInput additionally w_reverse = 1 and the SAME lists, because
  *   (i,o) in list k  <=>  (o,i) in list 26-k).
  *   in_col/out_col: 0/1 for conv + submanifold, 1/0 for deconvolution
  *   (sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49); bases = scn_tile_bases(.., out_col, n_out).
- *   wpack: scn_conv_wpack_bytes(K,Ci,Co) bytes of scratch (weights re-laid out in MFMA fragment order). */
+ *   wpack: scn_conv_wpack_bytes(K,Ci,Co) bytes holding the weights re-laid out in MFMA fragment order.
+ *   wpack_ready = 0: scn_conv_forward packs (W, w_transposed, w_reverse) into it first; 1: the caller already ran
+ *   scn_weight_pack for exactly this (W contents, w_transposed, w_reverse) -- weights change once per optimizer
+ *   step, not once per call -- and W is not read (planes that are not multiples of 16 always read W itself).
+ *   workspace: scn_conv_workspace_bytes(...) bytes (0 for most launches).  Launches with few output tiles (the coarse
+ *   UNet levels) split their offsets over several workgroups per tile; the partial tiles go to the workspace and are
+ *   added in a fixed order, so every launch is bitwise reproducible run to run (the reference scatters with float
+ *   atomics, sparseconvnet/SCN/CUDA/Convolution.cu:529,1147). */
 size_t scn_conv_wpack_bytes(int K, int Ci, int Co);
+size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co);
+/* which kernel scn_conv_forward runs for this shape (for per-kernel reporting): 100 * kind + offset split, kind
+ * 0 = generic (planes not multiples of 16), 1 = synchronous fallback (> 4 GiB), 2 = k_conv_tile2 (LDS-staged),
+ * 4 = k_conv_tile4 (barrier-free), 5 = k_conv_expand (one contribution per output row: deconvolution, conv dInput, NiN) */
+int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co);
+int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int Ci, int Co, void *wpack,
+                    void *stream);
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
                      const float *bias, const int32_t *rules, const int32_t *bases, int K,
                      int64_t stride, int in_col, int out_col, int64_t n_in, int64_t n_out, int Ci,
-                     int Co, void *wpack, void *stream);
+                     int Co, void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes,
+                     void *stream);
 
-/* debugging aid for A/B runs: key 0 = gather-mm kernel variant (1 synchronous, 2 LDS-staged pipelined for all
- * shapes, 4 [default] barrier-free two-wave kernel where it applies); key 1 = ablation/stamp build of that kernel */
-int scn_set_tuning(int key, int value);
-/* debugging aid: cycle sums per pipeline segment of the diagnostic kernel build (8 x u64, host) */
-int scn_debug_stamps(unsigned long long *out_host);
+/* scn_set_tuning / scn_debug_stamps (kernel-variant selection, timing-only ablation builds, cycle stamps) are NOT
+ * part of this ABI: they exist only in libscn_hip_tuning.so (same sources compiled with -DSCN_TUNING), which
+ * tools/ and the variant-equivalence test load explicitly. */
 
 /* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller,
  * as the reference's callers do: sparseconvnet/submanifoldConvolution.py:114-115).

@@ -33,10 +33,15 @@ def _prof_begin():
 
 
 def _prof_end(ev, kernel, flops, nbytes, shape=None):
+    """nbytes may be a callable (evaluated when the profile is summarised: pair counts that are not known on the
+    host yet when a rulebook build is queued)"""
     if ev is not None:
         end = torch.cuda.Event(enable_timing=True)
         end.record()
         PROFILE.append((kernel, flops, nbytes, ev, end, shape))
+
+
+_CONV_KERNELS = {0: "conv_generic", 1: "conv_tile_fallback", 2: "conv_tile2", 4: "conv_tile4", 5: "conv_expand"}
 
 
 def _lib_():
@@ -64,6 +69,7 @@ def _need_cuda(t, what):
 # for the rest of the step.  Purely a scheduling matter: the lazily built result is identical.
 _PLANS = {}
 PREBUILD = True
+KEEP_NBR = False  # tests only: keep each submanifold rulebook's neighbour table (`d_global_query_result`) alive
 _COORD_DTYPES = {torch.int32: 0, torch.int64: 1, torch.float32: 2}  # scn_grid_build coords_dtype
 
 # Grids + rulebooks built AHEAD of the InputLayer call that will use them (prefetch_input below), keyed by the
@@ -136,6 +142,7 @@ class Metadata_3(object):
     def _build_grid(self, coords_dev, dtype_code, ncols, shift, P):
         lib = _lib_()
         dev = coords_dev.device
+        ev = _prof_begin()
         tb = lib.scn_grid_build_temp_bytes(P)
         temp = torch.empty(tb, dtype=torch.uint8, device=dev)
         keys_sorted = torch.empty(P, dtype=torch.int64, device=dev)
@@ -152,6 +159,10 @@ class Metadata_3(object):
         check(lib.scn_grid_finalize(ptr(coords_dev), int(dtype_code), ncols, shift, P, N, ptr(keys_sorted),
                                     ptr(order), ptr(site_start), ptr(site_coords), ptr(site_keys),
                                     stream()))
+        # algorithmic bytes: coordinates read twice (keys, site coords), keys + order written and read by the ranking
+        # passes, site_of_row / site_start / site coords / site keys written (the radix sort's own passes not counted)
+        _prof_end(ev, "grid_build", 0.0, 2.0 * P * ncols * coords_dev.element_size() + P * (12 + 12 + 8) + N * 24.0,
+                  (P, N))
         return _Grid(N, site_coords, site_keys), order, site_of_row, site_start[:N + 1]
 
     def _hash(self, g):
@@ -272,10 +283,14 @@ class Metadata_3(object):
             counts = torch.empty(27, dtype=torch.int32, device=dev)
             tb = lib.scn_rules_temp_bytes(N, 27)
             temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+            ev = _prof_begin()
             check(lib.scn_submanifold_rules(ptr(g.coords), N, ptr(g.hash_keys), ptr(g.hash_vals), g.hash_cap,
                                             ptr(nbr), ptr(rules), ptr(counts), ptr(temp), tb, stream()))
             rb = _RuleBook(27, N, rules, counts)
-            rb.nbr = nbr
+            # read 16 N (coords), write + read the 27 probe results (2 x 108 N), write 8 R
+            _prof_end(ev, "sub_rules", 0.0, lambda rb=rb, N=N: 16.0 * N + 216.0 * N + 8.0 * (rb.total_pairs or 0), (N,))
+            if KEEP_NBR:  # the probe table (108 B/site) is scratch of the build; tests ask to see it
+                rb.nbr = nbr
             self._tile_bases(rb, 1, N)
             if not _defer:
                 rb.total_pairs = int(counts.sum().item())
@@ -308,8 +323,10 @@ class Metadata_3(object):
             counts = torch.empty(8, dtype=torch.int32, device=dev)
             tb = lib.scn_rules_temp_bytes(Nf, 8)
             temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+            ev = _prof_begin()
             check(lib.scn_strided_rules(ptr(fine.coords), Nf, ptr(coarse_of_fine), ptr(rules), ptr(counts),
                                         ptr(temp), tb, stream()))
+            _prof_end(ev, "strided_rules", 0.0, 2.0 * (16.0 + 4.0) * Nf + 8.0 * Nf, (Nf,))
             rb = _RuleBook(8, Nf, rules, counts)
             self._tile_bases(rb, 1, coarse.n)  # lists are also ascending in the coarse id
             self._tile_bases(rb, 0, Nf)
@@ -366,6 +383,37 @@ def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=Tr
 
 
 # ----------------------------------------------------------------- helpers ---
+# Weights re-laid out in MFMA fragment order (scn_weight_pack), cached per (weight tensor, transposed, reversed) and
+# re-packed only when the tensor's version counter moved: weights change once per optimizer step, not once per call
+# (in evaluation never).  In-place updates through `.data` do not move the counter: call invalidate_weight_cache().
+import weakref  # noqa: E402
+
+_WPACK = {}
+WPACK_CACHE = True
+
+
+def invalidate_weight_cache():
+    _WPACK.clear()
+
+
+def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
+    """returns (packed tensor, ready flag for scn_conv_forward)"""
+    base = weight._base if weight._base is not None else weight
+    key = (id(base), weight.data_ptr(), bool(w_transposed), bool(w_reverse))
+    ent = _WPACK.get(key) if WPACK_CACHE else None
+    if ent is not None and ent[0]() is base and ent[1] == weight._version and ent[2].numel() == K * Ci * Co:
+        return ent[2], 1
+    wpack = torch.empty(K * Ci * Co, dtype=torch.float32, device=weight.device)
+    if not WPACK_CACHE:
+        return wpack, 0
+    check(_lib_().scn_weight_pack(ptr(weight), int(w_transposed), int(w_reverse), K, Ci, Co, ptr(wpack), stream()))
+
+    def _drop(_ref, key=key):
+        _WPACK.pop(key, None)
+    _WPACK[key] = (weakref.ref(base, _drop), weight._version, wpack)
+    return wpack, 1
+
+
 def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False):
     """out = gather-mm-scatter over rb; weight is the module's [K, a, b] tensor, used as [K, Ci, Co]
     (forward) or, with w_transposed, as its per-offset transpose (dInput)."""
@@ -375,17 +423,23 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     assert K == rb.K, (K, rb.K)
     assert inp.is_contiguous() and weight.is_contiguous() and inp.size(1) == Ci
     out.resize_(n_out, Co)
-    wpack = torch.empty(K * Ci * Co, dtype=torch.float32, device=inp.device)
+    wpack, ready = _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co)
+    # launches with few output tiles split their offsets over workgroups; partial tiles go through this workspace
+    ws_bytes = lib.scn_conv_workspace_bytes(K, rb.stride, inp.size(0), n_out, Ci, Co)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=inp.device) if ws_bytes else None
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None,
                                ptr(rb.rules), ptr(rb.bases[out_col]), K, rb.stride, in_col, out_col, inp.size(0),
-                               n_out, Ci, Co, ptr(wpack), stream()))
+                               n_out, Ci, Co, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
     # algorithmic work of one launch: flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
-    R = rb.total_pairs
-    _prof_end(ev, "conv_tile", 2.0 * R * Ci * Co, 4.0 * (R * Ci + n_out * Co) + 8.0 * R + 4.0 * K * Ci * Co,
-              (K, n_out, Ci, Co, int(w_transposed)))
+    if ev is not None:
+        R = rb.total_pairs
+        code = lib.scn_conv_plan(K, rb.stride, inp.size(0), n_out, Ci, Co)
+        name = _CONV_KERNELS.get(code // 100, "conv") + ("_split" if code % 100 > 1 else "")
+        _prof_end(ev, name, 2.0 * R * Ci * Co, 4.0 * (R * Ci + n_out * Co) + 8.0 * R + 4.0 * K * Ci * Co,
+                  (K, n_out, Ci, Co, int(w_transposed), in_col))
 
 
 def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse):
@@ -405,8 +459,8 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
         check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts), K,
                                    rb.stride, in_col, out_col, inp.size(0), d_out.size(0), Ci, Co, stream()))
         R = rb.total_pairs
-        _prof_end(ev, "dw_tile", 2.0 * R * Ci * Co, 4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co,
-                  (K, inp.size(0), Ci, Co, 0))
+        _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else "dw_narrow", 2.0 * R * Ci * Co,
+                  4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
     if d_bias is not None and d_bias.numel():
         check(lib.scn_column_sum(ptr(d_out), ptr(d_bias), d_out.size(0), Co, stream()))
 
@@ -427,8 +481,10 @@ def InputLayer_updateOutput(m, spatialSize, input_coords, input_features, output
     N = m.nActive[m.inputSpatialSize]
     C = input_features.size(1)
     output_features.resize_(N, C)
+    ev = _prof_begin()
     check(_lib_().scn_input_forward(ptr(input_features.contiguous()), ptr(output_features), ptr(m.input_order),
                                     ptr(m.input_site_start), N, C, int(mode == 4), stream()))
+    _prof_end(ev, "io", 0.0, 4.0 * C * (m.input_P + N) + 4.0 * (m.input_P + N), (m.input_P, N, C))
 
 
 def InputLayer_updateGradInput(m, d_input_features, d_output_features):
@@ -436,9 +492,11 @@ def InputLayer_updateGradInput(m, d_input_features, d_output_features):
     _need_cuda(d_output_features, "InputLayer_updateGradInput")
     C = d_output_features.size(1)
     d_input_features.resize_(m.input_P, C)
+    ev = _prof_begin()
     check(_lib_().scn_input_backward(ptr(d_input_features), ptr(d_output_features.contiguous()),
                                      ptr(m.input_site_of_row), ptr(m.input_site_start), m.input_P, C,
                                      int(m.input_mode == 4), stream()))
+    _prof_end(ev, "io", 0.0, 8.0 * C * m.input_P + 12.0 * m.input_P, (m.input_P, 0, C))
 
 
 def OutputLayer_updateOutput(m, input_features, output_features):
@@ -446,8 +504,10 @@ def OutputLayer_updateOutput(m, input_features, output_features):
     _need_cuda(input_features, "OutputLayer_updateOutput")
     C = input_features.size(1)
     output_features.resize_(m.input_P, C)
+    ev = _prof_begin()
     check(_lib_().scn_output_forward(ptr(input_features.contiguous()), ptr(output_features),
                                      ptr(m.input_site_of_row), m.input_P, C, stream()))
+    _prof_end(ev, "io", 0.0, 8.0 * C * m.input_P + 4.0 * m.input_P, (m.input_P, 0, C))
 
 
 def OutputLayer_updateGradInput(m, d_input_features, d_output_features):
@@ -456,8 +516,10 @@ def OutputLayer_updateGradInput(m, d_input_features, d_output_features):
     C = d_output_features.size(1)
     N = m.nActive[m.inputSpatialSize]
     d_input_features.resize_(N, C)
+    ev = _prof_begin()
     check(_lib_().scn_output_backward(ptr(d_input_features), ptr(d_output_features.contiguous()),
                                       ptr(m.input_order), ptr(m.input_site_start), N, C, stream()))
+    _prof_end(ev, "io", 0.0, 4.0 * C * (m.input_P + N) + 4.0 * (m.input_P + N), (m.input_P, N, C))
 
 
 def SubmanifoldConvolution_updateOutput(spatialSize, filterSize, m, input_features, output_features, weight,
@@ -539,9 +601,11 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
     saveMean.resize_(C)
     saveInvStd.resize_(C)
     temp = _bn_temp(C, x.device)
+    ev = _prof_begin()
     check(_lib_().scn_bn_forward(ptr(x), ptr(output_features), ptr(saveMean), ptr(saveInvStd), ptr(runningMean),
                                  ptr(runningVar), ptr(weight), ptr(bias), float(eps), float(momentum), int(train),
                                  float(leakiness), N, C, ptr(temp), stream()))
+    _prof_end(ev, "bn_fwd", 0.0, (12.0 if train else 8.0) * N * C, (N, C))  # read, read, write
 
 
 def BatchNormalization_backward(input_features, d_input_features, output_features, d_output_features, saveMean,
@@ -558,10 +622,12 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     N, C = x.shape
     d_input_features.resize_(N, C)
     temp = _bn_temp(C, x.device)
+    ev = _prof_begin()
     check(_lib_().scn_bn_backward(ptr(x), ptr(d_input_features), ptr(output_features), ptr(d_output_features),
                                   ptr(saveMean), ptr(saveInvStd), ptr(weight), ptr(d_weight), ptr(d_bias),
                                   float(leakiness), N, C, int(bool(_rewrite_d_output)) | (2 if _accumulate else 0), ptr(temp),
                                   stream()))
+    _prof_end(ev, "bn_bwd", 0.0, 20.0 * N * C, (N, C))  # x, y, dOut read; dOut, dIn written
 
 
 _IDENTITY_RB = {}  # (n, device index) -> _RuleBook with the single list {(i, i)}; tiny LRU
@@ -639,7 +705,7 @@ def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weig
         check(_lib_().scn_conv_dweight(ptr(input_features.contiguous()), ptr(d_output_features.contiguous()),
                                        ptr(d_weight), ptr(rb.rules), ptr(rb.counts), 1, rb.stride, 0, 1, n, n, Ci, Co,
                                        stream()))
-        _prof_end(ev, "dw_tile", 2.0 * n * Ci * Co, 4.0 * n * (Ci + Co) + 8.0 * n + 4.0 * Ci * Co, (1, n, Ci, Co, 0))
+        _prof_end(ev, "dw_tile", 2.0 * n * Ci * Co, 4.0 * n * (Ci + Co) + 8.0 * n + 4.0 * Ci * Co, (1, n, Ci, Co, 0, 0))
         return
     if n:
         torch.mm(input_features.t(), d_output_features, out=d_weight)

@@ -30,10 +30,11 @@ SIGNATURES = {
     "scn_strided_rules": (c_int, [_P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "scn_tile_bases": (c_int, [_P, _P, c_int, c_int64, c_int, c_int64, _P, _P]),
     "scn_conv_wpack_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "scn_conv_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int]),
+    "scn_conv_plan": (c_int, [c_int, c_int64, c_int64, c_int64, c_int, c_int]),
+    "scn_weight_pack": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64,
-                                 c_int64, c_int, c_int, _P, _P]),
-    "scn_set_tuning": (c_int, [c_int, c_int]),
-    "scn_debug_stamps": (c_int, [_P]),
+                                 c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
     "scn_bn_temp_bytes": (c_size_t, [c_int]),
@@ -46,28 +47,58 @@ SIGNATURES = {
     "scn_output_backward": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
 }
 
+# only in libscn_hip_tuning.so (-DSCN_TUNING): variant selection, timing-only ablation builds, cycle stamps
+TUNING_SIGNATURES = {
+    "scn_set_tuning": (c_int, [c_int, c_int]),
+    "scn_debug_stamps": (c_int, [_P]),
+    "scn_peak_mfma_f32": (c_int, [_P, c_int, ctypes.POINTER(c_double), _P]),
+    "scn_peak_copy": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
+}
+TUNING_LIB_PATH = os.path.join(_HERE, "libscn_hip_tuning.so")
+ABI_VERSION = 2
+
 _lib = None
+
+
+def _open(path, signatures):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "occuseg_amd: %s is missing -- build it with `python -m occuseg_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.scn_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("occuseg_amd: %s has ABI version %d, expected %d" % (os.path.basename(path), got, ABI_VERSION))
+    return lib
 
 
 def load():
     """Load the library once; raise loudly if it has not been built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            "occuseg_amd: %s is missing -- build it with `python -m occuseg_amd.build` "
-            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
-        fn.restype = res
-        fn.argtypes = args
-    got = lib.scn_abi_version()
-    if got != 1:
-        raise RuntimeError("occuseg_amd: libscn_hip.so ABI version %d, expected 1" % got)
-    _lib = lib
-    return lib
+    if _lib is None:
+        _lib = _open(LIB_PATH, SIGNATURES)
+    return _lib
+
+
+def use_tuning_build():
+    """tools/ and the kernel-variant test only: route every call of this process through libscn_hip_tuning.so
+    (the same sources with -DSCN_TUNING: scn_set_tuning / scn_debug_stamps and the ablation instantiations).
+    Returns the handle; `use_product_build()` switches back."""
+    global _lib
+    sigs = dict(SIGNATURES)
+    sigs.update(TUNING_SIGNATURES)
+    _lib = _open(TUNING_LIB_PATH, sigs)
+    return _lib
+
+
+def use_product_build():
+    global _lib
+    _lib = None
+    return load()
 
 
 def check(status):

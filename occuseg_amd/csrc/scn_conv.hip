@@ -548,17 +548,26 @@ __global__ void __launch_bounds__(64 * NW * NWM)
       for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], seg[i]);
   }
   const int rows = (int)min((int64_t)M, n_out - o0);
-  if (ksplit == 1) {
-    for (int i = tid; i < rows * (COB / 4); i += NT) {
-      const int r = i / (COB / 4), c4 = i % (COB / 4);
-      *(float4 *)(out + (o0 + r) * Co + co0 + c4 * 4) = *(const float4 *)(o_tile + r * OS + c4 * 4);
+  // ksplit > 1: `out` is the launcher's workspace [ksplit][n_out][Co]; this workgroup's partial tile (zeros when it
+  // owns no offset here) goes to slab blockIdx.y and k_split_reduce adds the slabs in a FIXED order: no float
+  // atomics, the result does not depend on which workgroup finishes first.
+  float *dst = out + (int64_t)blockIdx.y * n_out * Co;
+  for (int i = tid; i < rows * (COB / 4); i += NT) {
+    const int r = i / (COB / 4), c4 = i % (COB / 4);
+    *(float4 *)(dst + (o0 + r) * Co + co0 + c4 * 4) = *(const float4 *)(o_tile + r * OS + c4 * 4);
+  }
+}
+
+// out[i] = part[0][i] + part[1][i] + ... + part[ksplit-1][i], always in this order
+__global__ void __launch_bounds__(256)
+    k_split_reduce(const float *__restrict__ part, float *__restrict__ out, int64_t total4, int ksplit) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    float4 a = ((const float4 *)part)[i];
+    for (int j = 1; j < ksplit; ++j) {
+      const float4 b = ((const float4 *)part)[(int64_t)j * total4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-  } else if (nphase > 0 || blockIdx.y == 0) {
-    // partial sums of an offset subset: `out` was zeroed by the launcher, float atomics combine them
-    for (int i = tid; i < rows * COB; i += NT) {
-      const int r = i / COB, c = i % COB;
-      unsafeAtomicAdd(out + (o0 + r) * Co + co0 + c, o_tile[r * OS + c]);
-    }
+    ((float4 *)out)[i] = a;
   }
 }
 
@@ -1225,14 +1234,67 @@ __global__ void __launch_bounds__(256)
 }  // namespace scn
 using namespace scn;
 
-static int g_conv_dbg = 0;
-static int g_dw_slices = 256;  // tuning key 5: dWeight slices over the longest list
-static int g_conv_small_policy = 1500;  // tuning key 4: launches with few tiles keep the 128 x 64 tile and split their
-                                        // offsets until there are this many workgroups (0 = the older rule, for A/B:
-                                        // 64 x 32 tiles first); +16-22 % on the three coarsest UNet levels
-static int g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile, never split offsets (A/B runs)
-static int g_conv_variant = 4;  // 1 = first synchronous kernel (kept for A/B runs), 2 = LDS-staged pipelined kernel for
-                                // every shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
+// ---- knobs.  The product library (libscn_hip.so) is built WITHOUT -DSCN_TUNING: every knob is a constant, the
+// ablation / stamp instantiations of the kernels do not exist in it and scn_set_tuning / scn_debug_stamps are not
+// exported.  tools/ use libscn_hip_tuning.so (same sources + -DSCN_TUNING, built next to it by occuseg_amd/build.py).
+#ifdef SCN_TUNING
+#define SCN_KNOB static int
+#else
+#define SCN_KNOB static constexpr int
+#endif
+SCN_KNOB g_conv_dbg = 0;       // tuning key 1: ablation / stamp build of the gather-mm kernels (timing only: wrong results)
+SCN_KNOB g_dw_dbg = 0;         // tuning key 6: ablation build of the dWeight kernel (timing only)
+SCN_KNOB g_dw_slices = 256;    // tuning key 5: dWeight slices over the longest list
+SCN_KNOB g_conv_small_policy = 1500;  // tuning key 4: launches with few tiles keep the 128 x 64 tile and split their
+                                      // offsets until there are this many workgroups (0 = the older rule, for A/B:
+                                      // 64 x 32 tiles first); +16-22 % on the three coarsest UNet levels
+SCN_KNOB g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile, never split offsets (A/B runs)
+SCN_KNOB g_conv_variant = 4;    // tuning key 0: 1 = first synchronous kernel, 2 = LDS-staged pipelined kernel for every
+                                // shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
+SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
+
+// Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.
+struct ConvPlan {
+  int kind;    // 0 generic (any planes), 1 first synchronous tile kernel, 2 k_conv_tile2, 4 k_conv_tile4
+  int nw;      // waves per workgroup = 16-plane slices per workgroup (kinds 1, 2)
+  int ksplit;  // kind 2: workgroups per (tile, plane block), each taking the offsets k == j (mod ksplit)
+  bool huge;   // > 4 GiB of input rows or packed weights: 32-bit buffer offsets do not reach
+};
+static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co) {
+  ConvPlan p{0, 0, 1, false};
+  if (Ci % 16 != 0 || Co % 16 != 0) return p;
+  // the pipelined kernels address `in` and the packed weights with unsigned 32-bit buffer offsets
+  p.huge = n_in * Ci * 4 >= ((int64_t)1 << 32) || (int64_t)K * Ci * Co * 4 >= ((int64_t)1 << 32);
+  const int s16 = Co / 16;
+  if (g_conv_variant == 1 || p.huge) {
+    p.kind = 1;
+    p.nw = s16 % 4 == 0 ? 4 : s16 % 3 == 0 ? 3 : s16 % 2 == 0 ? 2 : 1;
+    return p;
+  }
+  // Tile shape: 4 waves (128 rows x 64 planes) when that still yields >= 2 workgroups per CU; the
+  // coarse UNet levels (a few hundred to a few thousand sites) keep that tile and split their offsets.
+  auto blocks = [&](int nw) { return ((n_out + 32 * nw - 1) / (32 * nw)) * (int64_t)(Co / (16 * nw)); };
+  const int64_t want = 512;
+  if (g_conv_variant == 4 && s16 % 4 == 0 && Ci % 64 == 0 && Ci / 64 <= SCN_TILE4_MAX_CHUNKS && blocks(4) >= want &&
+      n_in < (1 << 24) && (int64_t)K * stride * 8 < (int64_t)0x7fffffff) {
+    p.kind = 4;
+    p.nw = 2;
+    return p;
+  }
+  p.kind = 2;
+  if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off || (g_conv_small_policy >= 1 && blocks(4) >= 8))) p.nw = 4;
+  else if (s16 % 3 == 0 && s16 % 2 != 0) p.nw = 3;
+  else if (s16 % 2 == 0 && (blocks(2) >= want || g_conv_small_off)) p.nw = 2;
+  else p.nw = 1;
+  // coarse UNet levels: too few tiles to fill 256 CUs and every workgroup walks all K offsets one after the other
+  // -> split the offsets over up to 27 workgroups per tile; their partial tiles are combined in a fixed order
+  const int64_t nblk = blocks(p.nw);
+  const int64_t target = (g_conv_small_policy >= 1 && p.nw == 4) ? g_conv_small_policy : 4096;
+  if (!g_conv_small_off && K > 1 && (p.nw < 4 || nblk < 512))
+    while (p.ksplit < 27 && nblk * p.ksplit < target) p.ksplit *= 3;
+  if (p.ksplit > K) p.ksplit = K;
+  return p;
+}
 
 template <int NW, int COS, int M, int CK>
 static int launch_tile(const float *in, float *out, const float *W, const float *bias,
@@ -1249,25 +1311,20 @@ static int launch_tile(const float *in, float *out, const float *W, const float 
 template <int NW, int COS, int CK, int NWM = 1, int M_ = 0>
 static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias,
                         const int32_t *rules, const int32_t *bases, int K, int64_t stride,
-                        int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, hipStream_t stream) {
+                        int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
+                        hipStream_t stream) {
   constexpr int M = M_ ? M_ : 32 * NW;
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / (NW * COS * 16);
   const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
-  // coarse UNet levels: too few tiles to fill 256 CUs and every workgroup walks all K offsets one
-  // after the other -> split the offsets over up to 27 workgroups per tile and combine with atomics
-  int ksplit = 1;
-  const int64_t target = (g_conv_small_policy >= 1 && NW == 4) ? g_conv_small_policy : 4096;
-  if (!g_conv_small_off && K > 1 && (NW < 4 || (int64_t)ntiles * ncb < 512))
-    while (ksplit < 27 && (int64_t)ntiles * ncb * ksplit < target) ksplit *= 3;
-  if (ksplit > K) ksplit = K;
-  if (ksplit > 1) SCN_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)n_out * Co * sizeof(float), stream));
+  float *dst = ksplit > 1 ? part : out;
   const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_T2(D)                                                                                   \
   k_conv_tile2<NW, COS, CK, D, NWM, M_><<<grid2, 64 * NW * NWM, 0, stream>>>(                             \
-      in, out, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit, \
+      in, dst, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit, \
       in_bytes, wp_bytes)
+#ifdef SCN_TUNING
   if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 9) SCN_LAUNCH_T2(9);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 27) SCN_LAUNCH_T2(27);
@@ -1281,13 +1338,20 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 512) SCN_LAUNCH_T2(512);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 260) SCN_LAUNCH_T2(260);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 258) SCN_LAUNCH_T2(258);
-  else SCN_LAUNCH_T2(0);
+  else
+#endif
+    SCN_LAUNCH_T2(0);
 #undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();
+  if (ksplit > 1) {
+    const int64_t total4 = n_out * Co / 4;
+    int64_t g = (total4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
+    SCN_CHECK_LAUNCH();
+  }
   return 0;
 }
-
-static int g_conv_wide = 0;  // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
@@ -1301,7 +1365,8 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   k_conv_tile4<D><<<(unsigned)(ntiles * ncb), 128, 0, stream>>>(in, out, Wp, bias, (const int2 *)rules, bases, K,   \
                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, \
                                                                 in_bytes, wp_bytes)
-  switch (g_conv_dbg) {  // ablation builds for tools/bench_conv.py and tools/stamps.py; 0 in production
+#ifdef SCN_TUNING
+  switch (g_conv_dbg) {  // ablation builds for tools/bench_conv.py and tools/stamps.py
     case 1: SCN_LAUNCH_TILE4(1); break;     // no scatter
     case 2: SCN_LAUNCH_TILE4(3); break;     // + no gather
     case 8: SCN_LAUNCH_TILE4(11); break;    // + no weights: loop skeleton + MFMAs
@@ -1313,6 +1378,9 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 8192: SCN_LAUNCH_TILE4(8192); break;  // A/B: unneeded loads point out of range instead of reading offset 0
     default: SCN_LAUNCH_TILE4(0);
   }
+#else
+  SCN_LAUNCH_TILE4(0);
+#endif
 #undef SCN_LAUNCH_TILE4
   SCN_CHECK_LAUNCH();
   return 0;
@@ -1321,16 +1389,20 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 template <int NW>
 static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias,
                            const int32_t *rules, const int32_t *bases, int K, int64_t stride,
-                           int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, hipStream_t stream) {
-  if (NW == 4 && g_conv_wide && Ci % 64 == 0 && Co % 128 == 0)
-    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
-  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
-  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
-  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
+                           int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
+                           hipStream_t stream) {
+#ifdef SCN_TUNING
+  if (NW == 4 && g_conv_wide && Ci % 64 == 0 && Co % 128 == 0 && ksplit == 1)
+    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, 1, part, stream);
+#endif
+  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
 }
 
 extern "C" {
 
+#ifdef SCN_TUNING
 // debugging aid: read (and clear) the per-segment cycle sums of the diagnostic kernel build
 int scn_debug_stamps(unsigned long long *out_host) {
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1340,78 +1412,91 @@ int scn_debug_stamps(unsigned long long *out_host) {
 }
 
 int scn_set_tuning(int key, int value) {
-  if (key == 0 && (value == 1 || value == 2 || value == 4)) {
-    g_conv_variant = value;
-    return 0;
-  }
-  if (key == 1) {
-    g_conv_dbg = value;
-    return 0;
-  }
-  if (key == 2) {
-    g_conv_wide = value;
-    return 0;
-  }
-  if (key == 4) {
-    g_conv_small_policy = value;
-    return 0;
-  }
-  if (key == 5 && value >= 1) {
-    g_dw_slices = value;
-    return 0;
-  }
-  if (key == 3) {
-    g_conv_small_off = value;
-    return 0;
-  }
+  if (key == 0 && (value == 1 || value == 2 || value == 4)) { g_conv_variant = value; return 0; }
+  if (key == 1) { g_conv_dbg = value; return 0; }
+  if (key == 2) { g_conv_wide = value; return 0; }
+  if (key == 3) { g_conv_small_off = value; return 0; }
+  if (key == 4) { g_conv_small_policy = value; return 0; }
+  if (key == 5 && value >= 1) { g_dw_slices = value; return 0; }
+  if (key == 6) { g_dw_dbg = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
+#endif
 
 size_t scn_conv_wpack_bytes(int K, int Ci, int Co) { return (size_t)K * Ci * Co * 4; }
+
+size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co) {
+  if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
+  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co);
+  return p.ksplit > 1 ? (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4 : 0;
+}
+
+int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co) {
+  if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
+  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co);
+  return 100 * p.kind + p.ksplit;
+}
+
+int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int Ci, int Co, void *wpack,
+                    void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(K >= 1 && K <= KMAX && Ci > 0 && Co > 0 && wpack != nullptr, "scn_weight_pack: bad arguments");
+  if (Ci % 16 != 0 || Co % 16 != 0) return 0;  // the generic kernel reads W itself
+  const int64_t total = (int64_t)K * Ci * Co;
+  int pg = (int)((total + 255) / 256);
+  if (pg > 2048) pg = 2048;
+  // fragment order for every kernel but the first synchronous one (which only the > 4 GiB fallback still uses)
+  const bool plain = g_conv_variant == 1 || total * 4 >= ((int64_t)1 << 32);
+  k_weight_pack<<<pg, 256, 0, stream>>>(W, (float *)wpack, K, Ci, Co, w_transposed, w_reverse, plain ? 0 : 1);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
 
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
                      const float *bias, const int32_t *rules, const int32_t *bases, int K,
                      int64_t stride, int in_col, int out_col, int64_t n_in, int64_t n_out, int Ci, int Co,
-                     void *wpack, void *stream_) {
+                     void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_forward: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_forward: in_col/out_col must be 0/1 or 1/0");
   SCN_REQUIRE(Ci > 0 && Co > 0, "scn_conv_forward: bad plane counts");
   if (n_out <= 0) return 0;
-  if (Ci % 16 == 0 && Co % 16 == 0) {
+  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co);
+  if (p.kind != 0) {
     SCN_REQUIRE(wpack != nullptr, "scn_conv_forward: wpack workspace required");
-    // the pipelined kernel addresses `in` and the packed weights with 32-bit buffer offsets
-    const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 31) || (int64_t)K * Ci * Co * 4 >= ((int64_t)1 << 31);
     float *Wp = (float *)wpack;
-    const int64_t total = (int64_t)K * Ci * Co;
-    int pg = (int)((total + 255) / 256);
-    if (pg > 2048) pg = 2048;
-    const int s16 = Co / 16;
-    if (g_conv_variant == 1 || huge) {
-      k_weight_pack<<<pg, 256, 0, stream>>>(W, Wp, K, Ci, Co, w_transposed, w_reverse, 0);
-      SCN_CHECK_LAUNCH();
-      if (s16 % 4 == 0) return launch_tile<4, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-      if (s16 % 3 == 0) return launch_tile<3, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-      if (s16 % 2 == 0) return launch_tile<2, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-      return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+    if (!wpack_ready) {
+      const int st = scn_weight_pack(W, w_transposed, w_reverse, K, Ci, Co, wpack, stream_);
+      if (st) return st;
     }
-    k_weight_pack<<<pg, 256, 0, stream>>>(W, Wp, K, Ci, Co, w_transposed, w_reverse, 1);
-    SCN_CHECK_LAUNCH();
-    // Tile shape: 4 waves (128 rows x 64 planes) when that still yields >= 2 workgroups per CU; the
-    // coarse UNet levels (a few hundred to a few thousand sites) get 64x32 or 32x16 tiles instead, so
-    // that all 256 CUs have work (their features and weights are L2 resident, the re-gather is free).
-    auto blocks = [&](int nw) { return ((n_out + 32 * nw - 1) / (32 * nw)) * (int64_t)(Co / (16 * nw)); };
-    const int64_t want = 512;
-    if (g_conv_variant == 4 && s16 % 4 == 0 && Ci % 64 == 0 && Ci / 64 <= SCN_TILE4_MAX_CHUNKS && blocks(4) >= want && n_in < (1 << 24) &&
-        (int64_t)K * stride * 8 < (int64_t)0x7fffffff)
-      return launch_tile4(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
-    if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off || (g_conv_small_policy >= 1 && blocks(4) >= 8)))
-      return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
-    if (s16 % 3 == 0 && s16 % 2 != 0)
-      return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
-    if (s16 % 2 == 0 && (blocks(2) >= want || g_conv_small_off))
-      return launch_tile2_ck<2>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
-    return launch_tile2_ck<1>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
+    if (p.kind == 1) {
+      if (p.huge) {  // say so once: this launch runs on the slow first kernel (~45 TFLOP/s instead of ~90)
+        static bool warned = false;
+        if (!warned) {
+          warned = true;
+          fprintf(stderr, "libscn_hip: warning: gather-mm input of %lld rows x %d planes (or its weights) exceeds the 4 GiB "
+                          "reach of 32-bit buffer offsets; using the synchronous fallback kernel (about half the "
+                          "throughput).  Split the batch to stay below 4 GiB per feature tensor.\n", (long long)n_in, Ci);
+        }
+      }
+      switch (p.nw) {
+        case 4: return launch_tile<4, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        case 3: return launch_tile<3, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        case 2: return launch_tile<2, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        default: return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+      }
+    }
+    if (p.kind == 4) return launch_tile4(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
+    if (p.ksplit > 1)
+      SCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4,
+                  "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
+    float *part = (float *)workspace;
+    switch (p.nw) {
+      case 4: return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 3: return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 2: return launch_tile2_ck<2>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      default: return launch_tile2_ck<1>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+    }
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)n_gran, (unsigned)((Co + 63) / 64));
@@ -1433,7 +1518,7 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_dweight: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_dweight: in_col/out_col must be 0/1 or 1/0");
   if (stride <= 0) return 0;
-  const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 31) || n_dout * Co * 4 >= ((int64_t)1 << 31);
+  const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 32) || n_dout * Co * 4 >= ((int64_t)1 << 32);
   if (Ci % 32 == 0 && Co % 32 == 0 && !huge) {
     const unsigned in_bytes = (unsigned)(n_in * Ci * 4), do_bytes = (unsigned)(n_dout * Co * 4);
     // slices per list: enough workgroups per (k, plane block) to fill the chip, few enough that the float atomics of
@@ -1445,13 +1530,15 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     const int gx = (int)((stride + per - 1) / per);
     if (Ci % 64 == 0 && Co % 64 == 0) {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 64) * (Co / 64));
-      if (g_conv_dbg == 100)  // A/B: 32 pairs per step
+#ifdef SCN_TUNING
+      if (g_dw_dbg == 100)  // A/B: 32 pairs per step
         k_dw_tile<2, 2, 32><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
-      else if (g_conv_dbg == 103)  // timing only: every row load reads row 0 (no gather traffic)
+      else if (g_dw_dbg == 103)  // timing only: every row load reads row 0 (no gather traffic)
         k_dw_tile<2, 2, 64, 1><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
-      else if (g_conv_dbg == 101)
+      else if (g_dw_dbg == 101)
         k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col + 2, Ci, Co, gx, in_bytes, do_bytes, -K);
       else
+#endif
         k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
     } else {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 32) * (Co / 32));

@@ -5,12 +5,22 @@ at all; batch-norm statistics stay per replica on p
 (SURVEY.md section 5): the reference semantics are single-GPU batch statistics.
 
 Gradients live in one contiguous buffer (parameters' .grad are views into it).  The buffer
-is cut into a few large contiguous buckets in parameter order; backward produces gradients
-in reverse order, so as soon as the FIRST parameter of a bucket has its gradient the whole
-bucket is final and its all-reduce is launched asynchronously, overlapping the rest of
-backward (the coarse UNet levels and the decoder finish first, the level-0 encoder last).
-xGMI is a point-to-point mesh: few, large messages (tens of MB) rather than per-tensor ones.
+is cut into a few large contiguous buckets in parameter order.  With ``enable_overlap()``
+every parameter reports when its gradient has been written (autograd's post-accumulate hook,
+or -- for the convolutions and batch norms, which accumulate straight into the flat buffer
+and hand autograd no gradient -- a direct call from their backward); a bucket's all-reduce is
+launched asynchronously when the LAST of its parameters has reported, whatever order backward
+visits them in, and overlaps the rest of backward (the coarse UNet levels and the decoder
+finish first, the level-0 encoder last).  A parameter that reports after its bucket was
+launched is an error, not a silent partial sum.  xGMI is a point-to-point mesh: few, large
+messages (tens of MB) rather than per-tensor ones.
+
+Use ``bucket.zero()`` instead of ``optimizer.zero_grad()``: the default ``set_to_none=True``
+detaches every ``.grad`` from the flat buffer (``zero()`` / ``all_reduce_mean()`` re-attach
+and say so if that happened).
 """
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -23,71 +33,144 @@ class FlatGradBucket(object):
         self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
         off = 0
         self.offsets = []
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+        self._index = {}
+        for i, p in enumerate(self.params):
             self.offsets.append(off)
+            self._index[id(p)] = i
             off += p.numel()
         # bucket boundaries at parameter boundaries, roughly equal sizes
-        self.buckets = []  # (start, end, index of first parameter)
+        self.buckets = []  # (start, end, first parameter index, last parameter index + 1)
+        self._bucket_of = [0] * len(self.params)
         target = (n + n_buckets - 1) // n_buckets
         start, first = 0, 0
         for i, p in enumerate(self.params):
             end = self.offsets[i] + p.numel()
             if end - start >= target or i == len(self.params) - 1:
-                self.buckets.append((start, end, first))
+                for j in range(first, i + 1):
+                    self._bucket_of[j] = len(self.buckets)
+                self.buckets.append((start, end, first, i + 1))
                 start, first = end, i + 1
         self._work = []
         self._hooks = []
         self._launched = set()
-        self._first_of = {}
-        # this object owns the (zeroed) gradient buffers: let the convolutions accumulate dWeight straight into them
-        from .sparseconvnet import conv as _conv
-        _conv.ACCUMULATE_INTO_GRAD = True
-        _conv.GRAD_WRITTEN = self._grad_written
+        self._overlap = False
+        self._remaining = []
+        self._reported = set()
+        self.launch_log = []  # (bucket, frozenset of parameter indices reported so far) per launch, for tests
+        self._attach()
+        # this object owns the (zeroed) gradient buffers of exactly these parameters: the convolutions and batch
+        # norms may accumulate their parameter gradients straight into them (per-parameter opt-in, nothing global)
+        for p in self.params:
+            p._scn_grad_owner = self
+        self._reset_counts()
 
-    def _grad_written(self, param):
-        """a convolution accumulated its weight gradient directly (no autograd hook fires for it)"""
-        b = self._first_of.get(id(param))
-        if b is not None:
-            self._launch(b)
+    # -- ownership of the .grad views -----------------------------------------
+    def _view(self, i):
+        p = self.params[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
 
+    def _attach(self):
+        """make every .grad a view of the flat buffer again; returns how many had been detached"""
+        fixed = 0
+        for i, p in enumerate(self.params):
+            g = p.grad
+            v = self._view(i)
+            if g is not None and g.data_ptr() == v.data_ptr() and g.is_contiguous():
+                continue
+            if g is not None:  # a foreign tensor (e.g. created by autograd after set_to_none): keep its values
+                v.copy_(g)
+            p.grad = v
+            fixed += 1
+        return fixed
+
+    def owns(self, param):
+        """True when param.grad is (still) this bucket's view: direct accumulation is safe"""
+        i = self._index.get(id(param))
+        g = param.grad
+        return (i is not None and g is not None and g.is_contiguous()
+                and g.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[i])
+
+    def close(self):
+        """give the parameters back: no direct accumulation, no hooks (the .grad views stay valid tensors)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._overlap = False
+        for p in self.params:
+            if getattr(p, "_scn_grad_owner", None) is self:
+                del p._scn_grad_owner
+
+    # -- overlap ----------------------------------------------------------------
     def _distributed(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
+    def _reset_counts(self):
+        self._remaining = [last - first for (_s, _e, first, last) in self.buckets]
+        self._reported = set()
+
     def enable_overlap(self):
-        """launch each bucket's all-reduce from a hook on the bucket's first parameter (the last of the
-        bucket to receive its gradient in backward)"""
-        if self._hooks:
+        """launch each bucket's all-reduce as soon as ALL of its parameters have reported their gradient (one
+        backward pass per step; with gradient accumulation over several backward passes leave overlap off)"""
+        if self._overlap:
             return
-        for b, (start, end, first) in enumerate(self.buckets):
-            def hook(_param, b=b):
-                self._launch(b)
-            self._hooks.append(self.params[first].register_post_accumulate_grad_hook(hook))
-            self._first_of[id(self.params[first])] = b
+        self._overlap = True
+        for i, p in enumerate(self.params):
+            def hook(_param, i=i):
+                self._written(i)
+            self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+
+    def grad_written(self, param):
+        """a convolution / batch norm accumulated this parameter's gradient directly (no autograd hook fires)"""
+        i = self._index.get(id(param))
+        if i is not None:
+            self._written(i)
+
+    def _written(self, i):
+        b = self._bucket_of[i]
+        if self._overlap and b in self._launched:
+            raise RuntimeError("FlatGradBucket: gradient of parameter %d written after the all-reduce of its bucket "
+                               "%d was launched (more than one backward pass per step with overlap enabled?)" % (i, b))
+        if not self._overlap or i in self._reported:
+            return
+        self._reported.add(i)
+        self._remaining[b] -= 1
+        if self._remaining[b] == 0:
+            self._launch(b)
 
     def _launch(self, b):
-        if b in self._launched or not self._distributed():
+        if b in self._launched:
             return
         self._launched.add(b)
-        start, end, _ = self.buckets[b]
+        self.launch_log.append((b, frozenset(self._reported)))
+        if not self._distributed():
+            return
+        start, end = self.buckets[b][:2]
         self._work.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, async_op=True))
 
     def zero(self):
+        """replacement for optimizer.zero_grad()"""
         self.flat.zero_()
+        if self._attach():
+            warnings.warn("FlatGradBucket: some .grad tensors had been detached from the flat buffer "
+                          "(optimizer.zero_grad(set_to_none=True)?) -- re-attached; use bucket.zero() instead")
         self._work = []
         self._launched = set()
+        self.launch_log = []
+        self._reset_counts()
 
     def all_reduce_mean(self):
-        """finish the exchange: launch whatever the hooks have not launched, wait, average.
-        No-op in a single-process run."""
-        if not self._distributed():
-            return
+        """finish the exchange: launch whatever has not been launched, wait, average.
+        No-op (besides the bookkeeping) in a single-process run."""
+        if self._attach():
+            warnings.warn("FlatGradBucket: some .grad tensors were not views of the flat buffer at all_reduce time "
+                          "-- their values were copied in; use bucket.zero() instead of zero_grad()")
         for b in range(len(self.buckets)):
             self._launch(b)
         for w in self._work:
             w.wait()
         self._work = []
-        self.flat.div_(dist.get_world_size())
+        if self._distributed():
+            self.flat.div_(dist.get_world_size())
 
 
 def shard(items, rank, world):

@@ -15,10 +15,19 @@ from . import counters
 from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTensorReturn, toLongTensor
 
 
-# Opt-in "fused weight-gradient accumulation" (see _RuleConvFunction.backward): set by the owner of the .grad
-# buffers; only valid when gradients are consumed through .grad (loss.backward()), not through torch.autograd.grad.
-ACCUMULATE_INTO_GRAD = False
-GRAD_WRITTEN = None  # optional callback(param) fired after a gradient was accumulated directly
+def grad_owner(*params):
+    """Opt-in "fused parameter-gradient accumulation" (see _RuleConvFunction.backward): the owner of the (zeroed) .grad
+    buffers (occuseg_amd.dp.FlatGradBucket) marks ITS parameters with ``_scn_grad_owner``; the backward kernels then
+    accumulate straight into ``param.grad`` and report to the owner.  Per parameter, nothing process-global; only
+    valid when gradients are consumed through .grad (loss.backward()), not through torch.autograd.grad.
+    Returns the owner when every given parameter has the same one and its .grad is still the owner's view."""
+    owner = getattr(params[0], "_scn_grad_owner", None)
+    if owner is None:
+        return None
+    for p in params:
+        if getattr(p, "_scn_grad_owner", None) is not owner or not owner.owns(p):
+            return None
+    return owner
 
 
 class _RuleConvFunction(Function):
@@ -51,9 +60,10 @@ class _RuleConvFunction(Function):
         # the reference always computes dInput; it is skipped here when autograd does not ask for it
         grad_input = like_empty(grad_output) if ctx.needs_input_grad[0] else None
         # The dWeight kernel ACCUMULATES (float atomics into a zeroed buffer, as the reference's does).  When the
-        # owner of the gradients says so (occuseg_amd.dp.FlatGradBucket: .grad are views of one zeroed flat buffer)
-        # it accumulates straight into weight.grad: no zeros_like, no autograd add kernel per parameter.
-        direct = ACCUMULATE_INTO_GRAD and weight.grad is not None and weight.grad.is_contiguous()
+        # owner of the gradients says so (occuseg_amd.dp.FlatGradBucket: .grad are views of one zeroed flat buffer,
+        # see grad_owner above) it accumulates straight into weight.grad: no zeros_like, no autograd add kernel.
+        owner = grad_owner(weight)
+        direct = owner is not None
         grad_weight = weight.grad if direct else torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
         m = ctx.scn_meta
@@ -68,8 +78,7 @@ class _RuleConvFunction(Function):
                                        grad_output, weight, grad_weight, grad_bias)
         ctx.scn_meta = None
         if direct:
-            if GRAD_WRITTEN is not None:
-                GRAD_WRITTEN(weight)
+            owner.grad_written(weight)
             grad_weight = None
         return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7
 
@@ -142,6 +151,8 @@ class Convolution(_RuleConv):
     def output_spatial_size(self, in_size):
         # integer division: sparseconvnet/convolution.py:35-38 relied on LongTensor `/` flooring (torch 1.1)
         out = (in_size - self.filter_size) // self.filter_stride + 1
+        # same check, same place as the reference's forward (sparseconvnet/convolution.py:36-37): a spatial size the
+        # stride does not divide is an AssertionError there too
         assert ((out - 1) * self.filter_stride + self.filter_size == in_size).all(), \
             (in_size, out, self.filter_size, self.filter_stride)
         return out
@@ -161,6 +172,4 @@ class Deconvolution(_RuleConv):
         return (in_size - 1) * self.filter_stride + self.filter_size
 
     def input_spatial_size(self, out_size):
-        in_size = (out_size - self.filter_size) // self.filter_stride + 1
-        assert ((in_size - 1) * self.filter_stride + self.filter_size == out_size).all()
-        return in_size
+        return (out_size - self.filter_size) // self.filter_stride + 1

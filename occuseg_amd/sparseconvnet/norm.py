@@ -36,17 +36,16 @@ class _BatchNormFunction(Function):
         grad_output = grad_output.contiguous()
         grad_input = like_empty(grad_output)
         # fused parameter-gradient accumulation, as in conv.py (the owner of the .grad buffers opts in)
-        direct = (conv.ACCUMULATE_INTO_GRAD and weight.numel() > 0 and bias.numel() > 0
-                  and weight.grad is not None and bias.grad is not None)
+        owner = conv.grad_owner(weight, bias) if weight.numel() > 0 and bias.numel() > 0 else None
+        direct = owner is not None
         grad_weight = weight.grad if direct else torch.zeros_like(weight)
         grad_bias = bias.grad if direct else torch.zeros_like(bias)
         SCN.BatchNormalization_backward(features, grad_input, out, grad_output, save_mean, save_invstd,
                                         running_mean, running_var, weight, bias, grad_weight, grad_bias,
                                         ctx.leakiness, _rewrite_d_output=False, _accumulate=direct)
         if direct:
-            if conv.GRAD_WRITTEN is not None:
-                conv.GRAD_WRITTEN(weight)
-                conv.GRAD_WRITTEN(bias)
+            owner.grad_written(weight)
+            owner.grad_written(bias)
             return (grad_input, None, None) + (None,) * 6
         return (grad_input, optionalTensorReturn(grad_weight), optionalTensorReturn(grad_bias)) + (None,) * 6
 

@@ -1,5 +1,8 @@
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -10,6 +13,45 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config._scn_jobs = {}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def pytest_collection_finish(session):
+    """tests/test_gpu_dp.py needs child processes that use the GPU.  They are started HERE, before any test (and so
+    before any HIP call in this process): a process that has initialised the GPU must not fork+exec on this pool."""
+    names = {item.name for item in session.items if item.fspath.basename == "test_gpu_dp.py"}
+    if not names or not os.path.exists("/dev/kfd"):
+        return
+    tmp = tempfile.mkdtemp(prefix="scn_dp_")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    jobs = session.config._scn_jobs
+    if "test_real_unet_under_process_group_world2" in names:
+        port = str(_free_port())
+        out = os.path.join(tmp, "dp_verdict.json")
+        log = os.path.join(tmp, "dp_rank%d.log")
+        procs = []
+        for rank in range(2):
+            e = dict(env, RANK=str(rank), WORLD_SIZE="2", MASTER_PORT=port)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out],
+                                          env=e, stdout=open(log % rank, "w"), stderr=subprocess.STDOUT))
+        jobs["dp"] = {"procs": procs, "out": out, "log": log}
+    if "test_bench_two_ranks_code_path" in names:
+        log = os.path.join(tmp, "bench2.log")
+        e = dict(env, SCN_BENCH_BACKEND="gloo", SCN_BENCH_ONE_DEVICE="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--m", "16",
+               "--sites", "5000", "--scenes-per-gpu", "2", "--no-cpu-baseline"]
+        jobs["bench2"] = {"procs": [subprocess.Popen(cmd, env=e, stdout=open(log, "w"), stderr=subprocess.STDOUT,
+                                                     cwd=ROOT)], "log": log}
 
 
 @pytest.fixture(scope="session")

@@ -23,7 +23,14 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()  # raises if the .so is missing or a symbol cannot be resolved
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.scn_abi_version() == 1
+    assert lib.scn_abi_version() == 2
+    # tuning / ablation entry points are not part of the product library (only of libscn_hip_tuning.so)
+    assert not hasattr(lib, "scn_set_tuning") and not hasattr(lib, "scn_debug_stamps")
+    assert os.path.exists(_lib.TUNING_LIB_PATH)
+    # launches with many output tiles need no workspace; a coarse level (few tiles) splits its offsets 9- or 27-fold
+    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64) == 0
+    ws = lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384)
+    assert ws % (2000 * 384 * 4) == 0 and ws // (2000 * 384 * 4) in (3, 9, 27)
     # size queries are host-only arithmetic: safe without a GPU
     assert lib.scn_hash_capacity(1000) == 2048
     assert lib.scn_conv_wpack_bytes(27, 64, 64) == 27 * 64 * 64 * 4

@@ -36,6 +36,10 @@ def _worker(rank, world, port, ret):
     net(x).sum().backward()
     if ret.get("overlap"):
         assert len(bucket._launched) == 2  # both buckets were sent from backward hooks
+        # ... and each only after EVERY one of its parameters had reported its gradient
+        for b, reported in bucket.launch_log:
+            first, last = bucket.buckets[b][2:]
+            assert set(range(first, last)) <= reported, (b, sorted(reported))
         local = None
     else:
         local = bucket.flat.clone()
@@ -66,6 +70,29 @@ def test_flat_gradient_allreduce_world2(overlap):
         ret["overlap"] = overlap
         mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert ret[0] is True and ret[1] is True
+
+
+def test_bucket_waits_for_every_parameter_whatever_the_order():
+    """The advisor's case: the FIRST parameter of a bucket reports before the others (a convolution weight whose
+    bias gradient arrives later through autograd).  The bucket must not launch until all of them have reported, and a
+    report after the launch is an error."""
+    from occuseg_amd import dp
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4))
+    b = dp.FlatGradBucket(net.parameters(), n_buckets=2)
+    b.enable_overlap()
+    params = list(net.parameters())
+    first, last = b.buckets[0][2:]
+    assert last - first >= 2
+    b.zero()
+    b.grad_written(params[first])          # direct accumulation reports the first parameter of bucket 0 ...
+    assert 0 not in b._launched            # ... the bucket is NOT complete yet
+    for i in range(first + 1, last):
+        b.grad_written(params[i])
+    assert 0 in b._launched and b.launch_log[0][1] >= set(range(first, last))
+    with pytest.raises(RuntimeError, match="written after the all-reduce"):
+        b.grad_written(params[first])
+    b.close()
+    assert not hasattr(params[0], "_scn_grad_owner")
 
 
 def test_bucket_is_a_noop_without_process_group():

@@ -41,7 +41,11 @@ def test_solid_block_2m_sites_m128(gpu):
     out = torch.empty(0, device=gpu)
     macs = SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x, out, w, torch.empty(0, device=gpu), 1)
     assert macs == float((3 * side - 2) ** 3) * ci * co
-    nb = (rb.nbr >= 0).sum(0).to(torch.float32)            # neighbours per site, from the device table
+    # neighbours per site from the rulebook itself: how often each site is an output over the 27 lists
+    nb = torch.zeros(n, device=gpu)
+    cnt = rb.counts.cpu().tolist()
+    for k in range(27):
+        nb.index_add_(0, rb.rules[k, :cnt[k], 1].long(), torch.ones(cnt[k], device=gpu))
     assert torch.equal(out[:, 0], nb * ci) and torch.equal(out[:, co - 1], nb * ci)
     assert float(out.sum().item()) == float((3 * side - 2) ** 3) * ci * co  # exact in fp32? (integers < 2^24 per term)
     # dInput of ones equals the forward by the k <-> 26-k symmetry; dWeight[k] = pairs_k everywhere

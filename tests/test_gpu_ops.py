@@ -220,8 +220,9 @@ def test_network_in_network(gpu, ci, co):
 @pytest.mark.parametrize("ci,co", [(64, 64), (128, 64), (64, 128), (320, 64)])
 def test_submanifold_forward_variants(gpu, ci, co):
     """The barrier-free two-wave forward kernel (default where it applies: >= 512 tiles, C_i a multiple of 64 up to
-    320, C_o a multiple of 64 -- hence the larger grid) and the LDS-staged kernel (scn_set_tuning(0, 2)) against
-    the float64 oracle and against each other."""
+    320, C_o a multiple of 64 -- hence the larger grid) and the LDS-staged kernel (scn_set_tuning(0, 2), which only
+    libscn_hip_tuning.so exports) against the float64 oracle and against each other; then the product library
+    against the tuning build's default (same sources, same kernel: bit-identical)."""
     from occuseg_amd import SCN, _lib
     from oracle import arith as A, rules as R
     m, size, grid, _, _ = _setup(gpu, seed=11, n=72000, batch=2, extent=60)
@@ -232,17 +233,23 @@ def test_submanifold_forward_variants(gpu, ci, co):
     w = (rng.normal(size=(27, ci, co)) * (2.0 / ci / 27) ** 0.5).astype(np.float32)
     b = rng.normal(size=co).astype(np.float32)
     want, macs = A.conv_forward(x, w, rules, grid.n, b, dtype=np.float64)
-    lib = _lib.load()
+    assert not hasattr(_lib.load(), "scn_set_tuning")  # the product library has no tuning entry points
     outs = {}
+    xt, wt, bt = _t(x, gpu), _t(w, gpu), _t(b, gpu)
     try:
+        lib = _lib.use_tuning_build()
         for variant in (4, 2):
             lib.scn_set_tuning(0, variant)
             out = torch.empty(0, device=gpu)
-            got = SCN.SubmanifoldConvolution_updateOutput(size, F3, m, _t(x, gpu), out, _t(w, gpu), _t(b, gpu), 1)
+            got = SCN.SubmanifoldConvolution_updateOutput(size, F3, m, xt, out, wt, bt, 1)
             assert got == macs
             outs[variant] = out.cpu().numpy()
-    finally:
         lib.scn_set_tuning(0, 4)
+    finally:
+        _lib.use_product_build()
+    out = torch.empty(0, device=gpu)
+    SCN.SubmanifoldConvolution_updateOutput(size, F3, m, xt, out, wt, bt, 1)
+    assert np.array_equal(out.cpu().numpy(), outs[4])
     assert_close(outs[4], want, "variant 4 forward %d->%d" % (ci, co))
     assert_close(outs[2], want, "variant 2 forward %d->%d" % (ci, co))
     # same per-(offset, chunk) summation order in both kernels: bit-identical

@@ -24,8 +24,10 @@ def _cases():
 
 
 @pytest.mark.parametrize("name,coords", list(_cases()), ids=[n for n, _ in _cases()])
-def test_rulebooks_bit_exact(gpu, name, coords):
+def test_rulebooks_bit_exact(gpu, name, coords, monkeypatch):
+    from occuseg_amd import SCN
     from oracle import rules as R
+    monkeypatch.setattr(SCN, "KEEP_NBR", True)  # the probe table is dropped after the build unless a test asks
     m, size = build_metadata(coords, gpu)
     grid, header, table, site_of_point = R.input_layer_rules(coords)
     # site order and coordinates
@@ -111,3 +113,24 @@ def test_float_and_int32_coordinates(gpu):
     a = layer([torch.from_numpy(cf).to(gpu), feats, None, 2])
     b = layer([torch.from_numpy(c64), feats, None, 2])
     assert torch.equal(a.features, b.features)
+
+
+def test_rulebooks_against_hand_derived_literal_vectors(gpu):
+    """The HIP path against tests/golden/literal_rules.py -- vectors written out by hand from the reference's CUDA
+    source (not produced by oracle/rules.py): site order, input rules, 27 + 8 lists, coarse grid, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import literal_rules as L
+    m, size = build_metadata(L.POINTS, gpu)
+    assert np.array_equal(m.getSpatialLocations(size).numpy(), L.SITE_COORDS)
+    h, t = m.getInputRulesHost()
+    assert np.array_equal(h, L.INPUT_HEADER) and np.array_equal(t, L.INPUT_TABLE)
+    assert np.array_equal(m.input_site_of_row.cpu().numpy().astype(np.int64), L.SITE_OF_POINT)
+    got = m.getSubmanifoldRuleBook(size, torch.tensor([3, 3, 3])).host_lists()
+    for k, want in enumerate(L.lists(L.SUBMANIFOLD, 27)):
+        assert np.array_equal(got[k], want), k
+    rb = m.getRuleBook(size, size // 2, torch.tensor([2, 2, 2]), torch.tensor([2, 2, 2]))
+    assert np.array_equal(m.getSpatialLocations(size // 2).numpy(), L.COARSE_COORDS)
+    for k, want in enumerate(L.lists(L.STRIDED, 8)):
+        assert np.array_equal(rb.host_lists()[k], want), k

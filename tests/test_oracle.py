@@ -213,3 +213,29 @@ def test_backward_formulas_match_autograd():
     assert_close(dxo, xb.grad.numpy(), "bn dInput", 1e-9)
     assert_close(dgo, g.grad.numpy(), "bn dWeight", 1e-9)
     assert_close(dbo, b.grad.numpy(), "bn dBias", 1e-9)
+
+
+def test_oracle_against_hand_derived_literal_vectors():
+    """oracle/rules.py against tests/golden/literal_rules.py: site order, input rules, 27 submanifold lists, coarse
+    grid and 8 strided lists written out BY HAND from the reference's CUDA source for a 9-site, 2-sample case that
+    includes coordinate 0 and the far corner of the key box (the aliasing pair).  Independent of both restatements."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import literal_rules as L
+    from oracle import bruteforce as BF, rules as R
+    grid, header, table, site_of_point = R.input_layer_rules(L.POINTS)
+    assert np.array_equal(grid.coords, L.SITE_COORDS)
+    assert np.array_equal(header, L.INPUT_HEADER) and np.array_equal(table, L.INPUT_TABLE)
+    assert np.array_equal(site_of_point, L.SITE_OF_POINT)
+    rules, _ = R.submanifold_rules(grid)
+    for k, (got, want) in enumerate(zip(rules, L.lists(L.SUBMANIFOLD, 27))):
+        assert np.array_equal(got, want), k
+    coarse, srules, _ = R.strided_rules(grid)
+    assert np.array_equal(coarse.coords, L.COARSE_COORDS)
+    for k, (got, want) in enumerate(zip(srules, L.lists(L.STRIDED, 8))):
+        assert np.array_equal(got, want), k
+    # the pairs the reference would add through its unchecked neighbour key: 19 + 15 + 15, all with in = site 6
+    extra = L.reference_alias_pairs()
+    assert sum(len(v) for v in extra.values()) == 49 and all(i == 6 for v in extra.values() for i, _ in v)
+    assert 13 not in extra and 26 not in extra and 22 not in extra

@@ -30,7 +30,7 @@ def step():
 
 def apply(name, val):
     if name.startswith("tune"):
-        _lib.load().scn_set_tuning(int(name[4:]), int(val))
+        _lib.use_tuning_build().scn_set_tuning(int(name[4:]), int(val))
     else:
         setattr(SCN, name, type(getattr(SCN, name))(int(val)))
 

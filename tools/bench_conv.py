@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--dw-variants", default="101,0,101,0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = _lib.load()
+    lib = _lib.use_tuning_build()
     coords, _ = scenes.batch([1000 + i for i in range(args.scenes)], args.sites)
     md = SCN.Metadata_3()
     size = torch.tensor([4096] * 3)
@@ -56,6 +56,7 @@ def main():
                 line = "L%d N=%d nu=%.1f SC %d->%d GF=%.1f:" % (lv, n, rb.total_pairs / n, ci, co, flops / 1e9)
                 for v in args.variants.split(","):
                     lib.scn_set_tuning(0, int(v) % 10)
+                    SCN.invalidate_weight_cache()  # variant 1 packs the weights in a different layout
                     lib.scn_set_tuning(1, (int(v) // 10) % 1000)
                     lib.scn_set_tuning(2, (int(v) // 10000) % 10)
                     lib.scn_set_tuning(4, int(v) // 100000)

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--dbg", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = _lib.load()
+    lib = _lib.use_tuning_build()
     coords, _ = scenes.batch([1000, 1001], args.sites)
     md = SCN.Metadata_3()
     size = torch.tensor([4096] * 3)
@@ -34,6 +34,7 @@ def main():
         outs = []
         for v in vs:
             lib.scn_set_tuning(0, v)
+            SCN.invalidate_weight_cache()  # variant 1 packs the weights in a different layout
             lib.scn_set_tuning(1, args.dbg if v == 4 else 0)
             out = torch.empty(0, device=dev)
             SCN._conv(x, out, w, b, rb, 0, 1, n)

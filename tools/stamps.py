@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from occuseg_amd import SCN, _lib, scenes
-dev = torch.device("cuda:0"); lib = _lib.load()
+dev = torch.device("cuda:0"); lib = _lib.use_tuning_build()
 coords, _ = scenes.batch([1000, 1001, 1002, 1003], 150000)
 md = SCN.Metadata_3(); size = torch.tensor([4096] * 3)
 md.inputLayer(size, torch.from_numpy(coords), 0, 4, dev)

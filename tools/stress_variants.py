@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = _lib.load()
+    lib = _lib.use_tuning_build()
     lib.scn_set_tuning(3, 1)  # launches with few tiles: no offset split (float atomics are not reproducible)
     rng = np.random.default_rng(args.seed)
     f3, f2 = torch.tensor([3, 3, 3]), torch.tensor([2, 2, 2])
@@ -59,6 +59,7 @@ def main():
         outs = []
         for v in (4, 2):
             lib.scn_set_tuning(0, v)
+            SCN.invalidate_weight_cache()  # variant 1 packs the weights in a different layout
             out = torch.empty(0, device=dev)
             SCN._conv(x, out, w, bias, rb, in_col, out_col, n_out, w_transposed=wt, w_reverse=wr)
             outs.append(out.clone())
