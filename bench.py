@@ -117,9 +117,12 @@ def measured_peaks(dev):
     dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     gbs = ctypes.c_double(0)
     _lib.check(lib.scn_peak_copy(src.data_ptr(), dst.data_ptr(), nbytes, 3, ctypes.byref(gbs), stream))
+    rd = ctypes.c_double(0)
+    _lib.check(lib.scn_peak_read(src.data_ptr(), scratch.data_ptr(), nbytes, 3, ctypes.byref(rd), stream))
     del src, dst
-    return {"f32_mfma_tflops": best_tf, "hbm_copy_GBs": gbs.value,
-            "how": "v_mfma_f32_16x16x4_f32 chains on every SIMD; float4 copy of 1 GiB (bytes read + written)"}
+    return {"f32_mfma_tflops": best_tf, "hbm_copy_GBs": gbs.value, "hbm_read_GBs": rd.value,
+            "how": "v_mfma_f32_16x16x4_f32 chains on every SIMD (1 and 2 waves per SIMD, best); float4 copy of 1 GiB "
+                   "(bytes read + written) and float4 read-only stream of 1 GiB, best of 3"}
 
 
 def main():
@@ -131,7 +134,9 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=4)
     ap.add_argument("--sites", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-every", type=int, default=4, help="time the kernels with HIP events on every n-th step")
+    ap.add_argument("--event-every", type=int, default=10,
+                    help="time the kernels with HIP events on every n-th step of the timed region (a timed event drains "
+                         "the queue between two kernels: ~1200 of them cost a profiled step ~25 ms)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="build each step's rulebooks inside the step instead of one step ahead on a side stream")
     ap.add_argument("--same-batch", action="store_true", help="replay ONE batch (round-1 behaviour) instead of alternating two")
@@ -247,7 +252,7 @@ def main():
             launches.append((kernel, shape, ms, flops, nbytes))
         sampled = len(range(0, args.steps, args.event_every))  # steps whose launches carry events
         peaks = measured_peaks(dev) if world == 1 else None
-        hbm_meas = peaks["hbm_copy_GBs"] if peaks else None
+        hbm_meas = max(peaks["hbm_copy_GBs"], peaks["hbm_read_GBs"]) if peaks else None
         kernels = {}
         for kname, (cnt, flops, nbytes, secs) in sorted(agg.items(), key=lambda kv: -kv[1][3]):
             k = {"launches_per_step": cnt / sampled, "ms_per_step": 1e3 * secs / sampled, "avg_ms": 1e3 * secs / cnt,
@@ -266,6 +271,24 @@ def main():
                 kernels[g] = {"ms_per_step": 1e3 * secs / sampled, "algo_bytes_per_step": nbytes / sampled,
                               "algo_GBs": nbytes / secs / 1e9, "hbm_frac": nbytes / secs / 1e9 / HBM_PEAK_GBS,
                               "members": [n for n in names if n in agg]}
+        if "rules" in kernels:
+            # inside the step the rule build runs on the side stream UNDER the step's big kernels (that is its point),
+            # so the event times above include waiting for CUs.  The same build alone on an idle GPU:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            alone = []
+            for b in batches + batches:
+                md = SCN.Metadata_3()
+                e0.record()
+                md.inputLayer(torch.tensor([4096] * 3), b[0], 0, 4, dev)  # grids + every rulebook of the recorded plan
+                e1.record()
+                torch.cuda.synchronize()
+                alone.append(e0.elapsed_time(e1))
+            kernels["rules"]["alone_ms_per_batch"] = min(alone)
+            kernels["rules"]["alone_algo_GBs"] = kernels["rules"]["algo_bytes_per_step"] / min(alone) / 1e6
+            kernels["rules"]["alone_hbm_frac"] = kernels["rules"]["alone_algo_GBs"] / HBM_PEAK_GBS
+            kernels["rules"]["note"] = ("ms_per_step: on the side stream, overlapped with and slowed by the step's "
+                                        "kernels; alone_*: the same build on an idle GPU, incl. its ~7 host syncs")
         mm = [k for k in agg if k.startswith(("conv_", "dw_"))]
         dom = max(mm, key=lambda k: agg[k][3]) if mm else None
         # HBM bytes per launch of the dominant kernel: rocprofv3 PMC counters cannot be read from inside this process;
@@ -297,7 +320,7 @@ def main():
             if peaks:
                 roof["peak_measured"] = peaks["f32_mfma_tflops"]
                 roof["frac_of_measured"] = achieved / peaks["f32_mfma_tflops"]
-                roof["hbm_peak_measured"] = peaks["hbm_copy_GBs"]
+                roof["hbm_peak_measured"] = hbm_meas
             # all gather-mm + dWeight launches together (what round 1 reported as "conv_tile")
             fl, se = sum(agg[k][1] for k in mm), sum(agg[k][3] for k in mm)
             roof["all_matrix_kernels"] = {"tflops": fl / se / 1e12, "frac": fl / se / 1e12 / F32_MFMA_PEAK_TFLOPS,

@@ -152,10 +152,12 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
 
 /* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller,
  * as the reference's callers do: sparseconvnet/submanifoldConvolution.py:114-115).
- * Replaces dConvolution_KMxKN_backward_dW_* (sparseconvnet/SCN/CUDA/Convolution.cu:265-442,:695-753). */
+ * Replaces dConvolution_KMxKN_backward_dW_* (sparseconvnet/SCN/CUDA/Convolution.cu:265-442,:695-753).
+ * bases: scn_tile_bases(.., out_col, n_dout) or NULL; with it, narrow inputs (Ci <= 4: the 3 -> m stem) are processed
+ * output-row major (every dOut row read once instead of once per pair). */
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
-                     const int32_t *counts, int K, int64_t stride, int in_col, int out_col,
-                     int64_t n_in, int64_t n_dout, int Ci, int Co, void *stream);
+                     const int32_t *counts, const int32_t *bases, int K, int64_t stride, int in_col,
+                     int out_col, int64_t n_in, int64_t n_dout, int Ci, int Co, void *stream);
 
 /* column sums: d_bias[c] = sum_rows dOut[r][c] (sparseconvnet/SCN/CUDA/Convolution.cu:52-75) */
 int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream);
@@ -167,9 +169,13 @@ int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream
  * temp: scn_bn_temp_bytes(C) bytes.  Backward flags: bit 0 (SCN_BN_REWRITE_D_OUT) = rewrite d_out in place with the
  * gradient masked by the (leaky) ReLU, as the reference does (BatchNormalization.cu:151-153); without it d_out is left
  * untouched and the masked gradient is staged in d_x instead (same traffic, and an autograd caller needs no private
- * copy).  Bit 1 (SCN_BN_ACCUMULATE_DPARAMS) = d_weight / d_bias += instead of = (the reference assigns). */
+ * copy).  Bit 1 (SCN_BN_ACCUMULATE_DPARAMS) = d_weight / d_bias += instead of = (the reference assigns).
+ * Bit 2 (SCN_BN_MASK_FROM_X) = do not read y at all (it may be NULL): the sign of y is recomputed from x with the forward
+ * pass's own arithmetic (y = fma(x, w, b), w = invstd*gamma, b = fma(-mean, w, beta): bit-identical), d_out is read
+ * twice and never written: 20 B per element instead of 28.  Needs `bias`; excludes bit 0. */
 #define SCN_BN_REWRITE_D_OUT 1
 #define SCN_BN_ACCUMULATE_DPARAMS 2
+#define SCN_BN_MASK_FROM_X 4
 size_t scn_bn_temp_bytes(int C);
 int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invstd,
                    float *running_mean, float *running_var, const float *weight,
@@ -177,8 +183,8 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
                    int64_t N, int C, void *temp, void *stream);
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
                     const float *save_mean, const float *save_invstd, const float *weight,
-                    float *d_weight, float *d_bias, double leakiness, int64_t N, int C,
-                    int flags, void *temp, void *stream);
+                    const float *bias, float *d_weight, float *d_bias, double leakiness, int64_t N,
+                    int C, int flags, void *temp, void *stream);
 
 /* ------------------------------------------------------ input / output ---
  * Replaces InputLayer_fp/bp (sparseconvnet/SCN/CUDA/IOLayers.cu:17-76) and the four wrappers of

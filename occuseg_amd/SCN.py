@@ -456,8 +456,9 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
             _conv(d_out, d_in, weight, None, rb, out_col, in_col, n_in, True, False)
     if d_weight is not None and d_weight.numel():
         ev = _prof_begin()
-        check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts), K,
-                                   rb.stride, in_col, out_col, inp.size(0), d_out.size(0), Ci, Co, stream()))
+        check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts),
+                                   ptr(rb.bases.get(out_col)), K, rb.stride, in_col, out_col, inp.size(0),
+                                   d_out.size(0), Ci, Co, stream()))
         R = rb.total_pairs
         _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else "dw_narrow", 2.0 * R * Ci * Co,
                   4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
@@ -610,12 +611,13 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
 
 def BatchNormalization_backward(input_features, d_input_features, output_features, d_output_features, saveMean,
                                 saveInvStd, runningMean, runningVar, weight, bias, d_weight, d_bias, leakiness,
-                                _rewrite_d_output=True, _accumulate=False):
+                                _rewrite_d_output=True, _accumulate=False, _mask_from_x=False):
     """sparseconvnet/SCN/sparseconvnet.h:27-32 -> sparseconvnet/SCN/CUDA/BatchNormalization.cpp:45-76.
     d_output_features must be contiguous: it is rewritten in place
     (sparseconvnet/SCN/CUDA/BatchNormalization.cu:151-153).  ``_rewrite_d_output=False`` (not in the reference;
     used by the autograd module, which must not mutate autograd's buffer) leaves it untouched; ``_accumulate=True``
-    adds to d_weight / d_bias instead of assigning."""
+    adds to d_weight / d_bias instead of assigning; ``_mask_from_x=True`` recomputes the sign of y from x instead of
+    reading ``output_features`` (bit-identical, 20 instead of 28 bytes per element; implies d_output untouched)."""
     _need_cuda(d_output_features, "BatchNormalization_backward")
     assert d_output_features.is_contiguous()
     x = input_features.contiguous()
@@ -623,10 +625,10 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     d_input_features.resize_(N, C)
     temp = _bn_temp(C, x.device)
     ev = _prof_begin()
+    flags = (4 if _mask_from_x else int(bool(_rewrite_d_output))) | (2 if _accumulate else 0)
     check(_lib_().scn_bn_backward(ptr(x), ptr(d_input_features), ptr(output_features), ptr(d_output_features),
-                                  ptr(saveMean), ptr(saveInvStd), ptr(weight), ptr(d_weight), ptr(d_bias),
-                                  float(leakiness), N, C, int(bool(_rewrite_d_output)) | (2 if _accumulate else 0), ptr(temp),
-                                  stream()))
+                                  ptr(saveMean), ptr(saveInvStd), ptr(weight), ptr(bias), ptr(d_weight), ptr(d_bias),
+                                  float(leakiness), N, C, flags, ptr(temp), stream()))
     _prof_end(ev, "bn_bwd", 0.0, 20.0 * N * C, (N, C))  # x, y, dOut read; dOut, dIn written
 
 
@@ -703,8 +705,8 @@ def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weig
         d_weight.zero_()
         ev = _prof_begin()
         check(_lib_().scn_conv_dweight(ptr(input_features.contiguous()), ptr(d_output_features.contiguous()),
-                                       ptr(d_weight), ptr(rb.rules), ptr(rb.counts), 1, rb.stride, 0, 1, n, n, Ci, Co,
-                                       stream()))
+                                       ptr(d_weight), ptr(rb.rules), ptr(rb.counts), ptr(rb.bases.get(1)), 1, rb.stride,
+                                       0, 1, n, n, Ci, Co, stream()))
         _prof_end(ev, "dw_tile", 2.0 * n * Ci * Co, 4.0 * n * (Ci + Co) + 8.0 * n + 4.0 * Ci * Co, (1, n, Ci, Co, 0, 0))
         return
     if n:

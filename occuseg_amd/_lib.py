@@ -35,12 +35,12 @@ SIGNATURES = {
     "scn_weight_pack": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64,
                                  c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
-    "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P]),
+    "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
     "scn_bn_temp_bytes": (c_size_t, [c_int]),
     "scn_bn_forward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_int, c_double,
                                c_int64, c_int, _P, _P]),
-    "scn_bn_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P]),
+    "scn_bn_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P]),
     "scn_input_forward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_input_backward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_output_forward": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
@@ -53,6 +53,7 @@ TUNING_SIGNATURES = {
     "scn_debug_stamps": (c_int, [_P]),
     "scn_peak_mfma_f32": (c_int, [_P, c_int, ctypes.POINTER(c_double), _P]),
     "scn_peak_copy": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
+    "scn_peak_read": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
 }
 TUNING_LIB_PATH = os.path.join(_HERE, "libscn_hip_tuning.so")
 ABI_VERSION = 2

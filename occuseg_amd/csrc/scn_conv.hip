@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(128)
                  const float *__restrict__ bias, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
-                 unsigned in_bytes, unsigned wp_bytes) {
+                 unsigned in_bytes, unsigned wp_bytes, int ksplit) {
   constexpr int M = 128, COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
   constexpr int TMAX = KMAX * 4 * SCN_TILE4_MAX_CHUNKS + 8;  // passes per tile: <= 4 per (offset, chunk); + sentinels
   __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
@@ -643,12 +643,14 @@ __global__ void __launch_bounds__(128)
   for (int i = lane; i < (M + 1) * 8; i += 64) {
     const int r = i >> 3, c4 = (i & 7) * 4;
     floatx4 v = {0.f, 0.f, 0.f, 0.f};
-    if (bias) v = *(const floatx4 *)(bias + co0 + 32 * w + c4);
+    if (bias && blockIdx.y == 0) v = *(const floatx4 *)(bias + co0 + 32 * w + c4);
     *(floatx4 *)(o_tile + r * OS + 32 * w + c4) = v;
   }
   if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
     int s = 0, c = 0;
-    if (tid < K) {
+    // ksplit > 1 (launches with few tiles, the coarse UNet levels): this workgroup takes the offsets k == blockIdx.y
+    // (mod ksplit) and writes its partial tile to slab blockIdx.y of the launcher's workspace (k_split_reduce adds them)
+    if (tid < K && tid % ksplit == (int)blockIdx.y) {
       s = bases[(int64_t)tid * (n_gran + 1) + g0];
       c = bases[(int64_t)tid * (n_gran + 1) + g1] - s;
     }
@@ -924,9 +926,10 @@ __global__ void __launch_bounds__(128)
     for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
   // each wave stores its own 32 planes: no barrier needed
   const int rows = (int)min((int64_t)M, n_out - o0);
+  float *dst = out + (int64_t)blockIdx.y * n_out * Co;
   for (int i = lane; i < rows * 8; i += 64) {
     const int r = i >> 3, c4 = (i & 7) * 4;
-    *(floatx4 *)(out + (o0 + r) * Co + co0 + 32 * w + c4) = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
+    *(floatx4 *)(dst + (o0 + r) * Co + co0 + 32 * w + c4) = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
   }
 }
 
@@ -944,9 +947,9 @@ __global__ void __launch_bounds__(256)
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [K][Ci][64] when W_IN_LDS
   __shared__ int src[KMAX][M];
   const int tid = threadIdx.x;
-  const int64_t o0 = (int64_t)blockIdx.x * M;
   const int cb = blockIdx.y * 64;
-  for (int i = tid; i < K * M; i += 256) src[i / M][i % M] = -1;
+  // the weights are staged ONCE per workgroup, which then walks granules blockIdx.x, blockIdx.x + gridDim.x, ...
+  // (one workgroup per 32 rows re-staged 20 KB of weights for every 8 KB of output: 0.43 ms for the 600k-site stem)
   if (W_IN_LDS)
     for (int i = tid; i < K * Ci * 64; i += 256) {
       const int k = i / (Ci * 64), r = i % (Ci * 64), ci = r / 64, co = cb + r % 64;
@@ -955,10 +958,14 @@ __global__ void __launch_bounds__(256)
       if (co < Co) v = w_transposed ? W[((int64_t)ks * Co + co) * Ci + ci] : W[((int64_t)ks * Ci + ci) * Co + co];
       wl[i] = v;
     }
+  for (int g = blockIdx.x; g < n_gran; g += gridDim.x) {
+  const int64_t o0 = (int64_t)g * M;
+  __syncthreads();  // weights staged / previous granule done with src[]
+  for (int i = tid; i < K * M; i += 256) src[i / M][i % M] = -1;
   __syncthreads();
   for (int k = 0; k < K; ++k) {
-    const int s = bases[(int64_t)k * (n_gran + 1) + blockIdx.x];
-    const int e = bases[(int64_t)k * (n_gran + 1) + blockIdx.x + 1];
+    const int s = bases[(int64_t)k * (n_gran + 1) + g];
+    const int e = bases[(int64_t)k * (n_gran + 1) + g + 1];
     const int2 *rk = rules + (int64_t)k * stride;
     for (int j = s + tid; j < e; j += 256) {
       const int2 p = rk[j];
@@ -1027,6 +1034,7 @@ __global__ void __launch_bounds__(256)
       for (int c = 0; c < 8; ++c)
         if (cb + cg + c < Co) op[c] = acc[c];
     }
+  }
   }
 }
 
@@ -1200,6 +1208,78 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// dW for narrow inputs, OUTPUT-ROW major (used when the caller passes the tile-base table of the dOut column): every dOut
+// row is read ONCE and meets the <= K narrow input rows of its neighbours, instead of once per pair (2 GB of dOut reads for
+// the 600k-site stem, 0.62 ms; 0.15 GB here).  Workgroups are persistent: per granule of 32 rows the tile's segments are
+// inverted into an LDS table src[k][row] (as the generic forward kernel does), wave w takes rows 8w..8w+7, lane = output
+// plane; lane k < K fetches the input row of offset k, the values reach all lanes through v_readlane.  The K x CI
+// accumulators per plane live in registers over all granules; one LDS reduction over the 4 waves and one float atomic
+// per (k, c, plane) and workgroup at the end.
+template <int CI>
+__global__ void __launch_bounds__(256)
+    k_dw_rows(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+              const int2 *__restrict__ rules, const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+              int n_gran, int64_t n_dout, int Co) {
+  constexpr int M = SCN_TILE_GRANULE;
+  __shared__ int src[KMAX][M];
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int co = blockIdx.y * 64 + lane;
+  float acc[KMAX][CI];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[k][c] = 0.f;
+  for (int g = blockIdx.x; g < n_gran; g += gridDim.x) {
+    const int64_t o0 = (int64_t)g * M;
+    __syncthreads();
+    for (int i = tid; i < K * M; i += 256) src[i / M][i % M] = -1;
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+      const int s = bases[(int64_t)k * (n_gran + 1) + g];
+      const int e = bases[(int64_t)k * (n_gran + 1) + g + 1];
+      const int2 *rk = rules + (int64_t)k * stride;
+      for (int j = s + tid; j < e; j += 256) {
+        const int2 p = rk[j];
+        src[k][(int)((in_col ? p.x : p.y) - o0)] = in_col ? p.y : p.x;
+      }
+    }
+    __syncthreads();
+    // 8 rows per wave: all their loads are requested before the first FMA (8 independent LDS -> global chains)
+    int sidx[8];
+    float d[8], x[8][CI];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = w * 8 + u;
+      sidx[u] = lane < K ? src[lane][r] : -1;
+      d[u] = (o0 + r < n_dout && co < Co) ? dout[(o0 + r) * Co + co] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) x[u][c] = sidx[u] >= 0 ? in[(int64_t)sidx[u] * CI + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K && __builtin_amdgcn_readlane(sidx[u], k) >= 0) {
+#pragma unroll
+          for (int c = 0; c < CI; ++c)
+            acc[k][c] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[u][c]), k)) * d[u];
+        }
+  }
+  // 4 waves hold partial sums for the same planes
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      if (k >= K) continue;
+      __syncthreads();
+      red[w][lane] = acc[k][c];
+      __syncthreads();
+      if (w == 0 && co < Co)
+        unsafeAtomicAdd(dW + ((int64_t)k * CI + c) * Co + co, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    }
+}
+
 // generic dW (any Ci, Co): block = (pair chunk, k); threads stride over (ci, co)
 __global__ void __launch_bounds__(256)
     k_dw_generic(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
@@ -1251,6 +1331,7 @@ SCN_KNOB g_conv_small_policy = 1500;  // tuning key 4: launches with few tiles k
 SCN_KNOB g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile, never split offsets (A/B runs)
 SCN_KNOB g_conv_variant = 4;    // tuning key 0: 1 = first synchronous kernel, 2 = LDS-staged pipelined kernel for every
                                 // shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
+SCN_KNOB g_conv_small_tile4 = 1;  // tuning key 7: 0 = launches with few tiles use k_conv_tile2 with the offset split (A/B)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 // Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.
@@ -1280,6 +1361,21 @@ static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, in
     p.kind = 4;
     p.nw = 2;
     return p;
+  }
+  // few tiles (coarse UNet levels): the same barrier-free kernel with the offsets split 3-, 9- or 27-fold over workgroups,
+  // as long as the pass table of one workgroup (<= 4 passes per offset and C_i chunk) fits
+  if (g_conv_small_tile4 && g_conv_variant == 4 && !g_conv_small_off && K > 1 && s16 % 4 == 0 && Ci % 64 == 0 && Ci / 64 <= 15 &&
+      blocks(4) >= 8 && blocks(4) < want && n_in < (1 << 24) && (int64_t)K * stride * 8 < (int64_t)0x7fffffff) {
+    int ks = 1;
+    while (ks < 27 && blocks(4) * ks < g_conv_small_policy) ks *= 3;
+    if (ks > K) ks = K;
+    const int per_wg = (K + ks - 1) / ks;
+    if (ks > 1 && per_wg * 4 * (Ci / 64) + 8 <= KMAX * 4 * SCN_TILE4_MAX_CHUNKS + 8) {
+      p.kind = 4;
+      p.nw = 2;
+      p.ksplit = ks;
+      return p;
+    }
   }
   p.kind = 2;
   if (s16 % 4 == 0 && (blocks(4) >= want || g_conv_small_off || (g_conv_small_policy >= 1 && blocks(4) >= 8))) p.nw = 4;
@@ -1355,16 +1451,18 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
 
 static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
-                        int Ci, int Co, hipStream_t stream) {
+                        int Ci, int Co, int ksplit, float *part, hipStream_t stream) {
   constexpr int M = 128;
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / 64;
   const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
+  float *dst4 = ksplit > 1 ? part : out;
+  const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_TILE4(D)                                                                                         \
-  k_conv_tile4<D><<<(unsigned)(ntiles * ncb), 128, 0, stream>>>(in, out, Wp, bias, (const int2 *)rules, bases, K,   \
-                                                                stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, \
-                                                                in_bytes, wp_bytes)
+  k_conv_tile4<D><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, (const int2 *)rules, bases, K,                     \
+                                             stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
+                                             in_bytes, wp_bytes, ksplit)
 #ifdef SCN_TUNING
   switch (g_conv_dbg) {  // ablation builds for tools/bench_conv.py and tools/stamps.py
     case 1: SCN_LAUNCH_TILE4(1); break;     // no scatter
@@ -1383,6 +1481,13 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 #endif
 #undef SCN_LAUNCH_TILE4
   SCN_CHECK_LAUNCH();
+  if (ksplit > 1) {
+    const int64_t total4 = n_out * Co / 4;
+    int64_t g = (total4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
+    SCN_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -1419,6 +1524,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 4) { g_conv_small_policy = value; return 0; }
   if (key == 5 && value >= 1) { g_dw_slices = value; return 0; }
   if (key == 6) { g_dw_dbg = value; return 0; }
+  if (key == 7) { g_conv_small_tile4 = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
 #endif
@@ -1486,11 +1592,12 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
         default: return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
       }
     }
-    if (p.kind == 4) return launch_tile4(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, stream);
     if (p.ksplit > 1)
       SCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4,
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     float *part = (float *)workspace;
+    if (p.kind == 4)
+      return launch_tile4(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
     switch (p.nw) {
       case 4: return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
       case 3: return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
@@ -1499,7 +1606,7 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     }
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
-  dim3 grid((unsigned)n_gran, (unsigned)((Co + 63) / 64));
+  dim3 grid((unsigned)(n_gran < 2048 ? n_gran : 2048), (unsigned)((Co + 63) / 64));  // persistent: weights staged once
   const size_t wbytes = (size_t)K * Ci * 64 * 4;
   if (wbytes <= 40 * 1024)
     k_conv_generic<true><<<grid, 256, wbytes, stream>>>(in, out, W, bias, (const int2 *)rules, bases, K, stride,
@@ -1512,7 +1619,7 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
 }
 
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
-                     const int32_t *counts, int K, int64_t stride, int in_col, int out_col,
+                     const int32_t *counts, const int32_t *bases, int K, int64_t stride, int in_col, int out_col,
                      int64_t n_in, int64_t n_dout, int Ci, int Co, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_dweight: filter volume must be 1..27");
@@ -1543,6 +1650,18 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     } else {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 32) * (Co / 32));
       k_dw_tile<1, 1, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+    }
+    SCN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (Ci >= 1 && Ci <= 4 && bases != nullptr && n_dout > 0) {
+    const int n_gran = (int)((n_dout + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+    dim3 grid((unsigned)(n_gran < 1024 ? n_gran : 1024), (unsigned)((Co + 63) / 64));
+    switch (Ci) {
+      case 1: k_dw_rows<1><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+      case 2: k_dw_rows<2><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+      case 3: k_dw_rows<3><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+      default: k_dw_rows<4><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co);
     }
     SCN_CHECK_LAUNCH();
     return 0;

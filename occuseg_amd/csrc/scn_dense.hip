@@ -121,9 +121,11 @@ __global__ void __launch_bounds__(256)
   }
   save_mean[c] = mean;
   save_invstd[c] = invstd;
+  // y = fma(x, w, b) with b = fma(-mean, w, beta): written with explicit fma here, in k_bn_apply and in the backward
+  // kernels, so that the backward pass can recompute the sign of y from x bit for bit (SCN_BN_MASK_FROM_X)
   const float w = invstd * (weight ? weight[c] : 1.f);
   wb[c] = w;
-  wb[C + c] = -mean * w + (bias ? bias[c] : 0.f);
+  wb[C + c] = fmaf(-mean, w, bias ? bias[c] : 0.f);
 }
 
 template <int VEC>
@@ -136,49 +138,73 @@ __global__ void __launch_bounds__(256)
       const float4 w = *(const float4 *)(wb + c);
       const float4 b = *(const float4 *)(wb + C + c);
       float4 o;
-      o.x = v.x * w.x + b.x; o.y = v.y * w.y + b.y; o.z = v.z * w.z + b.z; o.w = v.w * w.w + b.w;
+      o.x = fmaf(v.x, w.x, b.x); o.y = fmaf(v.y, w.y, b.y); o.z = fmaf(v.z, w.z, b.z); o.w = fmaf(v.w, w.w, b.w);
       o.x = o.x > 0 ? o.x : o.x * leak; o.y = o.y > 0 ? o.y : o.y * leak;
       o.z = o.z > 0 ? o.z : o.z * leak; o.w = o.w > 0 ? o.w : o.w * leak;
       ((float4 *)y)[i] = o;
     } else {
-      float o = x[i] * wb[c] + wb[C + c];
+      float o = fmaf(x[i], wb[c], wb[C + c]);
       y[i] = o > 0 ? o : o * leak;
     }
   }
 }
 
-// backward pass 1: masked gradient -> d_masked (d_out itself = the reference's in-place rewrite, or d_x),
-// reduce sum(d) and sum((x-mean) d)   (sparseconvnet/SCN/CPU/BatchNormalization.cpp:75-87)
-template <int VEC>
+// backward pass 1: masked gradient, reduce sum(d) and sum((x-mean) d)   (sparseconvnet/SCN/CPU/BatchNormalization.cpp:75-87)
+// FROM_X = false: mask from y as the reference does, masked gradient written to d_masked (d_out itself = the
+//                 reference's in-place rewrite, or d_x).  16 B per element.
+// FROM_X = true : the sign of y is recomputed from x with the forward pass's own arithmetic (same fma, same w and b:
+//                 bit-identical), nothing is written and y is not read.  8 B per element.
+template <int VEC, bool FROM_X>
 __global__ void __launch_bounds__(256)
     k_bn_bwd_stats(const float *x, const float *y, const float *d_out, float *d_masked, const float *save_mean,
+                   const float *save_invstd, const float *weight, const float *bias,
                    int64_t N, int C, float leak, float *partial) {
   bn_reduce_rows<VEC>(N, C, partial, [&](int64_t r, int c, float *a, float *b) {
     const int64_t o = r * C + c;
+    float xv[VEC], d[VEC], m[VEC];
     if (VEC == 4) {
-      const float4 xv = *(const float4 *)(x + o);
-      const float4 yv = *(const float4 *)(y + o);
-      float4 d = *(const float4 *)(d_out + o);
-      const float4 m = *(const float4 *)(save_mean + c);
-      d.x *= yv.x > 0 ? 1.f : leak; d.y *= yv.y > 0 ? 1.f : leak;
-      d.z *= yv.z > 0 ? 1.f : leak; d.w *= yv.w > 0 ? 1.f : leak;
-      *(float4 *)(d_masked + o) = d;
-      a[0] += d.x; a[1 % VEC] += d.y; a[2 % VEC] += d.z; a[3 % VEC] += d.w;
-      b[0] += (xv.x - m.x) * d.x; b[1 % VEC] += (xv.y - m.y) * d.y;
-      b[2 % VEC] += (xv.z - m.z) * d.z; b[3 % VEC] += (xv.w - m.w) * d.w;
+      const float4 t = *(const float4 *)(x + o), u = *(const float4 *)(d_out + o), v = *(const float4 *)(save_mean + c);
+      xv[0] = t.x; xv[1 % VEC] = t.y; xv[2 % VEC] = t.z; xv[3 % VEC] = t.w;
+      d[0] = u.x; d[1 % VEC] = u.y; d[2 % VEC] = u.z; d[3 % VEC] = u.w;
+      m[0] = v.x; m[1 % VEC] = v.y; m[2 % VEC] = v.z; m[3 % VEC] = v.w;
     } else {
-      float d = d_out[o] * (y[o] > 0 ? 1.f : leak);
-      d_masked[o] = d;
-      a[0] += d;
-      b[0] += (x[o] - save_mean[c]) * d;
+      xv[0] = x[o]; d[0] = d_out[o]; m[0] = save_mean[c];
+    }
+    if (FROM_X) {
+      if (leak != 1.f) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float w = save_invstd[c + i] * (weight ? weight[c + i] : 1.f);
+          const float yy = fmaf(xv[i], w, fmaf(-m[i], w, bias ? bias[c + i] : 0.f));
+          d[i] *= yy > 0 ? 1.f : leak;
+        }
+      }
+    } else {
+      float yv[VEC];
+      if (VEC == 4) {
+        const float4 t = *(const float4 *)(y + o);
+        yv[0] = t.x; yv[1 % VEC] = t.y; yv[2 % VEC] = t.z; yv[3 % VEC] = t.w;
+      } else {
+        yv[0] = y[o];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) d[i] *= yv[i] > 0 ? 1.f : leak;
+      if (VEC == 4) *(float4 *)(d_masked + o) = make_float4(d[0], d[1 % VEC], d[2 % VEC], d[3 % VEC]);
+      else d_masked[o] = d[0];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      a[i] += d[i];
+      b[i] += (xv[i] - m[i]) * d[i];
     }
   });
 }
 
-// (sparseconvnet/SCN/CPU/BatchNormalization.cpp:88-93,:103-106); coef = [gradMean | k | invstd*gamma]
+// (sparseconvnet/SCN/CPU/BatchNormalization.cpp:88-93,:103-106); coef = [gradMean | k | invstd*gamma | w | b]
 __global__ void __launch_bounds__(256)
-    k_bn_bwd_finalize(const float *partial, int nblk, int64_t N, int C, const float *save_invstd,
-                      const float *weight, float *d_weight, float *d_bias, float *coef, int accumulate) {
+    k_bn_bwd_finalize(const float *partial, int nblk, int64_t N, int C, const float *save_mean, const float *save_invstd,
+                      const float *weight, const float *bias, float *d_weight, float *d_bias, float *coef,
+                      int accumulate) {
   int c;
   double s = 0, dp = 0;
   if (!bn_sum_partials(partial, nblk, C, c, s, dp)) return;
@@ -187,22 +213,31 @@ __global__ void __launch_bounds__(256)
   if (d_weight) d_weight[c] = (accumulate ? d_weight[c] : 0.f) + (float)(dp * (double)invstd);
   coef[c] = (float)(s / (double)N);
   coef[C + c] = (float)(dp * (double)invstd * (double)invstd / (double)N);
-  coef[2 * C + c] = invstd * (weight ? weight[c] : 1.f);
+  const float w = invstd * (weight ? weight[c] : 1.f);
+  coef[2 * C + c] = w;
+  coef[3 * C + c] = w;                                                  // forward's w ...
+  coef[4 * C + c] = fmaf(-save_mean[c], w, bias ? bias[c] : 0.f);       // ... and b: y = fma(x, w, b)
 }
 
-template <int VEC>
+template <int VEC, bool FROM_X>
 __global__ void __launch_bounds__(256)
     k_bn_bwd_apply(const float *x, const float *d_out, float *d_x, const float *save_mean,
-                   int64_t total_vec, int C, const float *coef) {
+                   int64_t total_vec, int C, const float *coef, float leak) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)((i * VEC) % C);
     if (VEC == 4) {
       const float4 xv = ((const float4 *)x)[i];
-      const float4 d = ((const float4 *)d_out)[i];
+      float4 d = ((const float4 *)d_out)[i];
       const float4 m = *(const float4 *)(save_mean + c);
       const float4 gm = *(const float4 *)(coef + c);
       const float4 kk = *(const float4 *)(coef + C + c);
       const float4 sc = *(const float4 *)(coef + 2 * C + c);
+      if (FROM_X && leak != 1.f) {  // d_out is the raw gradient: apply the (leaky) ReLU mask recomputed from x
+        const float4 w = *(const float4 *)(coef + 3 * C + c);
+        const float4 b = *(const float4 *)(coef + 4 * C + c);
+        d.x *= fmaf(xv.x, w.x, b.x) > 0 ? 1.f : leak; d.y *= fmaf(xv.y, w.y, b.y) > 0 ? 1.f : leak;
+        d.z *= fmaf(xv.z, w.z, b.z) > 0 ? 1.f : leak; d.w *= fmaf(xv.w, w.w, b.w) > 0 ? 1.f : leak;
+      }
       float4 o;
       o.x = (d.x - gm.x - (xv.x - m.x) * kk.x) * sc.x;
       o.y = (d.y - gm.y - (xv.y - m.y) * kk.y) * sc.y;
@@ -210,7 +245,9 @@ __global__ void __launch_bounds__(256)
       o.w = (d.w - gm.w - (xv.w - m.w) * kk.w) * sc.w;
       ((float4 *)d_x)[i] = o;
     } else {
-      d_x[i] = (d_out[i] - coef[c] - (x[i] - save_mean[c]) * coef[C + c]) * coef[2 * C + c];
+      float d = d_out[i];
+      if (FROM_X && leak != 1.f) d *= fmaf(x[i], coef[3 * C + c], coef[4 * C + c]) > 0 ? 1.f : leak;
+      d_x[i] = (d - coef[c] - (x[i] - save_mean[c]) * coef[C + c]) * coef[2 * C + c];
     }
   }
 }
@@ -314,7 +351,7 @@ using namespace scn;
 
 extern "C" {
 
-size_t scn_bn_temp_bytes(int C) { return ((size_t)BN_MAX_BLOCKS * 2 * C + 3 * (size_t)C) * 4 + 256; }
+size_t scn_bn_temp_bytes(int C) { return ((size_t)BN_MAX_BLOCKS * 2 * C + 5 * (size_t)C) * 4 + 256; }
 
 int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invstd,
                    float *running_mean, float *running_var, const float *weight,
@@ -348,28 +385,41 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
 }
 
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
-                    const float *save_mean, const float *save_invstd, const float *weight,
+                    const float *save_mean, const float *save_invstd, const float *weight, const float *bias,
                     float *d_weight, float *d_bias, double leakiness, int64_t N, int C,
                     int flags, void *temp, void *stream_) {
-  const int rewrite_d_out = flags & 1, accumulate = (flags >> 1) & 1;
+  const int rewrite_d_out = flags & 1, accumulate = (flags >> 1) & 1, from_x = (flags >> 2) & 1;
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(C > 0 && N > 0, "scn_bn_backward: bad shape");
+  SCN_REQUIRE(!(from_x && rewrite_d_out), "scn_bn_backward: SCN_BN_MASK_FROM_X leaves d_out untouched; it cannot be combined with SCN_BN_REWRITE_D_OUT");
+  SCN_REQUIRE(from_x || y != nullptr, "scn_bn_backward: y is required unless SCN_BN_MASK_FROM_X is set");
   float *partial = (float *)temp;
   float *coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
   const int nblk = bn_blocks(N);
   const bool v4 = (C % 4) == 0;
   const int cg = v4 ? C / 4 : C;
   dim3 grid(nblk, (cg + 255) / 256);
+  const float leak = (float)leakiness;
   float *d_masked = rewrite_d_out ? d_out : d_x;  // pass 2 reads element i of it before writing element i of d_x
-  if (v4) k_bn_bwd_stats<4><<<grid, 256, 0, stream>>>(x, y, d_out, d_masked, save_mean, N, C, (float)leakiness, partial);
-  else k_bn_bwd_stats<1><<<grid, 256, 0, stream>>>(x, y, d_out, d_masked, save_mean, N, C, (float)leakiness, partial);
+  if (from_x) {
+    if (v4) k_bn_bwd_stats<4, true><<<grid, 256, 0, stream>>>(x, y, d_out, nullptr, save_mean, save_invstd, weight, bias, N, C, leak, partial);
+    else k_bn_bwd_stats<1, true><<<grid, 256, 0, stream>>>(x, y, d_out, nullptr, save_mean, save_invstd, weight, bias, N, C, leak, partial);
+  } else {
+    if (v4) k_bn_bwd_stats<4, false><<<grid, 256, 0, stream>>>(x, y, d_out, d_masked, save_mean, save_invstd, weight, bias, N, C, leak, partial);
+    else k_bn_bwd_stats<1, false><<<grid, 256, 0, stream>>>(x, y, d_out, d_masked, save_mean, save_invstd, weight, bias, N, C, leak, partial);
+  }
   SCN_CHECK_LAUNCH();
-  k_bn_bwd_finalize<<<(C + 15) / 16, 256, 0, stream>>>(partial, nblk, N, C, save_invstd, weight,
+  k_bn_bwd_finalize<<<(C + 15) / 16, 256, 0, stream>>>(partial, nblk, N, C, save_mean, save_invstd, weight, bias,
                                                         d_weight, d_bias, coef, accumulate);
   SCN_CHECK_LAUNCH();
   const int64_t total = N * C;
-  if (v4) k_bn_bwd_apply<4><<<grid_for(total / 4), 256, 0, stream>>>(x, d_masked, d_x, save_mean, total / 4, C, coef);
-  else k_bn_bwd_apply<1><<<grid_for(total), 256, 0, stream>>>(x, d_masked, d_x, save_mean, total, C, coef);
+  if (from_x) {
+    if (v4) k_bn_bwd_apply<4, true><<<grid_for(total / 4), 256, 0, stream>>>(x, d_out, d_x, save_mean, total / 4, C, coef, leak);
+    else k_bn_bwd_apply<1, true><<<grid_for(total), 256, 0, stream>>>(x, d_out, d_x, save_mean, total, C, coef, leak);
+  } else {
+    if (v4) k_bn_bwd_apply<4, false><<<grid_for(total / 4), 256, 0, stream>>>(x, d_masked, d_x, save_mean, total / 4, C, coef, leak);
+    else k_bn_bwd_apply<1, false><<<grid_for(total), 256, 0, stream>>>(x, d_masked, d_x, save_mean, total, C, coef, leak);
+  }
   SCN_CHECK_LAUNCH();
   return 0;
 }

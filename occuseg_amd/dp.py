@@ -12,7 +12,7 @@ and hand autograd no gradient -- a direct call from their backward); a bucket's 
 launched asynchronously when the LAST of its parameters has reported, whatever order backward
 visits them in, and overlaps the rest of backward (the coarse UNet levels and the decoder
 finish first, the level-0 encoder last).  A parameter that reports after its bucket was
-launched is an error, not a silent partial sum.  xGMI is a point-to-point mesh: few, large
+launched, or twice from the same source in one step, is an error, not a silent partial sum.  xGMI is a point-to-point mesh: few, large
 messages (tens of MB) rather than per-tensor ones.
 
 Use ``bucket.zero()`` instead of ``optimizer.zero_grad()``: the default ``set_to_none=True``
@@ -107,6 +107,7 @@ class FlatGradBucket(object):
     def _reset_counts(self):
         self._remaining = [last - first for (_s, _e, first, last) in self.buckets]
         self._reported = set()
+        self._sources = set()
 
     def enable_overlap(self):
         """launch each bucket's all-reduce as soon as ALL of its parameters have reported their gradient (one
@@ -116,22 +117,32 @@ class FlatGradBucket(object):
         self._overlap = True
         for i, p in enumerate(self.params):
             def hook(_param, i=i):
-                self._written(i)
+                self._written(i, "hook")
             self._hooks.append(p.register_post_accumulate_grad_hook(hook))
 
     def grad_written(self, param):
-        """a convolution / batch norm accumulated this parameter's gradient directly (no autograd hook fires)"""
+        """a convolution / batch norm accumulated this parameter's gradient directly into the flat buffer"""
         i = self._index.get(id(param))
         if i is not None:
-            self._written(i)
+            self._written(i, "direct")
 
-    def _written(self, i):
-        b = self._bucket_of[i]
-        if self._overlap and b in self._launched:
-            raise RuntimeError("FlatGradBucket: gradient of parameter %d written after the all-reduce of its bucket "
-                               "%d was launched (more than one backward pass per step with overlap enabled?)" % (i, b))
-        if not self._overlap or i in self._reported:
+    def _written(self, i, source):
+        """A parameter may report once per source and step: directly from the backward kernel's caller, and through
+        autograd's post-accumulate hook (torch fires it even when the Function handed autograd no gradient).  The
+        first report counts; the same source reporting again means a second write in the same step."""
+        if not self._overlap:
             return
+        b = self._bucket_of[i]
+        if (i, source) in self._sources:
+            raise RuntimeError("FlatGradBucket: gradient of parameter %d written twice in one step (bucket %d%s): with "
+                               "overlap enabled there must be exactly one backward pass between zero() and "
+                               "all_reduce_mean()" % (i, b, ", already launched" if b in self._launched else ""))
+        self._sources.add((i, source))
+        if i in self._reported:
+            return
+        if b in self._launched:
+            raise RuntimeError("FlatGradBucket: gradient of parameter %d written after the all-reduce of its bucket "
+                               "%d was launched" % (i, b))
         self._reported.add(i)
         self._remaining[b] -= 1
         if self._remaining[b] == 0:

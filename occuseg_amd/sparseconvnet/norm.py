@@ -31,8 +31,8 @@ class _BatchNormFunction(Function):
         features, out, weight, bias, running_mean, running_var, save_mean, save_invstd = ctx.saved_tensors
         assert ctx.train
         # the reference backend rewrites d_out in place (sparseconvnet/SCN/CUDA/BatchNormalization.cu:151-153), and
-        # autograd's buffer must never be mutated: ask the backend to stage the masked gradient in grad_input
-        # instead (same traffic, no private copy of grad_output)
+        # autograd's buffer must never be mutated: ask the backend to recompute the activation mask from x (the
+        # forward's own fma: bit-identical sign) -- d_out is only read, y is not read at all (20 B/element, not 28)
         grad_output = grad_output.contiguous()
         grad_input = like_empty(grad_output)
         # fused parameter-gradient accumulation, as in conv.py (the owner of the .grad buffers opts in)
@@ -42,7 +42,7 @@ class _BatchNormFunction(Function):
         grad_bias = bias.grad if direct else torch.zeros_like(bias)
         SCN.BatchNormalization_backward(features, grad_input, out, grad_output, save_mean, save_invstd,
                                         running_mean, running_var, weight, bias, grad_weight, grad_bias,
-                                        ctx.leakiness, _rewrite_d_output=False, _accumulate=direct)
+                                        ctx.leakiness, _rewrite_d_output=False, _accumulate=direct, _mask_from_x=True)
         if direct:
             owner.grad_written(weight)
             owner.grad_written(bias)

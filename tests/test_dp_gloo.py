@@ -89,8 +89,11 @@ def test_bucket_waits_for_every_parameter_whatever_the_order():
     for i in range(first + 1, last):
         b.grad_written(params[i])
     assert 0 in b._launched and b.launch_log[0][1] >= set(range(first, last))
-    with pytest.raises(RuntimeError, match="written after the all-reduce"):
+    with pytest.raises(RuntimeError, match="written twice in one step"):
         b.grad_written(params[first])
+    b.zero()
+    b._written(first, "hook")              # autograd's hook following the direct report of the same write: fine
+    b.grad_written(params[first])
     b.close()
     assert not hasattr(params[0], "_scn_grad_owner")
 
