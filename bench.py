@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--m", type=int, default=64)
+    ap.add_argument("--m", "--planes", dest="m", type=int, default=64)
     ap.add_argument("--scenes-per-gpu", type=int, default=4)
     ap.add_argument("--sites", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -275,6 +275,7 @@ def main():
             # inside the step the rule build runs on the side stream UNDER the step's big kernels (that is its point),
             # so the event times above include waiting for CUs.  The same build alone on an idle GPU:
             torch.cuda.synchronize()
+            SCN._PREFETCHED.clear()  # really build: do not adopt what the last step prefetched
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             alone = []
             for b in batches + batches:

@@ -933,6 +933,28 @@ __global__ void __launch_bounds__(128)
   }
 }
 
+// LDS table src[k][row] = input row feeding output row o0 + row through offset k, or -1: the tile's segments of all K
+// lists inverted.  8 threads per offset, all offsets in parallel: two dependent global loads per granule (the segment
+// bounds, then the pairs) instead of 2 K (one offset after the other: 27 x 2 L2 round trips per 32 rows).
+__device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], const int2 *__restrict__ rules,
+                                               const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                                               int n_gran, int g, int64_t o0) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < K * SCN_TILE_GRANULE; i += 256) src[i / SCN_TILE_GRANULE][i % SCN_TILE_GRANULE] = -1;
+  __syncthreads();
+  const int k = tid >> 3, sub = tid & 7;
+  if (k < K) {
+    const int s = bases[(int64_t)k * (n_gran + 1) + g];
+    const int e = bases[(int64_t)k * (n_gran + 1) + g + 1];
+    const int2 *rk = rules + (int64_t)k * stride;
+    for (int j = s + sub; j < e; j += 8) {
+      const int2 p = rk[j];
+      src[k][(int)((in_col ? p.x : p.y) - o0)] = in_col ? p.y : p.x;
+    }
+  }
+  __syncthreads();
+}
+
 // generic fallback (any Ci, Co; scalar FMA; used by the 3 -> m stem): 32 output rows x 64 planes per
 // block.  The tile's segments of all K lists are first inverted into an LDS table src[k][row] (one
 // barrier), then thread (row, 8 planes) walks the offsets on its own: no per-offset barrier, the
@@ -961,18 +983,7 @@ __global__ void __launch_bounds__(256)
   for (int g = blockIdx.x; g < n_gran; g += gridDim.x) {
   const int64_t o0 = (int64_t)g * M;
   __syncthreads();  // weights staged / previous granule done with src[]
-  for (int i = tid; i < K * M; i += 256) src[i / M][i % M] = -1;
-  __syncthreads();
-  for (int k = 0; k < K; ++k) {
-    const int s = bases[(int64_t)k * (n_gran + 1) + g];
-    const int e = bases[(int64_t)k * (n_gran + 1) + g + 1];
-    const int2 *rk = rules + (int64_t)k * stride;
-    for (int j = s + tid; j < e; j += 256) {
-      const int2 p = rk[j];
-      src[k][(int)((in_col ? p.x : p.y) - o0)] = in_col ? p.y : p.x;
-    }
-  }
-  __syncthreads();
+  fill_src_table(src, rules, bases, K, stride, in_col, n_gran, g, o0);
   const int r = tid >> 3, cg = (tid & 7) * 8;
   float acc[8];
 #pragma unroll
@@ -1233,18 +1244,7 @@ __global__ void __launch_bounds__(256)
   for (int g = blockIdx.x; g < n_gran; g += gridDim.x) {
     const int64_t o0 = (int64_t)g * M;
     __syncthreads();
-    for (int i = tid; i < K * M; i += 256) src[i / M][i % M] = -1;
-    __syncthreads();
-    for (int k = 0; k < K; ++k) {
-      const int s = bases[(int64_t)k * (n_gran + 1) + g];
-      const int e = bases[(int64_t)k * (n_gran + 1) + g + 1];
-      const int2 *rk = rules + (int64_t)k * stride;
-      for (int j = s + tid; j < e; j += 256) {
-        const int2 p = rk[j];
-        src[k][(int)((in_col ? p.x : p.y) - o0)] = in_col ? p.y : p.x;
-      }
-    }
-    __syncthreads();
+    fill_src_table(src, rules, bases, K, stride, in_col, n_gran, g, o0);
     // 8 rows per wave: all their loads are requested before the first FMA (8 independent LDS -> global chains)
     int sidx[8];
     float d[8], x[8][CI];
@@ -1331,7 +1331,8 @@ SCN_KNOB g_conv_small_policy = 1500;  // tuning key 4: launches with few tiles k
 SCN_KNOB g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile, never split offsets (A/B runs)
 SCN_KNOB g_conv_variant = 4;    // tuning key 0: 1 = first synchronous kernel, 2 = LDS-staged pipelined kernel for every
                                 // shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
-SCN_KNOB g_conv_small_tile4 = 1;  // tuning key 7: 0 = launches with few tiles use k_conv_tile2 with the offset split (A/B)
+SCN_KNOB g_conv_small_tile4 = 0;  // tuning key 7: 1 = launches with few tiles use k_conv_tile4 with the offset split instead of
+                                  // k_conv_tile2 (A/B on the train step: 53.14 against 52.79 ms, so off)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 // Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.

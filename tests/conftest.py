@@ -48,7 +48,7 @@ def pytest_collection_finish(session):
         e = dict(env, SCN_BENCH_BACKEND="gloo", SCN_BENCH_ONE_DEVICE="1")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--m", "16",
+               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--planes", "16",
                "--sites", "5000", "--scenes-per-gpu", "2", "--no-cpu-baseline"]
         jobs["bench2"] = {"procs": [subprocess.Popen(cmd, env=e, stdout=open(log, "w"), stderr=subprocess.STDOUT,
                                                      cwd=ROOT)], "log": log}
