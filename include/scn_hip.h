@@ -91,11 +91,20 @@ int scn_input_rules_table(const int32_t *order, const int32_t *site_start, int64
  * kernels sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:45-114) and the 27 CUDPP compactions.
  *   nbr    [27][N] i32   neighbour site per offset or -1
  *   rules  [27][N][2] i32, counts [27] i32 (device)
- *   temp   scn_rules_temp_bytes(N, 27) bytes */
+ *   temp   scn_rules_temp_bytes(N, 27) bytes
+ * Normal-guided filters (the fork's use_normal path): site_ori [N] = orientation class of each site (0, 2 or 4:
+ * OrientedFilter, sparseconvnet/SCN/Metadata/RectangularRegions.h:12-32, see scn_site_normals).
+ *   mode 0: plain rulebook (site_ori, nbr_tmp may be NULL);
+ *   mode 1: remap_rules_with_normal (sparseconvnet/SCN/Metadata/SubmanifoldConvolutionRules.h:213-245): the pair found at
+ *           offset i for output site o goes to list rot_index[ori(o)][i]; every list sorted by output site (the
+ *           reference's lists hold the same pairs as up to three such runs, ordered by i); nbr_tmp [27][N] scratch;
+ *   mode 2: plain offsets, but only the output sites of class `only_class` (the three such rulebooks are what the
+ *           dInput of a remapped convolution runs over: in them the input column is unique and ascending too). */
 size_t scn_rules_temp_bytes(int64_t N, int K);
 int scn_submanifold_rules(const int32_t *site_coords, int64_t N, const uint64_t *table_keys,
                           const int32_t *table_vals, int64_t capacity, int32_t *nbr,
                           int32_t *rules, int32_t *counts, void *temp, size_t temp_bytes,
+                          const int32_t *site_ori, int mode, int only_class, int32_t *nbr_tmp,
                           void *stream);
 
 /* size 2 / stride 2 rulebook: pairs (fine, coarse), 8 lists, ascending fine.
@@ -124,6 +133,10 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
  *   (i,o) in list k  <=>  (o,i) in list 26-k).
  *   in_col/out_col: 0/1 for conv + submanifold, 1/0 for deconvolution
  *   (sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49); bases = scn_tile_bases(.., out_col, n_out).
+ *   counts [K] (device) = pairs per list.  out_unique != 0 promises that EVERY output row appears in exactly one pair of
+ *   the rulebook (deconvolution and the dInput of a strided convolution: each fine row has one parity class,
+ *   sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49; NetworkInNetwork: the identity list): such launches run without any
+ *   accumulation across offsets (k_conv_expand).
  *   wpack: scn_conv_wpack_bytes(K,Ci,Co) bytes holding the weights re-laid out in MFMA fragment order.
  *   wpack_ready = 0: scn_conv_forward packs (W, w_transposed, w_reverse) into it first; 1: the caller already ran
  *   scn_weight_pack for exactly this (W contents, w_transposed, w_reverse) -- weights change once per optimizer
@@ -133,18 +146,18 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
  *   added in a fixed order, so every launch is bitwise reproducible run to run (the reference scatters with float
  *   atomics, sparseconvnet/SCN/CUDA/Convolution.cu:529,1147). */
 size_t scn_conv_wpack_bytes(int K, int Ci, int Co);
-size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co);
+size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
 /* which kernel scn_conv_forward runs for this shape (for per-kernel reporting): 100 * kind + offset split, kind
  * 0 = generic (planes not multiples of 16), 1 = synchronous fallback (> 4 GiB), 2 = k_conv_tile2 (LDS-staged),
  * 4 = k_conv_tile4 (barrier-free), 5 = k_conv_expand (one contribution per output row: deconvolution, conv dInput, NiN) */
-int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co);
+int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
 int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int Ci, int Co, void *wpack,
                     void *stream);
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const int32_t *rules, const int32_t *bases, int K,
-                     int64_t stride, int in_col, int out_col, int64_t n_in, int64_t n_out, int Ci,
-                     int Co, void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes,
-                     void *stream);
+                     const float *bias, const int32_t *rules, const int32_t *bases, const int32_t *counts,
+                     int K, int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in,
+                     int64_t n_out, int Ci, int Co, void *wpack, int wpack_ready, void *workspace,
+                     size_t workspace_bytes, void *stream);
 
 /* scn_set_tuning / scn_debug_stamps (kernel-variant selection, timing-only ablation builds, cycle stamps) are NOT
  * part of this ABI: they exist only in libscn_hip_tuning.so (same sources compiled with -DSCN_TUNING), which
@@ -197,6 +210,36 @@ int scn_output_forward(const float *in, float *out, const int32_t *site_of_row, 
                        int C, void *stream);
 int scn_output_backward(float *d_in, const float *d_out, const int32_t *order,
                         const int32_t *site_start, int64_t N, int C, void *stream);
+
+/* ------------------------------------------ either side of the hot path ---
+ * Normal-guided filters (the fork's use_normal path).  site_normals [N,3] = normalised mean of the point normals of
+ * each site, site_ori [N] = OrientedFilter(normal) in {0, 2, 4}.  Replaces the host loop of
+ * cuda_InputLayer_updateOutput (sparseconvnet/SCN/CUDA/IOLayers.cpp:36-65), Float3::normalize
+ * (sparseconvnet/SCN/Metadata/Metadata.h:95-101) and OrientedFilter (sparseconvnet/SCN/Metadata/RectangularRegions.h:12-32). */
+int scn_site_normals(const float *point_normals, const int32_t *order, const int32_t *site_start,
+                     int64_t N, float *site_normals, int32_t *site_ori, void *stream);
+
+/* out[q] = site id (key rank) of voxel query[q] / div in the grid with sorted unique keys site_keys, or -1.
+ * query int32 [Q,ncols] (ncols 4: last column = sample; ncols 3: all in sample `sample`).  Replaces
+ * ResolutionBasedScatteringCuda (sparseconvnet/SCN/Metadata/ConvolutionRules.h:327-342, bound at
+ * sparseconvnet/SCN/pybind.cpp:33-36). */
+int scn_lookup_sites(const uint64_t *site_keys, int64_t N, const int32_t *query, int ncols, int64_t Q,
+                     int div, int sample, int32_t *out, void *stream);
+
+/* Segment reductions over instance labels (the loss side, examples/ScanNet/train_instance.py:203-242 and
+ * examples/ScanNet/discriminative.py:52-53,146 call torch_scatter 1.4.0's scatter_add / scatter_mean / scatter_std /
+ * scatter_max with dim = 0): src fp32 [P,C], seg int64 [P] with labels in [0,S), out fp32 [S,C].
+ *   scn_segment_reduce: out[seg[p],c] (op 0: +=, op 1: = max) src[p,c]; `out` must hold 0 (op 0) or -FLT_MAX (op 1);
+ *   scn_segment_count:  counts[s] += |{p : seg[p] = s}|   (fp32, `counts` zeroed by the caller);
+ *   scn_segment_gather: out[p,c] = table[seg[p],c] * (scale ? scale[seg[p]] : 1);
+ *   scn_segment_sqdev:  out[seg[p],c] += (src[p,c] - mean[seg[p],c])^2. */
+int scn_segment_reduce(const float *src, const int64_t *seg, int64_t P, int C, int S, int op, float *out,
+                       void *stream);
+int scn_segment_count(const int64_t *seg, int64_t P, int S, float *counts, void *stream);
+int scn_segment_gather(const float *table, const int64_t *seg, const float *scale, int64_t P, int C,
+                       int S, float *out, void *stream);
+int scn_segment_sqdev(const float *src, const float *mean, const int64_t *seg, int64_t P, int C, int S,
+                      float *out, void *stream);
 
 #ifdef __cplusplus
 }

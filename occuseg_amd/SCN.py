@@ -94,7 +94,8 @@ class _Grid(object):
 class _RuleBook(object):
     """Device rulebook: rules int32 [K, stride, 2], counts int32 [K] (device),
     tile-base tables per output column."""
-    __slots__ = ("K", "stride", "rules", "counts", "bases", "n_rows", "total_pairs", "nbr")
+    __slots__ = ("K", "stride", "rules", "counts", "bases", "n_rows", "total_pairs", "nbr", "unique_col", "ori",
+                 "class_books")
 
     def __init__(self, K, stride, rules, counts):
         self.K = K
@@ -105,12 +106,38 @@ class _RuleBook(object):
         self.n_rows = {}     # out_col -> number of output rows
         self.total_pairs = None
         self.nbr = None
+        self.unique_col = None  # column in which every row id 0..n-1 appears exactly once over all lists (2: both)
+        self.ori = None          # normal-guided rulebook: int32 [N] orientation class of every (output) site
+        self.class_books = None  # ... and, built when a dInput needs them, {class: plain rulebook of that class's outputs}
 
     def host_lists(self):
-        """reference-format host rulebook: list of K int32 arrays [R_k, 2]"""
+        """reference-format host rulebook: list of K int32 arrays [R_k, 2].  A normal-guided rulebook is kept sorted by
+        output site on the device; the reference's list n is the same pairs as up to three runs, in the order of the
+        ORIGINAL offset i they were found at (remap_rules_with_normal walks the old lists i = 0..26 and appends,
+        sparseconvnet/SCN/Metadata/SubmanifoldConvolutionRules.h:232-243): reproduced here by a stable sort on i."""
         counts = self.counts.cpu().tolist()
         r = self.rules.cpu().numpy()
-        return [r[k, :counts[k]].copy() for k in range(self.K)]
+        lists = [r[k, :counts[k]].copy() for k in range(self.K)]
+        if self.ori is not None:
+            ori = self.ori.cpu().numpy()
+            inv = np.empty((6, 27), np.int64)
+            for o in range(6):
+                inv[o, ROT_INDEX[o]] = np.arange(27)
+            for n in range(self.K):
+                old_i = inv[ori[lists[n][:, 1]], n]
+                lists[n] = lists[n][np.argsort(old_i, kind="stable")]
+        return lists
+
+
+# rot_index / the `index` table of remap_rules_with_normal (sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:8-15,
+# sparseconvnet/SCN/Metadata/SubmanifoldConvolutionRules.h:217-223): new list = ROT_INDEX[orientation class][old offset]
+ROT_INDEX = np.array([
+    0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,
+    24,25,26,21,22,23,18,19,20,15,16,17,12,13,14,9,10,11,6,7,8,3,4,5,0,1,2,
+    6,7,8,15,16,17,24,25,26,3,4,5,12,13,14,21,22,23,0,1,2,9,10,11,18,19,20,
+    18,19,20,9,10,11,0,1,2,21,22,23,12,13,14,3,4,5,24,25,26,15,16,17,6,7,8,
+    2,11,20,5,14,23,8,17,26,1,10,19,4,13,22,7,16,25,0,9,18,3,12,21,6,15,24,
+    18,9,0,21,12,3,24,15,6,19,10,1,22,13,4,25,16,7,20,11,2,23,14,5,26,17,8], np.int64).reshape(6, 27)
 
 
 class Metadata_3(object):
@@ -124,6 +151,7 @@ class Metadata_3(object):
     def clear(self):
         self.grids = {}
         self.nActive = {}
+        self.normals = {}   # spatial size -> (site normals fp32 [N,3], orientation class int32 [N])  (use_normal path)
         self.submanifoldRuleBooks = {}
         self.ruleBooks = {}
         self.device = None
@@ -175,9 +203,11 @@ class Metadata_3(object):
             check(lib.scn_hash_build(ptr(g.keys), g.n, ptr(g.hash_keys), ptr(g.hash_vals), cap, stream()))
         return g
 
-    def inputLayer(self, spatialSize, coords, batchSize, mode, device):
+    def inputLayer(self, spatialSize, coords, batchSize, mode, device, normals=None):
         """Metadata::inputLayer (sparseconvnet/SCN/Metadata/Metadata.cpp:424-446) ->
-        inputLayerRulesSimple (sparseconvnet/SCN/Metadata/IOLayersRules.h:135-202)."""
+        inputLayerRulesSimple (sparseconvnet/SCN/Metadata/IOLayersRules.h:135-202).  ``normals`` (float [P,3], one per
+        input point) switches on the fork's normal-guided filters: per-site normals are averaged here
+        (sparseconvnet/SCN/CUDA/IOLayers.cpp:36-65) BEFORE any rulebook of this batch is built."""
         if mode not in (3, 4):
             raise NotImplementedError("InputLayer: the reference GPU path supports mode 3 and 4 only "
                                       "(sparseconvnet/SCN/Metadata/IOLayersRules.h:141)")
@@ -187,7 +217,8 @@ class Metadata_3(object):
         assert coords.dtype in _COORD_DTYPES, coords.dtype
         key = _size_key(spatialSize)
         pre = _PREFETCHED.pop(id(coords), None)
-        if pre is not None and pre[0] is coords and pre[1] == (key, int(mode), _norm_device(device)):
+        if pre is not None and pre[0] is coords and pre[1] == (key, int(mode), _norm_device(device)) \
+                and pre[4] is normals:
             self._adopt(pre[2], pre[3])
             return
         self.clear()
@@ -201,6 +232,13 @@ class Metadata_3(object):
         self.input_mode = int(mode)
         self.input_P = P
         self.input_order, self.input_site_of_row, self.input_site_start = order, site_of_row, site_start
+        if normals is not None:
+            assert normals.dim() == 2 and normals.size(0) == P and normals.size(1) == 3, normals.shape
+            pn = normals.to(device=device, dtype=torch.float32).contiguous()
+            sn = torch.empty((g.n, 3), dtype=torch.float32, device=c.device)
+            ori = torch.empty(g.n, dtype=torch.int32, device=c.device)
+            check(_lib_().scn_site_normals(ptr(pn), ptr(order), ptr(site_start), g.n, ptr(sn), ptr(ori), stream()))
+            self.normals[key] = (sn, ori)
         old_plan = _PLANS.get(key, [])
         self._plan = []          # requests made by the ops of THIS forward pass (stale ones drop out)
         _PLANS[key] = self._plan
@@ -223,9 +261,12 @@ class Metadata_3(object):
                 if t is not None:
                     yield t
         for rb in list(self.submanifoldRuleBooks.values()) + list(self.ruleBooks.values()):
-            for t in [rb.rules, rb.counts, rb.nbr] + list(rb.bases.values()):
+            for t in [rb.rules, rb.counts, rb.nbr, rb.ori] + list(rb.bases.values()):
                 if t is not None:
                     yield t
+        for sn, ori in self.normals.values():
+            yield sn
+            yield ori
         for t in (self.input_order, self.input_site_of_row, self.input_site_start):
             if t is not None:
                 yield t
@@ -283,10 +324,16 @@ class Metadata_3(object):
             counts = torch.empty(27, dtype=torch.int32, device=dev)
             tb = lib.scn_rules_temp_bytes(N, 27)
             temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+            # normals known at this scale (Metadata::getSubmanifoldRuleBook, sparseconvnet/SCN/Metadata/Metadata.cpp:514-530):
+            # remap every pair to list rot_index[class of its output site][offset]
+            ori = self.normals[key[:3]][1] if key[:3] in self.normals else None
+            nbr_tmp = torch.empty((27, N), dtype=torch.int32, device=dev) if ori is not None else None
             ev = _prof_begin()
             check(lib.scn_submanifold_rules(ptr(g.coords), N, ptr(g.hash_keys), ptr(g.hash_vals), g.hash_cap,
-                                            ptr(nbr), ptr(rules), ptr(counts), ptr(temp), tb, stream()))
+                                            ptr(nbr), ptr(rules), ptr(counts), ptr(temp), tb, ptr(ori),
+                                            1 if ori is not None else 0, -1, ptr(nbr_tmp), stream()))
             rb = _RuleBook(27, N, rules, counts)
+            rb.ori = ori
             # read 16 N (coords), write + read the 27 probe results (2 x 108 N), write 8 R
             _prof_end(ev, "sub_rules", 0.0, lambda rb=rb, N=N: 16.0 * N + 216.0 * N + 8.0 * (rb.total_pairs or 0), (N,))
             if KEEP_NBR:  # the probe table (108 B/site) is scratch of the build; tests ask to see it
@@ -301,6 +348,32 @@ class Metadata_3(object):
             self._record(("sub", key[:3], fs))
         return rb
 
+    def _class_books(self, spatialSize, rb):
+        """the three plain rulebooks {outputs of class c} a normal-guided rulebook's dInput runs over (see
+        SubmanifoldConvolution_backward); built once per batch, on first use"""
+        if rb.class_books is None:
+            lib = _lib_()
+            g = self._hash(self.grids[_size_key(spatialSize)])
+            dev, N = g.coords.device, g.n
+            books = {}
+            for cls in (0, 2, 4):
+                nbr = torch.empty((27, N), dtype=torch.int32, device=dev)
+                rules = torch.empty((27, N, 2), dtype=torch.int32, device=dev)
+                counts = torch.empty(27, dtype=torch.int32, device=dev)
+                tb = lib.scn_rules_temp_bytes(N, 27)
+                temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+                check(lib.scn_submanifold_rules(ptr(g.coords), N, ptr(g.hash_keys), ptr(g.hash_vals), g.hash_cap,
+                                                ptr(nbr), ptr(rules), ptr(counts), ptr(temp), tb, ptr(rb.ori), 2, cls,
+                                                None, stream()))
+                b = _RuleBook(27, N, rules, counts)
+                self._tile_bases(b, 0, N)  # for a fixed offset the input site is unique and ascending with the output site
+                books[cls] = b
+            totals = torch.stack([b.counts.sum() for b in books.values()]).cpu().tolist()
+            for b, t in zip(books.values(), totals):
+                b.total_pairs = int(t)
+            rb.class_books = books
+        return rb.class_books
+
     def getRuleBook(self, inputSpatialSize, outputSpatialSize, size, stride, _defer=False):
         """Metadata::getRuleBook (sparseconvnet/SCN/Metadata/Metadata.cpp:598-625): builds the coarse
         grid as a side effect and sets nActive[outputSpatialSize]."""
@@ -311,6 +384,12 @@ class Metadata_3(object):
         iS, oS = _size_key(inputSpatialSize), _size_key(outputSpatialSize)
         key = iS + fs + st
         rb = self.ruleBooks.get(key)
+        if rb is None and iS in self.normals and iS[0] >= self.normal_guide_scale:
+            raise NotImplementedError(
+                "normal-guided STRIDED rules (input spatial size %d >= normal_guide_scale %d) are not built: the "
+                "reference takes its hash-map path there (sparseconvnet/SCN/Metadata/ConvolutionRules.h:770-828, "
+                ":40-105); with the default rotation_guide_level 0 (examples/ScanNet/config.py:50, model.py:626) the "
+                "normals guide the input scale only, which is what this backend provides" % (iS[0], self.normal_guide_scale))
         if rb is None:
             lib = _lib_()
             fine = self.grids[iS]
@@ -331,6 +410,7 @@ class Metadata_3(object):
             self._tile_bases(rb, 1, coarse.n)  # lists are also ascending in the coarse id
             self._tile_bases(rb, 0, Nf)
             rb.total_pairs = Nf  # every fine site appears in exactly one list
+            rb.unique_col = 0
             self.ruleBooks[key] = rb
         if not _defer:
             self._record(("conv", iS, oS, fs, st))
@@ -358,7 +438,8 @@ def _norm_device(device):
     return device
 
 
-def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=True):
+def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=True, normals=None,
+                   normal_guide_scale=None):
     """Build the grids and (replaying the previous forward pass's requests) the rulebooks that the next
     ``InputLayer`` call on exactly this ``coords`` tensor will need, on a high-priority side stream, so that
     the build and its data-dependent host synchronisations overlap the current step's queued kernels.  The
@@ -374,12 +455,14 @@ def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=Tr
     if coords.is_cuda and wait_for_current_stream:
         side.wait_stream(torch.cuda.current_stream(device))
     m = Metadata_3()
+    if normals is not None and normals.is_cuda and wait_for_current_stream:
+        side.wait_stream(torch.cuda.current_stream(device))
     with torch.cuda.stream(side):
-        m.inputLayer(spatialSize, coords, 0, mode, device)
+        m.inputLayer(spatialSize, coords, 0, mode, device, normals=normals)
         done = torch.cuda.Event()
         done.record(side)
     _PREFETCHED.clear()  # one batch ahead is all a training loop needs; never keep stale grids alive
-    _PREFETCHED[id(coords)] = (coords, (_size_key(spatialSize), int(mode), device), m, done)
+    _PREFETCHED[id(coords)] = (coords, (_size_key(spatialSize), int(mode), device), m, done, normals)
 
 
 # ----------------------------------------------------------------- helpers ---
@@ -416,7 +499,9 @@ def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
 
 def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False):
     """out = gather-mm-scatter over rb; weight is the module's [K, a, b] tensor, used as [K, Ci, Co]
-    (forward) or, with w_transposed, as its per-offset transpose (dInput)."""
+    (forward) or, with w_transposed, as its per-offset transpose (dInput).  When every output row appears in exactly
+    one pair of the rulebook (rb.unique_col == out_col: the fine column of a strided rulebook, the identity list)
+    the backend runs the launch without accumulating across offsets."""
     lib = _lib_()
     K = weight.size(0)
     Ci, Co = (weight.size(2), weight.size(1)) if w_transposed else (weight.size(1), weight.size(2))
@@ -425,18 +510,19 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     out.resize_(n_out, Co)
     wpack, ready = _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co)
     # launches with few output tiles split their offsets over workgroups; partial tiles go through this workspace
-    ws_bytes = lib.scn_conv_workspace_bytes(K, rb.stride, inp.size(0), n_out, Ci, Co)
+    uniq = int(rb.unique_col is not None and (rb.unique_col == out_col or rb.unique_col == 2))
+    ws_bytes = lib.scn_conv_workspace_bytes(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=inp.device) if ws_bytes else None
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None,
-                               ptr(rb.rules), ptr(rb.bases[out_col]), K, rb.stride, in_col, out_col, inp.size(0),
-                               n_out, Ci, Co, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
+                               ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.counts), K, rb.stride, in_col, out_col, uniq,
+                               inp.size(0), n_out, Ci, Co, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
     # algorithmic work of one launch: flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
     if ev is not None:
         R = rb.total_pairs
-        code = lib.scn_conv_plan(K, rb.stride, inp.size(0), n_out, Ci, Co)
+        code = lib.scn_conv_plan(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
         name = _CONV_KERNELS.get(code // 100, "conv") + ("_split" if code % 100 > 1 else "")
         _prof_end(ev, name, 2.0 * R * Ci * Co, 4.0 * (R * Ci + n_out * Co) + 8.0 * R + 4.0 * K * Ci * Co,
                   (K, n_out, Ci, Co, int(w_transposed), in_col))
@@ -475,10 +561,12 @@ def InputLayer_updateOutput(m, spatialSize, input_coords, input_features, output
                             input_normal=None):
     """sparseconvnet/SCN/pybind.cpp:158-162 -> sparseconvnet/SCN/CUDA/IOLayers.cpp:17-80"""
     _need_cuda(input_features, "InputLayer_updateOutput")
-    m.inputLayer(spatialSize, input_coords, batchSize, mode, input_features.device)
-    if input_normal is not None and torch.is_tensor(input_normal) and input_normal.dim() == 2 \
-            and input_normal.size(0) == input_features.size(0):
-        raise NotImplementedError("normal-guided filters (use_normal) are out of scope (SURVEY.md section 2 row 30)")
+    # use_normal = a [P,3] tensor with one normal per input row (sparseconvnet/SCN/CUDA/IOLayers.cpp:38-40); anything
+    # else (the reference's callers pass zeros(3,3) or an empty tensor) means "no normals"
+    use_normal = (input_normal is not None and torch.is_tensor(input_normal) and input_normal.dim() == 2
+                  and input_normal.size(0) == input_features.size(0) and input_normal.size(1) == 3)
+    m.inputLayer(spatialSize, input_coords, batchSize, mode, input_features.device,
+                 normals=input_normal if use_normal else None)
     N = m.nActive[m.inputSpatialSize]
     C = input_features.size(1)
     output_features.resize_(N, C)
@@ -542,8 +630,25 @@ def SubmanifoldConvolution_backward(spatialSize, filterSize, m, input_features, 
     _need_cuda(d_output_features, "SubmanifoldConvolution_backward")
     rb = m.getSubmanifoldRuleBook(spatialSize, filterSize, dilated_rate)
     n = m.getNActive(spatialSize)
-    _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight, d_weight, d_bias,
-                   rb, 0, 1, n, reverse=True)
+    if rb.ori is None:
+        _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight, d_weight, d_bias,
+                       rb, 0, 1, n, reverse=True)
+        return
+    # Normal-guided rulebook: list n holds the pairs found at offset i = inv(class of the OUTPUT site)[n], so the
+    # (i,o) <-> (o,i) symmetry the plain dInput relies on is gone and an input site can appear several times in one
+    # list.  Split by class instead: over the outputs of class c the lists are the plain offsets i (input site unique
+    # and ascending per list) with weights W[rot_index[c][i]]; dIn = sum over the three classes.
+    _conv_backward(input_features.contiguous(), None, d_output_features, weight, d_weight, d_bias, rb, 0, 1, n,
+                   reverse=False)
+    if d_input_features is not None:
+        d_out = d_output_features.contiguous()
+        total = None
+        for cls, book in m._class_books(spatialSize, rb).items():
+            w_c = weight.index_select(0, torch.from_numpy(ROT_INDEX[cls]).to(weight.device))
+            part = torch.empty(0, dtype=d_out.dtype, device=d_out.device)
+            _conv(d_out, part, w_c, None, book, 1, 0, n, True, False)
+            total = part if total is None else total.add_(part)
+        d_input_features.resize_(n, weight.size(1)).copy_(total)
 
 
 def Convolution_updateOutput(inputSize, outputSize, filterSize, filterStride, m, input_features,
@@ -650,6 +755,7 @@ def _identity_rulebook(n, device):
         bases = torch.clamp(torch.arange(n_gran + 1, dtype=torch.int32, device=device) * GRANULE, max=n)
         rb.bases[0] = rb.bases[1] = bases.reshape(1, n_gran + 1).contiguous()
         rb.total_pairs = n
+        rb.unique_col = 2
         while len(_IDENTITY_RB) >= 8:
             _IDENTITY_RB.pop(next(iter(_IDENTITY_RB)))
     _IDENTITY_RB[key] = rb
@@ -721,7 +827,28 @@ def _not_in_scope(name):
     return f
 
 
-for _n in ("ResolutionBasedScattering", "ActivePooling_updateOutput", "ActivePooling_updateGradInput",
+def ResolutionBasedScattering(m, points_lr, points_hr, stride):
+    """sparseconvnet/SCN/pybind.cpp:33-36 -> ResolutionBasedScatteringCuda (sparseconvnet/SCN/Metadata/ConvolutionRules.h:
+    327-342): for every high-resolution point the site id (rank of its key) of the low-resolution point at
+    points_hr / stride, or -1.  points_*: int tensors [n,3] of ONE sample (as sparseconvnet/utils.py:85-90 calls it);
+    returns an int32 tensor [n_hr] on the device."""
+    dev = points_hr.device if points_hr.is_cuda else (points_lr.device if points_lr.is_cuda else None)
+    if dev is None:
+        raise RuntimeError("occuseg_amd.SCN.ResolutionBasedScattering: points must live on the GPU -- no CPU path")
+    lr = points_lr.to(dev, torch.int32).contiguous()
+    hr = points_hr.to(dev, torch.int32).contiguous()
+    assert lr.dim() == 2 and hr.dim() == 2 and lr.size(1) == 3 and hr.size(1) == 3
+    out = torch.empty(hr.size(0), dtype=torch.int32, device=dev)
+    if hr.size(0) == 0:
+        return out
+    if lr.size(0) == 0:
+        return out.fill_(-1)
+    grid, _order, _site_of_row, _start = m._build_grid(lr, 0, 3, 0, lr.size(0))  # the reference's pHash->insert
+    check(_lib_().scn_lookup_sites(ptr(grid.keys), grid.n, ptr(hr), 3, hr.size(0), int(stride), 0, ptr(out), stream()))
+    return out
+
+
+for _n in ("ActivePooling_updateOutput", "ActivePooling_updateGradInput",
            "AveragePooling_updateOutput", "AveragePooling_updateGradInput", "MaxPooling_updateOutput",
            "MaxPooling_updateGradInput", "SparseToDense_updateOutput", "SparseToDense_updateGradInput",
            "FullConvolution_updateOutput", "FullConvolution_backward", "RandomizedStrideConvolution_updateOutput",

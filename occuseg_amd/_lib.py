@@ -26,15 +26,15 @@ SIGNATURES = {
     "scn_input_rules_max_active": (c_int, [_P, c_int64, _P, ctypes.POINTER(c_int32), _P]),
     "scn_input_rules_table": (c_int, [_P, _P, c_int64, c_int32, _P, _P]),
     "scn_rules_temp_bytes": (c_size_t, [c_int64, c_int]),
-    "scn_submanifold_rules": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
+    "scn_submanifold_rules": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_size_t, _P, c_int, c_int, _P, _P]),
     "scn_strided_rules": (c_int, [_P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "scn_tile_bases": (c_int, [_P, _P, c_int, c_int64, c_int, c_int64, _P, _P]),
     "scn_conv_wpack_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "scn_conv_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int]),
-    "scn_conv_plan": (c_int, [c_int, c_int64, c_int64, c_int64, c_int, c_int]),
+    "scn_conv_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
+    "scn_conv_plan": (c_int, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_weight_pack": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64,
-                                 c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
+    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
+                                 c_int64, c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
     "scn_bn_temp_bytes": (c_size_t, [c_int]),
@@ -45,6 +45,12 @@ SIGNATURES = {
     "scn_input_backward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_output_forward": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "scn_output_backward": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "scn_site_normals": (c_int, [_P, _P, _P, c_int64, _P, _P, _P]),
+    "scn_lookup_sites": (c_int, [_P, c_int64, _P, c_int, c_int64, c_int, c_int, _P, _P]),
+    "scn_segment_reduce": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P]),
+    "scn_segment_count": (c_int, [_P, c_int64, c_int, _P, _P]),
+    "scn_segment_gather": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
+    "scn_segment_sqdev": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
 }
 
 # only in libscn_hip_tuning.so (-DSCN_TUNING): variant selection, timing-only ablation builds, cycle stamps

@@ -955,6 +955,104 @@ __device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], con
   __syncthreads();
 }
 
+// --------------------------------------------- one contribution per output row ---
+// Deconvolution, the dInput of a strided convolution and NetworkInNetwork write every output row exactly ONCE:
+//   out[o,:] = in[src(o),:] . W[k(o)]          (K = 8: o = fine row, src = its coarse row, k = its parity class; K = 1: identity)
+// so nothing is accumulated across offsets and the output-stationary tile of the kernels above is pure overhead
+// (a 128-row output tile holds ~16 pairs per offset: every pass a new phase, weights reloaded for 16 pairs).  Here the
+// unit of work is 32 consecutive PAIRS of one list x 64 output planes, owned by one wave: the whole C_i reduction runs
+// in registers (A = weight fragments, B = the gathered rows fetched straight from global memory in fragment shape, as
+// in k_conv_tile4), the result is stored straight to the 32 output rows.  No LDS, no barrier, no atomics.  C_i is
+// walked in chunks of 64 planes, the loads of chunk c+1 requested before the MFMAs of chunk c.
+__global__ void __launch_bounds__(64)
+    k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
+                  const float *__restrict__ bias, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
+                  int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes, unsigned wp_bytes) {
+  constexpr int CK = 64, NS16 = 4, COS = 4, PB = 32;
+  const int lane = threadIdx.x;
+  const int li = lane & 15, lq = lane >> 4;
+  // (list, block of 32 pairs, plane block) of this wave: blocks are numbered list after list
+  int blk = blockIdx.x / ncb;
+  const int co0 = (blockIdx.x % ncb) * 64;
+  int k = 0, cnt = 0;
+  for (; k < K; ++k) {
+    cnt = counts[k];
+    const int nb = (cnt + PB - 1) / PB;
+    if (blk < nb) break;
+    blk -= nb;
+  }
+  if (k >= K) return;
+  const int p0 = blk * PB;
+  const int2 *rk = rules + (int64_t)k * stride;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
+  unsigned roff[2];
+  int64_t orow[2];
+  bool live[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int p = p0 + 16 * g + li;
+    live[g] = p < cnt;
+    const int2 pr = rk[min(p, cnt - 1)];
+    roff[g] = (unsigned)(in_col ? pr.y : pr.x) * (unsigned)(Ci * 4) + (unsigned)(lq * 16);
+    orow[g] = in_col ? pr.x : pr.y;
+  }
+  const int nch = Ci / CK;
+  floatx4 acc[2][COS];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int q = 0; q < COS; ++q) acc[g][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+  floatx4 rA[2][NS16], wA[COS][NS16], rB[2][NS16], wB[COS][NS16];
+  auto load = [&](int c, floatx4 (&r)[2][NS16], floatx4 (&w)[COS][NS16]) __attribute__((always_inline)) {
+    // weight fragment (k, 16-plane reduction block rs, 16-plane output block cs) = 1 KiB at ((k Ci/16 + rs) Co/16 + cs) KiB
+    const int blk0 = (k * (Ci / 16) + c * (CK / 16)) * (Co / 16) + co0 / 16;
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp)
+#pragma unroll
+      for (int q = 0; q < COS; ++q)
+        w[q][sp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+            wp_rsrc, (unsigned)lane * 16u, (blk0 + sp * (Co / 16) + q) * 1024, 0));
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp)
+        r[g][sp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+            in_rsrc, roff[g] + (unsigned)(sp * 64), c * (CK * 4), 0));
+  };
+  auto mma = [&](const floatx4 (&r)[2][NS16], const floatx4 (&w)[COS][NS16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < COS; ++q)
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q][sp][e], r[g][sp][e], acc[g][q], 0, 0, 0);
+  };
+  load(0, rA, wA);
+  for (int c = 0; c < nch; c += 2) {
+    if (c + 1 < nch) load(c + 1, rB, wB);
+    mma(rA, wA);
+    if (c + 1 < nch) {
+      if (c + 2 < nch) load(c + 2, rA, wA);
+      mma(rB, wB);
+    }
+  }
+  // D[i = plane][j = pair]: lane (li, lq) holds planes 16 q + 4 lq .. + 3 of pair li
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+    if (live[g]) {
+#pragma unroll
+      for (int q = 0; q < COS; ++q) {
+        floatx4 v = acc[g][q];
+        if (bias) v += *(const floatx4 *)(bias + co0 + 16 * q + 4 * lq);
+        *(floatx4 *)(out + orow[g] * Co + co0 + 16 * q + 4 * lq) = v;
+      }
+    }
+}
+
 // generic fallback (any Ci, Co; scalar FMA; used by the 3 -> m stem): 32 output rows x 64 planes per
 // block.  The tile's segments of all K lists are first inverted into an LDS table src[k][row] (one
 // barrier), then thread (row, 8 planes) walks the offsets on its own: no per-offset barrier, the
@@ -1333,6 +1431,7 @@ SCN_KNOB g_conv_variant = 4;    // tuning key 0: 1 = first synchronous kernel, 2
                                 // shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
 SCN_KNOB g_conv_small_tile4 = 0;  // tuning key 7: 1 = launches with few tiles use k_conv_tile4 with the offset split instead of
                                   // k_conv_tile2 (A/B on the train step: 53.14 against 52.79 ms, so off)
+SCN_KNOB g_conv_expand = 1;     // tuning key 8: 0 = launches with one contribution per output row use the tile kernels (A/B)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 // Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.
@@ -1342,7 +1441,7 @@ struct ConvPlan {
   int ksplit;  // kind 2: workgroups per (tile, plane block), each taking the offsets k == j (mod ksplit)
   bool huge;   // > 4 GiB of input rows or packed weights: 32-bit buffer offsets do not reach
 };
-static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co) {
+static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique = 0) {
   ConvPlan p{0, 0, 1, false};
   if (Ci % 16 != 0 || Co % 16 != 0) return p;
   // the pipelined kernels address `in` and the packed weights with unsigned 32-bit buffer offsets
@@ -1351,6 +1450,14 @@ static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, in
   if (g_conv_variant == 1 || p.huge) {
     p.kind = 1;
     p.nw = s16 % 4 == 0 ? 4 : s16 % 3 == 0 ? 3 : s16 % 2 == 0 ? 2 : 1;
+    return p;
+  }
+  // every output row appears in exactly one pair (deconvolution, strided-conv dInput, NiN): nothing to accumulate
+  // across offsets -> k_conv_expand (register accumulators over the whole C_i reduction, direct stores)
+  if (out_unique && g_conv_expand != 0 && g_conv_variant == 4 && Ci % 64 == 0 && Co % 64 == 0 &&
+      (int64_t)K * stride * 8 < (int64_t)0x7fffffff) {
+    p.kind = 5;
+    p.nw = 1;
     return p;
   }
   // Tile shape: 4 waves (128 rows x 64 planes) when that still yields >= 2 workgroups per CU; the
@@ -1526,21 +1633,22 @@ int scn_set_tuning(int key, int value) {
   if (key == 5 && value >= 1) { g_dw_slices = value; return 0; }
   if (key == 6) { g_dw_dbg = value; return 0; }
   if (key == 7) { g_conv_small_tile4 = value; return 0; }
+  if (key == 8) { g_conv_expand = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
 #endif
 
 size_t scn_conv_wpack_bytes(int K, int Ci, int Co) { return (size_t)K * Ci * Co * 4; }
 
-size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co) {
+size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique) {
   if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
-  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co);
+  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
   return p.ksplit > 1 ? (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4 : 0;
 }
 
-int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co) {
+int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique) {
   if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
-  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co);
+  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
   return 100 * p.kind + p.ksplit;
 }
 
@@ -1560,15 +1668,15 @@ int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int 
 }
 
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const int32_t *rules, const int32_t *bases, int K,
-                     int64_t stride, int in_col, int out_col, int64_t n_in, int64_t n_out, int Ci, int Co,
-                     void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes, void *stream_) {
+                     const float *bias, const int32_t *rules, const int32_t *bases, const int32_t *counts, int K,
+                     int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in, int64_t n_out, int Ci,
+                     int Co, void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_forward: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_forward: in_col/out_col must be 0/1 or 1/0");
   SCN_REQUIRE(Ci > 0 && Co > 0, "scn_conv_forward: bad plane counts");
   if (n_out <= 0) return 0;
-  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co);
+  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique && counts != nullptr);
   if (p.kind != 0) {
     SCN_REQUIRE(wpack != nullptr, "scn_conv_forward: wpack workspace required");
     float *Wp = (float *)wpack;
@@ -1592,6 +1700,15 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
         case 2: return launch_tile<2, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
         default: return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
       }
+    }
+    if (p.kind == 5) {
+      const int ncb = Co / 64;
+      const int64_t nblk = (n_out + 31) / 32 + K;  // every output row in exactly one pair: sum_k ceil(count_k / 32) <= this
+      const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
+      k_conv_expand<<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, (const int2 *)rules, counts, K, stride,
+                                                             in_col, Ci, Co, ncb, in_bytes, wp_bytes);
+      SCN_CHECK_LAUNCH();
+      return 0;
     }
     if (p.ksplit > 1)
       SCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4,

@@ -69,8 +69,8 @@ int scn_peak_mfma_f32(float *scratch_dev, int waves_per_simd, double *tflops_hos
   SCN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
   const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
   *tflops_host = flops / ((double)ms * 1e-3) / 1e12;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return 0;
 }
 
@@ -93,8 +93,8 @@ int scn_peak_copy(const void *src, void *dst, int64_t bytes, int reps, double *g
     if (r > 0 && gbs > best) best = gbs;
   }
   *gbs_host = best;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return 0;
 }
 
@@ -117,8 +117,8 @@ int scn_peak_read(const void *src, float *sink_dev, int64_t bytes, int reps, dou
     if (r > 0 && gbs > best) best = gbs;
   }
   *gbs_host = best;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return 0;
 }
 

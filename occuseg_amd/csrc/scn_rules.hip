@@ -156,13 +156,15 @@ __device__ __forceinline__ int hash_lookup(const uint64_t *tkeys, const int32_t 
 // pass 1: probe the 27 neighbours of each site, write nbr[k][o], count per block
 __global__ void __launch_bounds__(256)
     k_sub_probe(const int4 *coords, int64_t N, const uint64_t *tkeys, const int32_t *tvals,
-                uint32_t mask, int32_t *nbr, int *blk_cnt, int nblk) {
+                uint32_t mask, int32_t *nbr, int *blk_cnt, int nblk, const int32_t *site_ori, int only_class) {
   __shared__ int wcnt[4][27];
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool valid = o < N;
   const int lane = lane_id(), w = threadIdx.x >> 6;
   int4 c = make_int4(0, 0, 0, 0);
   if (valid) c = coords[o];
+  // only_class >= 0: keep only the output sites whose orientation class (0 / 2 / 4) is only_class
+  const bool keep = valid && (only_class < 0 || site_ori[o] == only_class);
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     // k = (dx+1)*9 + (dy+1)*3 + (dz+1): sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:61-74
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(256)
         const int x = c.x + dx, y = c.y + dy, z = c.z + dz;
         if (in_key_box(x, y, z)) i = hash_lookup(tkeys, tvals, mask, voxel_key(x, y, z, c.w));
       }
+      if (!keep) i = -1;
       nbr[(int64_t)k * N + o] = i;
     }
     const unsigned long long m = __ballot(i >= 0);
@@ -184,6 +187,46 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x < 27) {
     const int k = threadIdx.x;
     blk_cnt[(int64_t)k * nblk + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+  }
+}
+
+// Normal-guided filters: the pair found at offset i for output site o goes to list rot[ori(o)][i]
+// (remap_rules_with_normal, sparseconvnet/SCN/Metadata/SubmanifoldConvolutionRules.h:213-245; the same table as
+// `rot_index`, sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:8-15; ori = OrientedFilter in {0, 2, 4}).  Here: permute the
+// probe results of each site (nbr_new[n][o] = nbr_old[inv(ori(o))[n]][o]) and count per NEW list, so that the ordinary
+// order-preserving fill produces the remapped lists sorted by output site.
+__constant__ int8_t c_rot_index[27 * 6] = {
+    0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,
+    24,25,26,21,22,23,18,19,20,15,16,17,12,13,14,9,10,11,6,7,8,3,4,5,0,1,2,
+    6,7,8,15,16,17,24,25,26,3,4,5,12,13,14,21,22,23,0,1,2,9,10,11,18,19,20,
+    18,19,20,9,10,11,0,1,2,21,22,23,12,13,14,3,4,5,24,25,26,15,16,17,6,7,8,
+    2,11,20,5,14,23,8,17,26,1,10,19,4,13,22,7,16,25,0,9,18,3,12,21,6,15,24,
+    18,9,0,21,12,3,24,15,6,19,10,1,22,13,4,25,16,7,20,11,2,23,14,5,26,17,8};
+
+__global__ void __launch_bounds__(256)
+    k_nbr_remap(const int32_t *nbr_old, int32_t *nbr_new, const int32_t *site_ori, int64_t N, int *blk_cnt, int nblk) {
+  __shared__ int wcnt[4][27];
+  __shared__ int8_t inv[6][27];
+  if (threadIdx.x < 27 * 6) inv[threadIdx.x / 27][c_rot_index[threadIdx.x]] = (int8_t)(threadIdx.x % 27);
+  __syncthreads();
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = o < N;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int ori = valid ? site_ori[o] : 0;
+#pragma unroll
+  for (int n = 0; n < 27; ++n) {
+    int i = -1;
+    if (valid) {
+      i = nbr_old[(int64_t)inv[ori][n] * N + o];
+      nbr_new[(int64_t)n * N + o] = i;
+    }
+    const unsigned long long m = __ballot(i >= 0);
+    if (lane == 0) wcnt[w][n] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int n = threadIdx.x;
+    blk_cnt[(int64_t)n * nblk + blockIdx.x] = wcnt[0][n] + wcnt[1][n] + wcnt[2][n] + wcnt[3][n];
   }
 }
 
@@ -469,9 +512,12 @@ size_t scn_rules_temp_bytes(int64_t N, int K) {
 int scn_submanifold_rules(const int32_t *site_coords, int64_t N, const uint64_t *table_keys,
                           const int32_t *table_vals, int64_t capacity, int32_t *nbr,
                           int32_t *rules, int32_t *counts, void *temp, size_t temp_bytes,
-                          void *stream_) {
+                          const int32_t *site_ori, int mode, int only_class, int32_t *nbr_tmp, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(temp_bytes >= scn_rules_temp_bytes(N, 27), "scn_submanifold_rules: workspace too small");
+  SCN_REQUIRE(mode == 0 || site_ori != nullptr, "scn_submanifold_rules: site_ori required for modes 1 and 2");
+  SCN_REQUIRE(mode != 1 || nbr_tmp != nullptr, "scn_submanifold_rules: nbr_tmp [27][N] required for mode 1");
+  SCN_REQUIRE(mode != 2 || only_class == 0 || only_class == 2 || only_class == 4, "scn_submanifold_rules: class must be 0, 2 or 4");
   if (N <= 0) {
     SCN_CHECK_HIP(hipMemsetAsync(counts, 0, 27 * 4, stream));
     return 0;
@@ -479,8 +525,13 @@ int scn_submanifold_rules(const int32_t *site_coords, int64_t N, const uint64_t 
   const int nblk = (int)((N + 255) / 256);
   int *blk_cnt = (int *)temp;
   k_sub_probe<<<nblk, 256, 0, stream>>>((const int4 *)site_coords, N, table_keys, table_vals,
-                                       (uint32_t)(capacity - 1), nbr, blk_cnt, nblk);
+                                       (uint32_t)(capacity - 1), mode == 1 ? nbr_tmp : nbr, blk_cnt, nblk, site_ori,
+                                       mode == 2 ? only_class : -1);
   SCN_CHECK_LAUNCH();
+  if (mode == 1) {
+    k_nbr_remap<<<nblk, 256, 0, stream>>>(nbr_tmp, nbr, site_ori, N, blk_cnt, nblk);
+    SCN_CHECK_LAUNCH();
+  }
   k_excl_scan_rows<<<27, 1024, 0, stream>>>(blk_cnt, nblk, counts);
   SCN_CHECK_LAUNCH();
   k_rules_fill<27><<<nblk, 256, 0, stream>>>(nbr, N, blk_cnt, nblk, (int2 *)rules);

@@ -17,6 +17,7 @@ from .io import InputLayer, OutputLayer  # noqa: E402,F401
 from .norm import BatchNormalization, BatchNormLeakyReLU, BatchNormReLU  # noqa: E402,F401
 from .tensor import Metadata, SparseConvNetTensor, optionalTensor, optionalTensorReturn, toLongTensor  # noqa: E402,F401
 from .unet import UNet  # noqa: E402,F401
+from .utils import add_feature_planes, upsample_feature  # noqa: E402,F401
 
 _OUT_OF_SCOPE = (
     "Tanh Sigmoid ReLU LeakyReLU ELU SELU BatchNormELU AveragePooling MeanOnlyBNLeakyReLU "

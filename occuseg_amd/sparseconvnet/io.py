@@ -78,8 +78,12 @@ class InputLayer(Module):
         stream (occuseg_amd.SCN.prefetch_input).  ``input[0]`` must be the same (int64 / int32 / float32) tensor object that will be
         passed to ``forward`` and must not change in between."""
         coords, features = input[0], input[1]
+        normals = input[2] if len(input) > 2 else None
+        use_normal = (torch.is_tensor(normals) and normals.dim() == 2 and normals.size(0) == features.size(0)
+                      and normals.size(1) == 3)
         SCN.prefetch_input(self.spatial_size, coords, self.mode, device if device is not None else features.device,
-                           wait_for_current_stream)
+                           wait_for_current_stream, normals=normals if use_normal else None,
+                           normal_guide_scale=self.normal_guide_scale)
 
 
 class OutputLayer(Module):

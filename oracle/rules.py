@@ -190,3 +190,77 @@ def strided_rules(grid):
         rules.append(np.stack([fine_ids[m], inv[m]], 1).astype(np.int32))
         child[inv[m], k] = fine_ids[m]
     return coarse, rules, child
+
+
+# ------------------------------------------------------- normal-guided filters ---
+# rot_index (sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:8-15) = the `index` table of remap_rules_with_normal
+# (sparseconvnet/SCN/Metadata/SubmanifoldConvolutionRules.h:217-223): rows = orientation classes 0..5 (only 0, 2, 4 are
+# ever produced by OrientedFilter), columns = original offset, entry = list the pair moves to.
+ROT_INDEX = np.array([
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26,
+    24, 25, 26, 21, 22, 23, 18, 19, 20, 15, 16, 17, 12, 13, 14, 9, 10, 11, 6, 7, 8, 3, 4, 5, 0, 1, 2,
+    6, 7, 8, 15, 16, 17, 24, 25, 26, 3, 4, 5, 12, 13, 14, 21, 22, 23, 0, 1, 2, 9, 10, 11, 18, 19, 20,
+    18, 19, 20, 9, 10, 11, 0, 1, 2, 21, 22, 23, 12, 13, 14, 3, 4, 5, 24, 25, 26, 15, 16, 17, 6, 7, 8,
+    2, 11, 20, 5, 14, 23, 8, 17, 26, 1, 10, 19, 4, 13, 22, 7, 16, 25, 0, 9, 18, 3, 12, 21, 6, 15, 24,
+    18, 9, 0, 21, 12, 3, 24, 15, 6, 19, 10, 1, 22, 13, 4, 25, 16, 7, 20, 11, 2, 23, 14, 5, 26, 17, 8], np.int64).reshape(6, 27)
+
+
+def site_normals(point_normals, table):
+    """per-site normal = normalize(mean of the normals of the site's input points), float32 arithmetic in the
+    reference's order (sparseconvnet/SCN/CUDA/IOLayers.cpp:43-62; Float3::normalize, sparseconvnet/SCN/Metadata/
+    Metadata.h:95-101: left as it is when its length is < 1e-8).  table = the input rule table [N, 1+maxActive]."""
+    pn = np.asarray(point_normals, np.float32)
+    N = table.shape[0]
+    out = np.zeros((N, 3), np.float32)
+    for s in range(N):
+        cnt = int(table[s, 0])
+        acc = np.zeros(3, np.float32)
+        for j in range(cnt):
+            acc = (acc + pn[table[s, 1 + j]]).astype(np.float32)
+        if cnt > 0:
+            acc = (acc / np.float32(cnt)).astype(np.float32)
+        mag = np.sqrt(np.float32(acc[0] * acc[0]) + np.float32(acc[1] * acc[1]) + np.float32(acc[2] * acc[2]), dtype=np.float32)
+        if not mag < 1e-8:
+            acc = (acc * (np.float32(1) / mag)).astype(np.float32)
+        out[s] = acc
+    return out
+
+
+def oriented_filter(normals):
+    """OrientedFilter (sparseconvnet/SCN/Metadata/RectangularRegions.h:12-32): 0 when |x| is the largest component
+    (ties first), 2 for |y|, 4 for |z|"""
+    a = np.abs(np.asarray(normals, np.float32))
+    x, y, z = a[:, 0], a[:, 1], a[:, 2]
+    face = np.zeros(len(a), np.int64)
+    is_x = (x >= y) & (x >= z)
+    is_y = ~is_x & (y >= x) & (y >= z)
+    is_z = ~is_x & ~is_y & (z >= x) & (z >= y)
+    face[is_y] = 2
+    face[is_z] = 4
+    return face
+
+
+def remap_rules_with_normal(rules, ori):
+    """remap_rules_with_normal (sparseconvnet/SCN/Metadata/SubmanifoldConvolutionRules.h:213-245): walk the old lists
+    i = 0..26 in order, every pair (in, out) is appended to list ROT_INDEX[ori[out]][i]."""
+    new = [[] for _ in range(27)]
+    for i in range(27):
+        r = rules[i]
+        if len(r):
+            tgt = ROT_INDEX[ori[r[:, 1]], i]
+            for n in np.unique(tgt):
+                new[n].append(r[tgt == n])
+    return [np.concatenate(x).astype(np.int32) if x else np.zeros((0, 2), np.int32) for x in new]
+
+
+def resolution_based_scattering(points_lr, points_hr, stride):
+    """ResolutionBasedScatteringCuda (sparseconvnet/SCN/Metadata/ConvolutionRules.h:327-342) for one sample: rank of
+    key(points_hr / stride) among the unique sorted keys of points_lr, or -1."""
+    lr = np.asarray(points_lr, np.int64)
+    hr = np.asarray(points_hr, np.int64) // int(stride)
+    keys = np.unique(key31(lr[:, 0], lr[:, 1], lr[:, 2]))
+    q = key31(hr[:, 0], hr[:, 1], hr[:, 2])
+    pos = np.searchsorted(keys, q)
+    ok = in_box(hr[:, 0], hr[:, 1], hr[:, 2]) & (pos < len(keys))
+    ok &= keys[np.minimum(pos, len(keys) - 1)] == q
+    return np.where(ok, pos, -1).astype(np.int32)

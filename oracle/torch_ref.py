@@ -81,7 +81,12 @@ def _bn(mod, x, dtype, stats):
         invstd = (mod.running_var.cpu().to(dtype) + mod.eps) ** -0.5
     w = invstd * (g if g is not None else 1.0)
     y = x * w + ((b if b is not None else 0.0) - mean * w)
-    return torch.where(y > 0, y, y * mod.leakiness)
+    # stats["masks"][id(module)]: activation mask to USE instead of this evaluation's own sign of y (the device's mask:
+    # an element with |y| ~ 1e-7 has a different sign in fp32 and fp64, and one flipped mask moves every gradient
+    # upstream of it by a whole term -- with the device's masks the backward pass can be compared at 1e-4)
+    pos = stats["masks"].get(id(mod)) if stats.get("masks") else None
+    stats.setdefault("own_masks", {})[id(mod)] = (y > 0).detach()
+    return torch.where(y > 0 if pos is None else pos, y, y * mod.leakiness)
 
 
 def _param(mod, name, dtype, stats):
@@ -133,10 +138,11 @@ def _run(mod, t, ctx, dtype, stats):
     raise NotImplementedError(type(mod))
 
 
-def ref_forward(net, coords, feats, dtype=torch.float64):
+def ref_forward(net, coords, feats, dtype=torch.float64, masks=None):
     """net: Sequential whose first child is an InputLayer.  Returns (output tensor with grad graph,
     stats) where stats['params'][id(module)][name] are leaf tensors holding the grads after backward,
-    stats['bn'][id(module)] = (batch mean, unbiased batch var)."""
+    stats['bn'][id(module)] = (batch mean, unbiased batch var), stats['own_masks'][id(module)] = this evaluation's
+    y > 0.  masks: {id(batch-norm module): bool tensor} = activation masks to use instead (see _bn)."""
     from occuseg_amd.sparseconvnet import io as IO
     children = list(net._modules.values())
     inp = children[0]
@@ -155,7 +161,7 @@ def ref_forward(net, coords, feats, dtype=torch.float64):
         m = cnt > j
         idx = torch.from_numpy(table[:, 1 + j].astype(np.int64))[m]
         x[m] += mult[m, None] * f[idx]
-    stats = {"params": {}, "bn": {}, "ctx": ctx}
+    stats = {"params": {}, "bn": {}, "ctx": ctx, "masks": masks}
     t = _T(x, size)
     for ch in children[1:]:
         t = _run(ch, t, ctx, dtype, stats)

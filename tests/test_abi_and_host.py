@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
     assert not hasattr(lib, "scn_set_tuning") and not hasattr(lib, "scn_debug_stamps")
     assert os.path.exists(_lib.TUNING_LIB_PATH)
     # launches with many output tiles need no workspace; a coarse level (few tiles) splits its offsets 9- or 27-fold
-    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64) == 0
-    ws = lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384)
+    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64, 0) == 0
+    ws = lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384, 0)
     assert ws % (2000 * 384 * 4) == 0 and ws // (2000 * 384 * 4) in (3, 9, 27)
     # size queries are host-only arithmetic: safe without a GPU
     assert lib.scn_hash_capacity(1000) == 2048

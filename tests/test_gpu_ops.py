@@ -194,21 +194,24 @@ def test_cpu_tensors_are_refused():
                                             torch.ones(16), torch.empty(0), torch.empty(0), 1e-4, 0.9, True, 1.0)
 
 
-@pytest.mark.parametrize("ci,co", [(128, 64), (64, 32), (20, 12)])
-def test_network_in_network(gpu, ci, co):
-    """1x1 convolution: gather-mm kernels over the identity rulebook (planes % 32 == 0) or library GEMM"""
+@pytest.mark.parametrize("ci,co,with_bias", [(128, 64, False), (256, 128, True), (192, 64, True), (64, 32, False),
+                                             (20, 12, True)])
+def test_network_in_network(gpu, ci, co, with_bias):
+    """1x1 convolution: the one-contribution-per-row kernel over the identity rulebook (planes % 64 == 0: k_conv_expand;
+    % 32: the tile kernels) or a library GEMM; with and without bias; 1, 3 and 4 chunks of C_i"""
     from occuseg_amd import SCN
     from oracle import arith as A
     rng = np.random.default_rng(ci + co)
     n = 3001
     x = rng.normal(size=(n, ci)).astype(np.float32)
     w = (rng.normal(size=(ci, co)) * (2.0 / ci) ** 0.5).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32) if with_bias else None
     dy = rng.normal(size=(n, co)).astype(np.float32)
     e = torch.empty(0, device=gpu)
     out = torch.empty(0, device=gpu)
-    macs = SCN.NetworkInNetwork_updateOutput(_t(x, gpu), out, _t(w, gpu), e)
+    macs = SCN.NetworkInNetwork_updateOutput(_t(x, gpu), out, _t(w, gpu), _t(b, gpu) if with_bias else e)
     assert macs == float(n) * ci * co
-    assert_close(out.cpu().numpy(), A.nin_forward(x, w, dtype=np.float64), "NiN fwd")
+    assert_close(out.cpu().numpy(), A.nin_forward(x, w, b, dtype=np.float64), "NiN fwd")
     d_in, d_w, _ = A.nin_backward(x, dy, w, dtype=np.float64)
     gi, gw = torch.empty(0, device=gpu), torch.full((ci, co), 7.0, device=gpu)
     SCN.NetworkInNetwork_updateGradInput(gi, _t(dy, gpu), _t(w, gpu))

@@ -239,3 +239,49 @@ def test_oracle_against_hand_derived_literal_vectors():
     extra = L.reference_alias_pairs()
     assert sum(len(v) for v in extra.values()) == 49 and all(i == 6 for v in extra.values() for i, _ in v)
     assert 13 not in extra and 26 not in extra and 22 not in extra
+
+
+def test_normal_guided_remap_restatement():
+    """oracle/rules.py's restatement of remap_rules_with_normal / OrientedFilter / the per-site normal average:
+    structural facts the reference code implies (SubmanifoldConvolutionRules.h:213-245, RectangularRegions.h:12-32)."""
+    from oracle import rules as R
+    rng = np.random.default_rng(0)
+    pts = np.concatenate([rng.integers(0, 12, (500, 3)), np.zeros((500, 1), np.int64)], 1)
+    grid, _, table, _ = R.input_layer_rules(pts)
+    pn = rng.normal(size=(500, 3)).astype(np.float32)
+    sn = R.site_normals(pn, table)
+    assert np.allclose(np.linalg.norm(sn, axis=1), 1.0, atol=1e-5)
+    ori = R.oriented_filter(sn)
+    assert set(np.unique(ori)) <= {0, 2, 4}
+    assert R.oriented_filter(np.array([[1, 1, 1], [0, 2, -2], [0, 0, 0], [-3, 1, 1]], np.float32)).tolist() == [0, 2, 0, 0]
+    for o in range(6):  # every class permutes the offsets and keeps the centre
+        assert sorted(R.ROT_INDEX[o]) == list(range(27)) and R.ROT_INDEX[o][13] == 13
+    rules, _ = R.submanifold_rules(grid)
+    new = R.remap_rules_with_normal(rules, ori)
+    assert sum(len(r) for r in new) == sum(len(r) for r in rules)
+    assert np.array_equal(new[13], rules[13])
+    for n, r in enumerate(new):
+        assert len(np.unique(r[:, 1])) == len(r)  # an output site at most once per list
+        # pairs of class-0 outputs did not move
+        keep = rules[n][ori[rules[n][:, 1]] == 0]
+        got = r[ori[r[:, 1]] == 0]
+        assert np.array_equal(got, keep)
+    # all-x normals: nothing moves at all
+    same = R.remap_rules_with_normal(rules, np.zeros(grid.n, np.int64))
+    assert all(np.array_equal(a, b) for a, b in zip(same, rules))
+    # cross-scale lookup
+    coarse, _, _ = R.strided_rules(grid)
+    idx = R.resolution_based_scattering(coarse.coords[:, :3], grid.coords[:, :3], 2)
+    assert np.array_equal(coarse.coords[idx, :3], grid.coords[:, :3] >> 1)
+
+
+def test_scatter_oracle_formulas():
+    from oracle import scatter as O
+    src = np.array([[1.0, 2.0], [3.0, 6.0], [5.0, 1.0], [7.0, 7.0]])
+    idx = np.array([0, 0, 2, 0])
+    assert O.scatter_add(src, idx, 4).tolist() == [[11, 15], [0, 0], [5, 1], [0, 0]]
+    assert np.allclose(O.scatter_mean(src, idx, 4), [[11 / 3, 5], [0, 0], [5, 1], [0, 0]])
+    assert np.allclose(O.scatter_std(src, idx, 4)[0], np.std(src[[0, 1, 3]], axis=0, ddof=1))
+    assert np.allclose(O.scatter_std(src, idx, 4)[2], 0)  # a single element: count - 1 clamped to 1
+    mx, arg = O.scatter_max(src, idx, 4)
+    assert mx.tolist() == [[7, 7], [0, 0], [5, 1], [0, 0]] and arg.tolist() == [[3, 3], [4, 4], [2, 2], [4, 4]]
