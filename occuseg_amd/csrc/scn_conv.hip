@@ -963,12 +963,15 @@ __device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], con
 // unit of work is 32 consecutive PAIRS of one list x 64 output planes, owned by one wave: the whole C_i reduction runs
 // in registers (A = weight fragments, B = the gathered rows fetched straight from global memory in fragment shape, as
 // in k_conv_tile4), the result is stored straight to the 32 output rows.  No LDS, no barrier, no atomics.  C_i is
-// walked in chunks of 64 planes, the loads of chunk c+1 requested before the MFMAs of chunk c.
+// walked in chunks of 32 planes, the loads of chunk c+1 requested before the MFMAs of chunk c.
 __global__ void __launch_bounds__(64)
     k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                   const float *__restrict__ bias, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
                   int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes, unsigned wp_bytes) {
-  constexpr int CK = 64, NS16 = 4, COS = 4, PB = 32;
+  // chunks of 32 reduction planes: 2 x (8 row + 32 weight) registers in flight + 32 accumulators keep the wave at
+  // ~150 VGPRs = three waves per SIMD (with 64-plane chunks it needed 272: one wave per SIMD, and a launch of
+  // single-chunk waves -- NiN 64 -> 128 on 600k rows -- ran at a third of the speed of the tile kernel it replaced)
+  constexpr int CK = 32, NS16 = 2, COS = 4, PB = 32;
   const int lane = threadIdx.x;
   const int li = lane & 15, lq = lane >> 4;
   // (list, block of 32 pairs, plane block) of this wave: blocks are numbered list after list
@@ -1032,13 +1035,11 @@ __global__ void __launch_bounds__(64)
             acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q][sp][e], r[g][sp][e], acc[g][q], 0, 0, 0);
   };
   load(0, rA, wA);
-  for (int c = 0; c < nch; c += 2) {
-    if (c + 1 < nch) load(c + 1, rB, wB);
+  for (int c = 0; c < nch; c += 2) {  // Ci % 64 == 0: an even number of 32-plane chunks
+    load(c + 1, rB, wB);
     mma(rA, wA);
-    if (c + 1 < nch) {
-      if (c + 2 < nch) load(c + 2, rA, wA);
-      mma(rB, wB);
-    }
+    if (c + 2 < nch) load(c + 2, rA, wA);
+    mma(rB, wB);
   }
   // D[i = plane][j = pair]: lane (li, lq) holds planes 16 q + 4 lq .. + 3 of pair li
 #pragma unroll

@@ -90,8 +90,9 @@ def test_normal_guided_convolution_fwd_bwd(gpu, ci, co):
     assert_close(out.detach().cpu().numpy(), want, "normal-guided forward")
     dy = rng.normal(size=want.shape).astype(np.float32)
     xt = t.features
-    g_x, = torch.autograd.grad(out, xt, torch.from_numpy(dy).to(gpu), retain_graph=True)
+    xt.retain_grad()
     out.backward(torch.from_numpy(dy).to(gpu))
+    g_x = xt.grad
     d_in, d_w, d_b = A.conv_backward(xs, dy, w, rules, want_bias=True, dtype=np.float64)
     assert_close(g_x.cpu().numpy(), d_in, "normal-guided dInput")
     assert_close(conv.weight.grad.cpu().numpy(), d_w, "normal-guided dWeight")

@@ -49,3 +49,26 @@ def test_instance_dense_unet_builds_unchanged():
     net2 = ref.LearningBWDenseUNet(config)
     net2.load_state_dict(sd, strict=True)
     assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+
+
+@pytest.mark.skipif(not os.path.exists(MODEL), reason="reference tree not present")
+def test_fixture_g6_belongs_to_the_reference_class():
+    """tests/golden/g6_instance_dense_unet.npz was generated from the reference's own model.py (make_g6.py): the
+    reference class, seeded the same way, still has the parameters the fixture recorded, and tests/instance_unet.py's
+    rebuild (what the GPU test uses) is bit-identical to it."""
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    sys.path.insert(0, here)
+    import instance_unet as IU
+    import make_g6
+    scn, ref = make_g6.load_reference_model()
+    g = np.load(os.path.join(here, "golden", "g6_instance_dense_unet.npz"))
+    torch.manual_seed(int(g["seed"]))
+    a = ref.LearningBWDenseUNet(IU.config(int(g["m"])))
+    torch.manual_seed(int(g["seed"]))
+    b = IU.LearningBWDenseUNet(scn, IU.config(int(g["m"])))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    checksum = sum(float(v.double().sum()) for v in sa.values())
+    assert abs(checksum - float(g["checksum_params"])) <= 1e-9 * abs(checksum)
