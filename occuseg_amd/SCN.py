@@ -245,11 +245,14 @@ class Metadata_3(object):
         if PREBUILD and old_plan:
             pending = []
             for req in old_plan:
-                if req[0] == "sub":
-                    rb = self.getSubmanifoldRuleBook(req[1], req[2], _defer=True)
-                    pending.append(rb)
-                else:
-                    self.getRuleBook(req[1], req[2], req[3], req[4], _defer=True)
+                try:
+                    if req[0] == "sub":
+                        rb = self.getSubmanifoldRuleBook(req[1], req[2], _defer=True)
+                        pending.append(rb)
+                    else:
+                        self.getRuleBook(req[1], req[2], req[3], req[4], _defer=True)
+                except NotImplementedError:
+                    break  # not buildable for THIS batch (e.g. normals now guide a strided scale): the op itself will say so
             if pending:  # ONE device->host copy for the pair counts of all submanifold rulebooks
                 totals = torch.stack([rb.counts.sum() for rb in pending]).cpu().tolist()
                 for rb, t in zip(pending, totals):

@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(128)
         if (DBG & 1) {
           asm volatile("" ::"v"(a[i][q]));
         } else {  // absent group / padded pair: sink row, += 0 or garbage nobody reads
-          *(floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq) = old[i][q] + a[i][q];
+          *(floatx4 *)__builtin_assume_aligned(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq, 16) = old[i][q] + a[i][q];
         }
       }
   };
@@ -744,7 +744,9 @@ __global__ void __launch_bounds__(128)
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < COS; ++q)
-        if (!(DBG & 1)) old[i][q] = *(const floatx4 *)(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq);
+        // (without the assumption hipcc loses the 16-byte alignment through the rotating row variables and emits two
+        //  ds_read2_b32 / ds_write2_b32 per fragment instead of one ds_read_b128 / ds_write_b128)
+        if (!(DBG & 1)) old[i][q] = *(const floatx4 *)__builtin_assume_aligned(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq, 16);
   };
   unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 
@@ -843,7 +845,7 @@ __global__ void __launch_bounds__(128)
             if (DBG & 1) {
               asm volatile("" ::"v"(prev[i][q]));
             } else {
-              *(floatx4 *)(o_tile + op[i] + 32 * w + 16 * q + 4 * lq) = old[i][q] + prev[i][q];
+              *(floatx4 *)__builtin_assume_aligned(o_tile + op[i] + 32 * w + 16 * q + 4 * lq, 16) = old[i][q] + prev[i][q];
             }
           }
         } else if (m == 15) {    // table entry p+4
