@@ -935,6 +935,363 @@ __global__ void __launch_bounds__(128)
   }
 }
 
+// ------------------------------ forward, barrier-free, ONE wave per tile (v5) ---
+// k_conv_tile4 with the other division of labour: the workgroup is a single wave that owns all 64 output planes of
+// the 128-row tile (four 16-plane slices), so every gathered row is fetched once instead of once per wave, and a pass
+// of 32 pairs carries 128 MFMAs instead of 64 behind the same 8 row loads, 2 index loads and scalar bookkeeping (the
+// weight loads and the output-tile traffic per MFMA stay as they were).  Occupancy is one wave per SIMD (four 39 KB
+// tiles per CU, as before): everything that hid behind the partner wave has to hide behind the wave's own MFMAs.
+// Same pass table, same load order (16 weight, 2 index, 8 row), same hand-counted waits as k_conv_tile4.
+template <int DBG = 0>
+__global__ void __launch_bounds__(64)
+    k_conv_tile5(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
+                 const float *__restrict__ bias, const int2 *__restrict__ rules,
+                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
+                 unsigned in_bytes, unsigned wp_bytes, int ksplit) {
+  constexpr int M = 128, COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 4;
+  constexpr int TMAX = KMAX * 4 * SCN_TILE4_MAX_CHUNKS + 8;  // passes per tile: <= 4 per (offset, chunk); + sentinels
+  __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
+  __shared__ __attribute__((aligned(8))) unsigned ptab[TMAX][2];  // {byte offset of the pass's first pair in `rules`,
+                                                                  //  pairs left in the list | chunk<<8 | k<<12 | first<<20}
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  constexpr int w = 0;  // one wave per workgroup: it owns all 64 planes of the tile
+  const int li = lane & 15, lq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ru_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)rules, 0, (int)(K * stride * 8), 0x00020000);
+
+  int lin;
+  {
+    // Workgroup b runs on XCD b % 8.  Each XCD takes CHUNKS of consecutive tiles (neighbouring tiles gather
+    // overlapping rows: shared L2), dealt round robin so that density differences along the row order (whole scenes)
+    // do not leave some XCDs with more work than others; the ragged end falls back to one contiguous range each.
+    const int total = ntiles * ncb;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int CH = 64 * ncb;
+    const int full = (DBG & 512) ? 0 : (total / (8 * CH)) * (8 * CH);  // part that divides into rounds of 8 chunks
+    if (bid < full) {
+      lin = ((j / CH) * 8 + xcd) * CH + j % CH;
+    } else {
+      const int rest = total - full, b2 = bid - full, x2 = b2 & 7, j2 = b2 >> 3;
+      const int q = rest >> 3, r = rest & 7;
+      lin = full + (x2 < r ? x2 * (q + 1) : r * (q + 1) + (x2 - r) * q) + j2;
+    }
+  }
+  const int tile = lin / ncb;
+  const int co0 = (lin % ncb) * COB;
+  const int64_t o0 = (int64_t)tile * M;
+  const int g0 = tile * (M / SCN_TILE_GRANULE);
+  const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
+  const int nch = Ci / CK;
+
+  for (int i = lane; i < (M + 1) * 16; i += 64) {
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    floatx4 v = {0.f, 0.f, 0.f, 0.f};
+    if (bias && blockIdx.y == 0) v = *(const floatx4 *)(bias + co0 + c4);
+    *(floatx4 *)(o_tile + r * OS + c4) = v;
+  }
+  if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
+    int s = 0, c = 0;
+    // ksplit > 1 (launches with few tiles, the coarse UNet levels): this workgroup takes the offsets k == blockIdx.y
+    // (mod ksplit) and writes its partial tile to slab blockIdx.y of the launcher's workspace (k_split_reduce adds them)
+    if (tid < K && tid % ksplit == (int)blockIdx.y) {
+      s = bases[(int64_t)tid * (n_gran + 1) + g0];
+      c = bases[(int64_t)tid * (n_gran + 1) + g1] - s;
+    }
+    const int npl = (c + 31) >> 5;  // passes per chunk
+    int pos = npl * nch;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(pos, o);
+      if (lane >= o) pos += y;
+    }
+    const int total = __shfl(pos, 63);
+    pos -= npl * nch;
+    const unsigned first = (unsigned)(((int64_t)tid * stride + s) * 8);
+    for (int chn = 0; chn < nch; ++chn)
+      for (int j = 0; j < npl; ++j) {
+        ptab[pos][0] = first + (unsigned)j * 256u;
+        ptab[pos][1] = (unsigned)(c - 32 * j) | (unsigned)chn << 8 | (unsigned)tid << 12 | (j == 0 ? 1u << 20 : 0u);
+        ++pos;
+      }
+    if (tid < 8) {  // sentinels: empty passes
+      ptab[total + tid][0] = 0u;
+      ptab[total + tid][1] = 0u;
+    }
+  }
+  __syncthreads();  // the only barrier
+  auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+  // offset of the loads a pass does not need (absent second group, passes past the end): the first bytes of the buffer
+  // (always valid; what they fetch is multiplied by nothing or lands in the sink row).  Pointing them past the end of the
+  // buffer instead (DBG & 8192: the range check returns 0 without touching memory) is 0.5-2 % SLOWER.
+  constexpr unsigned OOB = (DBG & 8192) ? 0x80000000u : 0u;
+  struct Ent { unsigned base, meta; };  // meta & 255: pairs left (0: no such pass)
+  auto entry = [&](int p) __attribute__((always_inline)) {
+    const uint2 v = *(const uint2 *)ptab[p];
+    return Ent{(unsigned)uni((int)v.x), (unsigned)uni((int)v.y)};
+  };
+  auto rem = [](const Ent &e) __attribute__((always_inline)) { return (int)(e.meta & 255u); };
+  // per-lane byte offsets of a pass's two index loads
+  auto index_offsets = [&](const Ent &e, unsigned (&vo)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vo[i] = (16 * i < rem(e) && !(DBG & 4096)) ? (unsigned)min(16 * i + li, rem(e) - 1) * 8u : OOB;
+  };
+  // row byte offsets / output-tile rows of a pass from its pair indices
+  auto addr = [&](const Ent &e, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned src = in_col ? pr[i].y : pr[i].x;
+      const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
+      off[i] = (16 * i < rem(e) && !(DBG & 2)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
+      orow[i] = (16 * i + li < rem(e)) ? dst * OS : M * OS;
+    }
+  };
+  auto weight_scalars = [&](const Ent &e, int (&so)[NS16], unsigned &voff, bool &fresh) __attribute__((always_inline)) {
+    const int k = (int)(e.meta >> 12) & 255, chn = (int)(e.meta >> 8) & 15;
+    fresh = (e.meta >> 20) & 1u;
+    const int blk = (k * (Ci / 16) + chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS;
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp) so[sp] = (blk + sp * (Co / 16)) * 1024;
+    voff = (fresh && !(DBG & 8)) ? (unsigned)lane * 16u : OOB;
+  };
+  auto load_idx = [&](const Ent &e, const unsigned (&vo)[2], u32x2 (&pr)[2]) __attribute__((always_inline)) {
+    const int base = (int)e.base;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(pr[i]) : "v"(vo[i]), "s"(ru_rsrc), "s"(base) : "memory");
+  };
+  auto load_rows = [&](int i, unsigned voff, int so, floatx4 (&rows)[2][NS16]) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rows[i][0]) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rows[i][1]) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rows[i][2]) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rows[i][3]) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+  };
+  auto load_weights = [&](int sp, unsigned voff, int so, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wr[0][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(wr[1][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=v"(wr[2][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:3072" : "=v"(wr[3][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+  };
+  // the NEXT phase's weights are loaded straight into accumulation registers (buffer loads may target AGPRs on gfx950):
+  // 64 registers that do not compete with the rows and the current weights for the 256 VGPRs of the wave -- with all of
+  // it in VGPRs hipcc parked freshly requested (still in flight!) load targets in AGPRs by itself
+  auto load_weights_a = [&](int sp, unsigned voff, int so, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(wr[0][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=a"(wr[1][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=a"(wr[2][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:3072" : "=a"(wr[3][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+  };
+#define SCN_ROWS(R) "v"(R[0][0]), "v"(R[0][1]), "v"(R[0][2]), "v"(R[0][3]), "v"(R[1][0]), "v"(R[1][1]), "v"(R[1][2]), "v"(R[1][3])
+#define SCN_WTS(R) SCN_ROWS(R), "v"(R[2][0]), "v"(R[2][1]), "v"(R[2][2]), "v"(R[2][3]), "v"(R[3][0]), "v"(R[3][1]), "v"(R[3][2]), "v"(R[3][3])
+#define SCN_WTS_A(R) "a"(R[0][0]), "a"(R[0][1]), "a"(R[0][2]), "a"(R[0][3]), "a"(R[1][0]), "a"(R[1][1]), "a"(R[1][2]), "a"(R[1][3]), \
+                     "a"(R[2][0]), "a"(R[2][1]), "a"(R[2][2]), "a"(R[2][3]), "a"(R[3][0]), "a"(R[3][1]), "a"(R[3][2]), "a"(R[3][3])
+  auto scatter = [&](const floatx4 (&a)[2][COS], const floatx4 (&old)[2][COS], const int (&orow)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < COS; ++q) {
+        if (DBG & 1) {
+          asm volatile("" ::"v"(a[i][q]));
+        } else {  // absent group / padded pair: sink row, += 0 or garbage nobody reads
+          *(floatx4 *)__builtin_assume_aligned(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq, 16) = old[i][q] + a[i][q];
+        }
+      }
+  };
+  auto tile_rows = [&](floatx4 (&old)[2][COS], const int (&orow)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < COS; ++q)
+        // (without the assumption hipcc loses the 16-byte alignment through the rotating row variables and emits two
+        //  ds_read2_b32 / ds_write2_b32 per fragment instead of one ds_read_b128 / ds_write_b128)
+        if (!(DBG & 1)) old[i][q] = *(const floatx4 *)__builtin_assume_aligned(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq, 16);
+  };
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+
+  Ent E0 = entry(0);
+  if (rem(E0) > 0) {
+    // ---- pipeline state at the top of pass p: rows(p) in rc, rows(p+1) in rm (arrived), weights(p) in wc, indices of
+    // pass p+2 in pr (arrived); E0..E3 = table entries p..p+3; `ioff` = index-load offsets of pass p+3.
+    u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
+    unsigned off[2], ioff[2];
+    floatx4 rA[2][NS16], rB[2][NS16], rC[2][NS16], wc[COS][NS16], wn[COS][NS16], prev[2][COS];
+    int o0r[2], o1r[2], o2r[2], op[2] = {M * OS, M * OS};  // output-tile rows of pass p, p+1, p+2, p-1
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < COS; ++q) prev[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    Ent E1 = entry(1), E2 = entry(2), E3 = entry(3);
+    int pnext = 4;  // table index of the entry read during the current pass
+    {  // prologue (not overlapped; once per tile)
+      int so[NS16];
+      unsigned voff;
+      bool fresh;
+      index_offsets(E0, ioff);
+      load_idx(E0, ioff, pr);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      addr(E0, pr, off, o0r);
+      weight_scalars(E0, so, voff, fresh);
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp) load_weights(sp, (DBG & 8) ? OOB : (unsigned)lane * 16u, so[sp], wc);
+      load_rows(0, off[0], (int)((E0.meta >> 8) & 15u) * (CK * 4), rA);
+      load_rows(1, off[1], (int)((E0.meta >> 8) & 15u) * (CK * 4), rA);
+      __builtin_amdgcn_sched_barrier(0);
+      index_offsets(E1, ioff);
+      load_idx(E1, ioff, pr);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]), SCN_ROWS(rA), SCN_WTS(wc) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      addr(E1, pr, off, o1r);
+      load_rows(0, off[0], (int)((E1.meta >> 8) & 15u) * (CK * 4), rB);
+      load_rows(1, off[1], (int)((E1.meta >> 8) & 15u) * (CK * 4), rB);
+      __builtin_amdgcn_sched_barrier(0);
+      index_offsets(E2, ioff);
+      load_idx(E2, ioff, pr);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]), SCN_ROWS(rB) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      index_offsets(E3, ioff);
+    }
+
+    auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rm)[2][NS16], floatx4 (&rn)[2][NS16]) __attribute__((always_inline)) {
+      const bool two = rem(E0) > 16;
+      floatx4 acc[2][COS], old[2][COS];
+      Ent E4 = E3;
+      int w_so[NS16], rso = 0;
+      unsigned w_off = OOB;
+      bool w_new = false;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < COS; ++q) acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      // Everything that is not an MFMA of this pass, cut into pieces of a few instructions; piece m is issued right
+      // after MFMA m of the first group (16 pieces).  Measured the same as seven larger slots between groups of four
+      // MFMAs (MFMA pipe busy 66 % either way, two waves per SIMD): the granularity of the interleave is not what
+      // limits the kernel, the vector-memory issue of the 10-18 loads per pass is.  Load order (vmcnt!): 8 weight,
+      // 2 index, 8 row.
+      auto piece = [&](int m) __attribute__((always_inline)) {
+        if (m == 0 || m == 1) {  // row offset / output row of group m of pass p+2 from its (arrived) pair indices
+          const int i = m;
+          const unsigned src = in_col ? pr[i].y : pr[i].x;
+          const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
+          off[i] = (16 * i < rem(E2) && !(DBG & 2) && !((DBG & 2048) && w == 1)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
+          o2r[i] = (16 * i + li < rem(E2)) ? dst * OS : M * OS;
+          if (m == 1) {
+            rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
+            w_new = (E1.meta >> 20) & 1u;
+          }
+        } else if (m == 2) {     // weights of pass p+1 only when it starts a new (offset, chunk) phase: they are OLDER than
+          if (w_new) weight_scalars(E1, w_so, w_off, w_new);  // the row loads, so the vmcnt(8) below is right either way
+        } else if (m >= 3 && m <= 6) {
+          if (w_new) load_weights_a(m - 3, w_off, w_so[m - 3], wn);
+        } else if (m == 7) {
+          tile_rows(old, op);
+        } else if (m == 8) {     // indices of pass p+3 (pr was consumed by pieces 0-1)
+          load_idx(E3, ioff, pr);
+        } else if (m >= 9 && m <= 12) {  // rows of pass p+2: the long-latency gathers, in flight until the end of pass p+1
+          const int i = (m - 9) >> 1;
+          if ((m - 9) & 1) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(rn[i][2]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "=v"(rn[i][3]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+          } else {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rn[i][0]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rn[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
+          }
+        } else if (m == 13 || m == 14) {  // read-add-write of pass p-1, one group per piece
+          const int i = m - 13;
+#pragma unroll
+          for (int q = 0; q < COS; ++q) {
+            if (DBG & 1) {
+              asm volatile("" ::"v"(prev[i][q]));
+            } else {
+              *(floatx4 *)__builtin_assume_aligned(o_tile + op[i] + 32 * w + 16 * q + 4 * lq, 16) = old[i][q] + prev[i][q];
+            }
+          }
+        } else if (m == 15) {    // table entry p+4
+          E4 = entry(pnext);
+        }
+      };
+      if (!(DBG & 16)) {
+#pragma unroll
+        for (int sp = 0; sp < NS16; ++sp) {
+#pragma unroll
+          for (int h = 0; h < 16; ++h) {
+            const int q = h & 3, e = h >> 2;
+            acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[q][sp][e], rc[0][sp][e], acc[0][q], 0, 0, 0);
+            if (sp == 0) {  // the 16 pieces ride on the first 16 of this pass's 128 MFMAs
+              __builtin_amdgcn_sched_barrier(0);
+              if (DBG & 256) t0 = stamp();
+              piece(h);
+              if (DBG & 256) { t1 = stamp(); seg[h < 3 ? 0 : h < 8 ? 1 : h < 9 ? 2 : 3] += t1 - t0; }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) piece(m);
+      }
+      if (two && !(DBG & 16)) {
+#pragma unroll
+        for (int sp = 0; sp < NS16; ++sp)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < COS; ++q)
+              acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[q][sp][e], rc[1][sp][e], acc[1][q], 0, 0, 0);
+      }
+      // rows of pass p+1 (requested one pass ago: rm), weights of pass p+1 and indices of pass p+3 (this pass); the 8 row
+      // loads of pass p+2 stay in flight.
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(8)" ::SCN_ROWS(rm), SCN_WTS_A(wn), "v"(pr[0]), "v"(pr[1]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG & 256) seg[4] += 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int q = 0; q < COS; ++q) prev[i][q] = acc[i][q];
+        op[i] = o0r[i]; o0r[i] = o1r[i]; o1r[i] = o2r[i];
+      }
+      if (w_new) {
+#pragma unroll
+        for (int q = 0; q < COS; ++q)
+#pragma unroll
+          for (int sp = 0; sp < NS16; ++sp) wc[q][sp] = wn[q][sp];
+      }
+      E0 = E1; E1 = E2; E2 = E3; E3 = E4;
+      index_offsets(E3, ioff);
+      ++pnext;
+    };
+    do {  // single exit: a mid-loop break makes hipcc read "undefined" scalars out of a row register.  A pass past the
+          // end is an empty one (dummy loads, output rows = sink) that only flushes `prev`.
+      body(rA, rB, rC);
+      body(rB, rC, rA);
+      body(rC, rA, rB);
+    } while (rem(E0) > 0);
+    // the (dummy) row prefetches of the passes past the end
+    asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS(rA), SCN_ROWS(rB), SCN_ROWS(rC) : "memory");
+    {  // result of the last pass
+      floatx4 old[2][COS];
+      tile_rows(old, op);
+      scatter(prev, old, op);
+    }
+  }
+#undef SCN_ROWS
+#undef SCN_WTS
+#undef SCN_WTS_A
+  if ((DBG & 256) && lane == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
+  const int rows = (int)min((int64_t)M, n_out - o0);
+  float *dst = out + (int64_t)blockIdx.y * n_out * Co;
+  for (int i = lane; i < rows * 16; i += 64) {
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    *(floatx4 *)(dst + (o0 + r) * Co + co0 + c4) = *(const floatx4 *)(o_tile + r * OS + c4);
+  }
+}
+
+
 // LDS table src[k][row] = input row feeding output row o0 + row through offset k, or -1: the tile's segments of all K
 // lists inverted.  8 threads per offset, all offsets in parallel: two dependent global loads per granule (the segment
 // bounds, then the pairs) instead of 2 K (one offset after the other: 27 x 2 L2 round trips per 32 rows).
@@ -1434,6 +1791,7 @@ SCN_KNOB g_conv_variant = 4;    // tuning key 0: 1 = first synchronous kernel, 2
                                 // shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
 SCN_KNOB g_conv_small_tile4 = 0;  // tuning key 7: 1 = launches with few tiles use k_conv_tile4 with the offset split instead of
                                   // k_conv_tile2 (A/B on the train step: 53.14 against 52.79 ms, so off)
+SCN_KNOB g_conv_tile5 = 0;      // tuning key 9: 1 = k_conv_tile5 (one wave per tile, 64 planes) where k_conv_tile4 would run
 SCN_KNOB g_conv_expand = 1;     // tuning key 8: 0 = launches with one contribution per output row use the tile kernels (A/B)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
@@ -1574,6 +1932,10 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   k_conv_tile4<D><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, (const int2 *)rules, bases, K,                     \
                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
                                              in_bytes, wp_bytes, ksplit)
+  if (g_conv_tile5 != 0) {  // one wave per tile, all 64 planes (k_conv_tile5)
+    k_conv_tile5<0><<<grid4, 64, 0, stream>>>(in, dst4, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out,
+                                             n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+  } else {
 #ifdef SCN_TUNING
   switch (g_conv_dbg) {  // ablation builds for tools/bench_conv.py and tools/stamps.py
     case 1: SCN_LAUNCH_TILE4(1); break;     // no scatter
@@ -1590,6 +1952,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 #else
   SCN_LAUNCH_TILE4(0);
 #endif
+  }
 #undef SCN_LAUNCH_TILE4
   SCN_CHECK_LAUNCH();
   if (ksplit > 1) {
@@ -1637,6 +2000,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 6) { g_dw_dbg = value; return 0; }
   if (key == 7) { g_conv_small_tile4 = value; return 0; }
   if (key == 8) { g_conv_expand = value; return 0; }
+  if (key == 9) { g_conv_tile5 = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
 #endif

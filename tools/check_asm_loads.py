@@ -19,13 +19,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 
 
 def regs(tok):
-    """VGPR numbers named by an operand like v12 or v[12:15]"""
-    m = re.fullmatch(r"v(\d+)", tok)
+    """registers named by an operand like v12, v[12:15], a3 or a[8:11]: VGPR n -> n, AGPR n -> 1000 + n (loads may
+    target accumulation registers too)"""
+    m = re.fullmatch(r"([va])(\d+)", tok)
     if m:
-        return {int(m.group(1))}
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        return {int(m.group(2)) + (1000 if m.group(1) == "a" else 0)}
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        base = 1000 if m.group(1) == "a" else 0
+        return set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
     return set()
 
 
@@ -114,7 +116,7 @@ def main():
                                   stderr=subprocess.DEVNULL)
             text = open(out).read()
     lines = text.split("\n")
-    starts = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3scn12k_conv_tile4\S*:", ln)]
+    starts = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3scn12k_conv_tile[45]\S*:", ln)]
     errors = []
     n = 0
     for st in starts:
