@@ -206,10 +206,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events around every kernel of interest, inside the timed region, on every EVENT_EVERY-th step: a
-    # timed event drains the queue between two kernels, and hundreds of them per step cost 3-4 ms of a 55 ms step.
-    # One more event per step (end of step, main stream) gives the per-step durations for the median.
-    prof = []
+    # HIP events around every MATRIX kernel (gather-mm, dWeight), inside the timed region, on every EVENT_EVERY-th
+    # step: a timed event drains the queue between two kernels (with events on ALL ~600 launches of a step -- batch
+    # norm, rule build, io layers too -- a profiled step took 127 ms instead of 50).  The HBM-bound launches are
+    # therefore timed in ONE extra step after the timed region.  One more event per step (end of step, main stream)
+    # gives the per-step durations for the median.
+    prof, prof_extra = [], []
+    SCN.PROFILE_KINDS = ("mm",)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sites_done = 0
     first = counter[0]
@@ -224,6 +227,13 @@ def main():
     SCN.PROFILE = None
     barrier()
     dt = time.perf_counter() - t0
+    if rank == 0:  # the extra, untimed step: events on batch norm, rule build and io launches only
+        SCN.PROFILE_KINDS = ("bn", "rules", "io")
+        SCN.PROFILE = prof_extra
+        step()
+        SCN.PROFILE = None
+        SCN.PROFILE_KINDS = ("mm", "bn", "rules", "io")
+        torch.cuda.synchronize()
 
     t = torch.tensor([dt, float(sites_done)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -241,16 +251,17 @@ def main():
         # per-kernel HIP-event timings over the timed region (events were recorded on the launch stream)
         agg = {}
         launches = []
-        for kernel, flops, nbytes, e0, e1, shape in prof:
-            nbytes = nbytes() if callable(nbytes) else nbytes
-            ms = e0.elapsed_time(e1)
-            a = agg.setdefault(kernel, [0, 0.0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += nbytes
-            a[3] += ms * 1e-3
-            launches.append((kernel, shape, ms, flops, nbytes))
-        sampled = len(range(0, args.steps, args.event_every))  # steps whose launches carry events
+        sampled = len(range(0, args.steps, args.event_every))  # steps whose matrix launches carry events
+        for plist, per in ((prof, 1.0), (prof_extra, float(sampled))):  # the extra step counts as `sampled` steps' worth
+            for kernel, flops, nbytes, e0, e1, shape in plist:
+                nbytes = nbytes() if callable(nbytes) else nbytes
+                ms = e0.elapsed_time(e1)
+                a = agg.setdefault(kernel, [0, 0.0, 0.0, 0.0])
+                a[0] += per
+                a[1] += flops * per
+                a[2] += nbytes * per
+                a[3] += ms * 1e-3 * per
+                launches.append((kernel, shape, ms * per, flops * per, nbytes * per, per))
         peaks = measured_peaks(dev) if world == 1 else None
         hbm_meas = max(peaks["hbm_copy_GBs"], peaks["hbm_read_GBs"]) if peaks else None
         kernels = {}
@@ -270,7 +281,8 @@ def main():
                 secs, nbytes = sum(a[3] for a in sel), sum(a[2] for a in sel)
                 kernels[g] = {"ms_per_step": 1e3 * secs / sampled, "algo_bytes_per_step": nbytes / sampled,
                               "algo_GBs": nbytes / secs / 1e9, "hbm_frac": nbytes / secs / 1e9 / HBM_PEAK_GBS,
-                              "members": [n for n in names if n in agg]}
+                              "members": [n for n in names if n in agg],
+                              "measured": "HIP events in one extra step right after the timed region"}
         if "rules" in kernels:
             # inside the step the rule build runs on the side stream UNDER the step's big kernels (that is its point),
             # so the event times above include waiting for CUs.  The same build alone on an idle GPU:
@@ -349,9 +361,9 @@ def main():
         }
         if args.dump_launches:
             per_shape = {}
-            for kernel, shape, ms, flops, nbytes in launches:
+            for kernel, shape, ms, flops, nbytes, per in launches:
                 d = per_shape.setdefault("%s %s" % (kernel, shape), [0, 0.0, 0.0, 0.0])
-                d[0] += 1
+                d[0] += per
                 d[1] += ms
                 d[2] += flops
                 d[3] += nbytes

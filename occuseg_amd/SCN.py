@@ -22,10 +22,11 @@ GRANULE = 32  # SCN_TILE_GRANULE
 # When set to a list, every gather-mm launch appends (kernel, flops, bytes, start_event, end_event):
 # used by bench.py to time the dominant kernels with HIP events on the launch stream.
 PROFILE = None
+PROFILE_KINDS = ("mm", "bn", "rules", "io")  # which launches carry events: matrix kernels / batch norm / rule build / io
 
 
-def _prof_begin():
-    if PROFILE is None:
+def _prof_begin(kind="mm"):
+    if PROFILE is None or kind not in PROFILE_KINDS:
         return None
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
@@ -170,7 +171,7 @@ class Metadata_3(object):
     def _build_grid(self, coords_dev, dtype_code, ncols, shift, P):
         lib = _lib_()
         dev = coords_dev.device
-        ev = _prof_begin()
+        ev = _prof_begin("rules")
         tb = lib.scn_grid_build_temp_bytes(P)
         temp = torch.empty(tb, dtype=torch.uint8, device=dev)
         keys_sorted = torch.empty(P, dtype=torch.int64, device=dev)
@@ -331,7 +332,7 @@ class Metadata_3(object):
             # remap every pair to list rot_index[class of its output site][offset]
             ori = self.normals[key[:3]][1] if key[:3] in self.normals else None
             nbr_tmp = torch.empty((27, N), dtype=torch.int32, device=dev) if ori is not None else None
-            ev = _prof_begin()
+            ev = _prof_begin("rules")
             check(lib.scn_submanifold_rules(ptr(g.coords), N, ptr(g.hash_keys), ptr(g.hash_vals), g.hash_cap,
                                             ptr(nbr), ptr(rules), ptr(counts), ptr(temp), tb, ptr(ori),
                                             1 if ori is not None else 0, -1, ptr(nbr_tmp), stream()))
@@ -405,7 +406,7 @@ class Metadata_3(object):
             counts = torch.empty(8, dtype=torch.int32, device=dev)
             tb = lib.scn_rules_temp_bytes(Nf, 8)
             temp = torch.empty(tb, dtype=torch.uint8, device=dev)
-            ev = _prof_begin()
+            ev = _prof_begin("rules")
             check(lib.scn_strided_rules(ptr(fine.coords), Nf, ptr(coarse_of_fine), ptr(rules), ptr(counts),
                                         ptr(temp), tb, stream()))
             _prof_end(ev, "strided_rules", 0.0, 2.0 * (16.0 + 4.0) * Nf + 8.0 * Nf, (Nf,))
@@ -573,7 +574,7 @@ def InputLayer_updateOutput(m, spatialSize, input_coords, input_features, output
     N = m.nActive[m.inputSpatialSize]
     C = input_features.size(1)
     output_features.resize_(N, C)
-    ev = _prof_begin()
+    ev = _prof_begin("io")
     check(_lib_().scn_input_forward(ptr(input_features.contiguous()), ptr(output_features), ptr(m.input_order),
                                     ptr(m.input_site_start), N, C, int(mode == 4), stream()))
     _prof_end(ev, "io", 0.0, 4.0 * C * (m.input_P + N) + 4.0 * (m.input_P + N), (m.input_P, N, C))
@@ -584,7 +585,7 @@ def InputLayer_updateGradInput(m, d_input_features, d_output_features):
     _need_cuda(d_output_features, "InputLayer_updateGradInput")
     C = d_output_features.size(1)
     d_input_features.resize_(m.input_P, C)
-    ev = _prof_begin()
+    ev = _prof_begin("io")
     check(_lib_().scn_input_backward(ptr(d_input_features), ptr(d_output_features.contiguous()),
                                      ptr(m.input_site_of_row), ptr(m.input_site_start), m.input_P, C,
                                      int(m.input_mode == 4), stream()))
@@ -596,7 +597,7 @@ def OutputLayer_updateOutput(m, input_features, output_features):
     _need_cuda(input_features, "OutputLayer_updateOutput")
     C = input_features.size(1)
     output_features.resize_(m.input_P, C)
-    ev = _prof_begin()
+    ev = _prof_begin("io")
     check(_lib_().scn_output_forward(ptr(input_features.contiguous()), ptr(output_features),
                                      ptr(m.input_site_of_row), m.input_P, C, stream()))
     _prof_end(ev, "io", 0.0, 8.0 * C * m.input_P + 4.0 * m.input_P, (m.input_P, 0, C))
@@ -608,7 +609,7 @@ def OutputLayer_updateGradInput(m, d_input_features, d_output_features):
     C = d_output_features.size(1)
     N = m.nActive[m.inputSpatialSize]
     d_input_features.resize_(N, C)
-    ev = _prof_begin()
+    ev = _prof_begin("io")
     check(_lib_().scn_output_backward(ptr(d_input_features), ptr(d_output_features.contiguous()),
                                       ptr(m.input_order), ptr(m.input_site_start), N, C, stream()))
     _prof_end(ev, "io", 0.0, 4.0 * C * (m.input_P + N) + 4.0 * (m.input_P + N), (m.input_P, N, C))
@@ -710,7 +711,7 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
     saveMean.resize_(C)
     saveInvStd.resize_(C)
     temp = _bn_temp(C, x.device)
-    ev = _prof_begin()
+    ev = _prof_begin("bn")
     check(_lib_().scn_bn_forward(ptr(x), ptr(output_features), ptr(saveMean), ptr(saveInvStd), ptr(runningMean),
                                  ptr(runningVar), ptr(weight), ptr(bias), float(eps), float(momentum), int(train),
                                  float(leakiness), N, C, ptr(temp), stream()))
@@ -732,7 +733,7 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     N, C = x.shape
     d_input_features.resize_(N, C)
     temp = _bn_temp(C, x.device)
-    ev = _prof_begin()
+    ev = _prof_begin("bn")
     flags = (4 if _mask_from_x else int(bool(_rewrite_d_output))) | (2 if _accumulate else 0)
     check(_lib_().scn_bn_backward(ptr(x), ptr(d_input_features), ptr(output_features), ptr(d_output_features),
                                   ptr(saveMean), ptr(saveInvStd), ptr(weight), ptr(bias), ptr(d_weight), ptr(d_bias),

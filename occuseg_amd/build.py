@@ -28,7 +28,7 @@ def build(force=False, verbose=True, tuning=True):
     headers = [os.path.join(CSRC, "scn_common.h"), os.path.join(HERE, "..", "include", "scn_hip.h")]
     sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     procs = []
-    checker = None
+    checkers = []
     objs = {False: [], True: []}
     for tune in ((False, True) if tuning else (False,)):
         for s in sources + (TUNING_ONLY if tune else []):
@@ -44,20 +44,22 @@ def build(force=False, verbose=True, tuning=True):
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 procs.append((cmd, subprocess.Popen(cmd)))
-                if s == "scn_conv.hip" and not tune:
+                if s == "scn_conv.hip":
                     # the hand-scheduled kernels issue their loads from inline asm with counted s_waitcnt: prove on the
                     # emitted assembly that no instruction touches a register whose load is still in flight
-                    chk = [sys.executable, os.path.join(HERE, "..", "tools", "check_asm_loads.py")]
-                    checker = (chk, subprocess.Popen(chk, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                    chk = [sys.executable, os.path.join(HERE, "..", "tools", "check_asm_loads.py")] + (["--tuning"] if tune else [])
+                    checkers.append((chk, subprocess.Popen(chk, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    if checker is not None:
-        out = checker[1].communicate()[0].decode()
+    for chk, proc in checkers:
+        out = proc.communicate()[0].decode()
         if verbose:
             print(out.strip().split("\n")[-1], flush=True)
-        if checker[1].returncode != 0:
-            os.remove(os.path.join(CSRC, "scn_conv.o"))
+        if proc.returncode != 0:
+            for o in ("scn_conv.o", "scn_conv.tuning.o"):
+                if os.path.exists(os.path.join(CSRC, o)):
+                    os.remove(os.path.join(CSRC, o))
             raise RuntimeError("check_asm_loads failed:\n" + out)
     for tune, lib in ((False, LIB), (True, LIB_TUNING)):
         if tune and not tuning:

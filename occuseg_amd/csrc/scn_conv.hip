@@ -942,6 +942,10 @@ __global__ void __launch_bounds__(128)
 // weight loads and the output-tile traffic per MFMA stay as they were).  Occupancy is one wave per SIMD (four 39 KB
 // tiles per CU, as before): everything that hid behind the partner wave has to hide behind the wave's own MFMAs.
 // Same pass table, same load order (16 weight, 2 index, 8 row), same hand-counted waits as k_conv_tile4.
+// MEASURED SLOWER (tools/ab_tile5.py, bit-identical outputs): 84 / 86 / 87 TFLOP/s against 94 / 99 / 98 on L0 128->64,
+// L1 128->128, L1 256->128; train step 54.3 against 51.4 ms.  One wave per SIMD cannot hide what two hide for each
+// other, even with half the gathers.  Kept in the tuning build only (tuning key 9) so that the A/B can be repeated.
+#ifdef SCN_TUNING
 template <int DBG = 0>
 __global__ void __launch_bounds__(64)
     k_conv_tile5(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
@@ -1291,6 +1295,8 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+
+#endif  // SCN_TUNING (k_conv_tile5)
 
 // LDS table src[k][row] = input row feeding output row o0 + row through offset k, or -1: the tile's segments of all K
 // lists inverted.  8 threads per offset, all offsets in parallel: two dependent global loads per granule (the segment
@@ -1932,10 +1938,13 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   k_conv_tile4<D><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, (const int2 *)rules, bases, K,                     \
                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
                                              in_bytes, wp_bytes, ksplit)
-  if (g_conv_tile5 != 0) {  // one wave per tile, all 64 planes (k_conv_tile5)
+#ifdef SCN_TUNING
+  if (g_conv_tile5 != 0) {  // one wave per tile, all 64 planes (k_conv_tile5): A/B only, measured slower
     k_conv_tile5<0><<<grid4, 64, 0, stream>>>(in, dst4, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out,
                                              n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
-  } else {
+  } else
+#endif
+  {
 #ifdef SCN_TUNING
   switch (g_conv_dbg) {  // ablation builds for tools/bench_conv.py and tools/stamps.py
     case 1: SCN_LAUNCH_TILE4(1); break;     // no scatter

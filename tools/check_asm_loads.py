@@ -6,7 +6,7 @@ so hipcc does not know that a destination register is not valid yet.  This scrip
 assembly, walks every k_conv_tile4 instantiation in layout order (the pass loop twice, to cover the back edge)
 with a FIFO model of the outstanding asm loads, and fails if ANY instruction outside the asm blocks reads or
 writes a register that an in-flight load is still going to write.
-usage: python tools/check_asm_loads.py [file.s]"""
+usage: python tools/check_asm_loads.py [--tuning] [file.s]"""
 import os
 import re
 import subprocess
@@ -107,12 +107,14 @@ def check_kernel(name, lines):
 
 
 def main():
-    if len(sys.argv) > 1:
-        text = open(sys.argv[1]).read()
+    args = [a for a in sys.argv[1:] if a != "--tuning"]
+    if args:
+        text = open(args[0]).read()
     else:
+        extra = ["-DSCN_TUNING"] if "--tuning" in sys.argv else []  # the tuning build holds more instantiations
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "conv.s")
-            subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-S", "--cuda-device-only", SRC, "-o", out],
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-S", "--cuda-device-only", SRC, "-o", out],
                                   stderr=subprocess.DEVNULL)
             text = open(out).read()
     lines = text.split("\n")
