@@ -109,7 +109,7 @@ def measured_peaks(dev):
     scratch = torch.zeros(64, device=dev)
     tf = ctypes.c_double(0)
     best_tf = 0.0
-    for wps in (1, 2):
+    for wps in (1, 2, 4):
         _lib.check(lib.scn_peak_mfma_f32(scratch.data_ptr(), wps, ctypes.byref(tf), stream))
         best_tf = max(best_tf, tf.value)
     nbytes = 1 << 30
@@ -121,7 +121,7 @@ def measured_peaks(dev):
     _lib.check(lib.scn_peak_read(src.data_ptr(), scratch.data_ptr(), nbytes, 3, ctypes.byref(rd), stream))
     del src, dst
     return {"f32_mfma_tflops": best_tf, "hbm_copy_GBs": gbs.value, "hbm_read_GBs": rd.value,
-            "how": "v_mfma_f32_16x16x4_f32 chains on every SIMD (1 and 2 waves per SIMD, best); float4 copy of 1 GiB "
+            "how": "v_mfma_f32_16x16x4_f32 chains on every SIMD (1, 2 and 4 waves per SIMD, best); float4 copy of 1 GiB "
                    "(bytes read + written) and float4 read-only stream of 1 GiB, best of 3"}
 
 

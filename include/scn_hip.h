@@ -133,6 +133,9 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
  *   (i,o) in list k  <=>  (o,i) in list 26-k).
  *   in_col/out_col: 0/1 for conv + submanifold, 1/0 for deconvolution
  *   (sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49); bases = scn_tile_bases(.., out_col, n_out).
+ *   residual (may be NULL): fp32 [n_out, Co] added to the result, out = residual + bias + sum ...: the output tile
+ *   starts from its rows, so the shortcut of a residual block (sparseconvnet/networkArchitectures.py:222-229: AddTable over
+ *   ConcatTable(shortcut, body)) costs one read instead of a separate elementwise kernel.  May alias nothing else.
  *   counts [K] (device) = pairs per list.  out_unique != 0 promises that EVERY output row appears in exactly one pair of
  *   the rulebook (deconvolution and the dInput of a strided convolution: each fine row has one parity class,
  *   sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49; NetworkInNetwork: the identity list): such launches run without any
@@ -154,7 +157,8 @@ int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, in
 int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int Ci, int Co, void *wpack,
                     void *stream);
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const int32_t *rules, const int32_t *bases, const int32_t *counts,
+                     const float *bias, const float *residual, const int32_t *rules,
+                     const int32_t *bases, const int32_t *counts,
                      int K, int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in,
                      int64_t n_out, int Ci, int Co, void *wpack, int wpack_ready, void *workspace,
                      size_t workspace_bytes, void *stream);

@@ -501,7 +501,7 @@ def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
     return wpack, 1
 
 
-def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False):
+def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False, residual=None):
     """out = gather-mm-scatter over rb; weight is the module's [K, a, b] tensor, used as [K, Ci, Co]
     (forward) or, with w_transposed, as its per-offset transpose (dInput).  When every output row appears in exactly
     one pair of the rulebook (rb.unique_col == out_col: the fine column of a strided rulebook, the identity list)
@@ -512,6 +512,8 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     assert K == rb.K, (K, rb.K)
     assert inp.is_contiguous() and weight.is_contiguous() and inp.size(1) == Ci
     out.resize_(n_out, Co)
+    if residual is not None:
+        assert residual.is_contiguous() and tuple(residual.shape) == (n_out, Co) and residual.data_ptr() != out.data_ptr()
     wpack, ready = _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co)
     # launches with few output tiles split their offsets over workgroups; partial tiles go through this workspace
     uniq = int(rb.unique_col is not None and (rb.unique_col == out_col or rb.unique_col == 2))
@@ -519,7 +521,7 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=inp.device) if ws_bytes else None
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
-                               ptr(bias) if bias is not None and bias.numel() else None,
+                               ptr(bias) if bias is not None and bias.numel() else None, ptr(residual),
                                ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.counts), K, rb.stride, in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
     # algorithmic work of one launch: flops = 2 R Ci Co;
@@ -616,14 +618,16 @@ def OutputLayer_updateGradInput(m, d_input_features, d_output_features):
 
 
 def SubmanifoldConvolution_updateOutput(spatialSize, filterSize, m, input_features, output_features, weight,
-                                        bias, dilated_rate=1):
+                                        bias, dilated_rate=1, residual=None):
     """sparseconvnet/SCN/pybind.cpp:138-142 -> sparseconvnet/SCN/CUDA/Convolution.cpp:105-162.
     Returns the multiply-add count sum_k R_k*Ci*Co (the reference returns 0 on
-    its chunk path, sparseconvnet/SCN/CUDA/Convolution.cu:1286,1374 -- treated as a bug)."""
+    its chunk path, sparseconvnet/SCN/CUDA/Convolution.cu:1286,1374 -- treated as a bug).
+    ``residual`` (not in the reference): [N, nOut] tensor added to the result inside the kernel."""
     _need_cuda(input_features, "SubmanifoldConvolution_updateOutput")
     rb = m.getSubmanifoldRuleBook(spatialSize, filterSize, dilated_rate)
     n = m.getNActive(spatialSize)
-    _conv(input_features.contiguous(), output_features, weight, bias, rb, 0, 1, n)
+    _conv(input_features.contiguous(), output_features, weight, bias, rb, 0, 1, n,
+          residual=residual.contiguous() if residual is not None else None)
     return float(rb.total_pairs) * weight.size(1) * weight.size(2)
 
 

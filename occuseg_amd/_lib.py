@@ -33,7 +33,7 @@ SIGNATURES = {
     "scn_conv_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_plan": (c_int, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_weight_pack": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
+    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
                                  c_int64, c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),

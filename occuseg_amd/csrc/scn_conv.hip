@@ -56,7 +56,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <int NW, int COS, int M, int CK>
 __global__ void __launch_bounds__(64 * NW)
     k_conv_tile(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
-                const float *__restrict__ bias, const int2 *__restrict__ rules,
+                const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                 int64_t n_out, int n_gran, int Ci, int Co) {
   constexpr int COB = NW * COS * 16;
@@ -78,7 +78,9 @@ __global__ void __launch_bounds__(64 * NW)
 
   for (int i = tid; i < M * COB; i += NT) {
     const int r = i / COB, c = i % COB;
-    o_tile[r * OS + c] = bias ? bias[co0 + c] : 0.f;
+    float v = bias ? bias[co0 + c] : 0.f;
+    if (residual && o0 + r < n_out) v += residual[(o0 + r) * Co + co0 + c];
+    o_tile[r * OS + c] = v;
   }
   if (tid < K) {
     seg[tid][0] = bases[(int64_t)tid * (n_gran + 1) + g0];
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(256)
 template <int NW, int COS, int CK, int DBG = 0, int NWM = 1, int M_ = 0>
 __global__ void __launch_bounds__(64 * NW * NWM)
     k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb, int ksplit,
                  unsigned in_bytes, unsigned wp_bytes) {
@@ -257,7 +259,11 @@ __global__ void __launch_bounds__(64 * NW * NWM)
 
   for (int i = tid; i < M * COB; i += NT) {
     const int r = i / COB, c = i % COB;
-    o_tile[r * OS + c] = (bias && blockIdx.y == 0) ? bias[co0 + c] : 0.f;
+    float v = (bias && blockIdx.y == 0) ? bias[co0 + c] : 0.f;
+    // residual: the tile starts from the rows of another tensor (out = residual + bias + sum ...): the shortcut of a
+    // residual block is added here for the price of reading it, instead of by a separate elementwise kernel
+    if (residual && blockIdx.y == 0 && o0 + r < n_out) v += residual[(o0 + r) * Co + co0 + c];
+    o_tile[r * OS + c] = v;
   }
   if (tid < 64) {
     // one lane per kernel offset: segment of list k inside this tile, then a ballot-compacted list of
@@ -597,7 +603,7 @@ __global__ void __launch_bounds__(256)
 template <int DBG = 0>
 __global__ void __launch_bounds__(128)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes, int ksplit) {
@@ -644,6 +650,7 @@ __global__ void __launch_bounds__(128)
     const int r = i >> 3, c4 = (i & 7) * 4;
     floatx4 v = {0.f, 0.f, 0.f, 0.f};
     if (bias && blockIdx.y == 0) v = *(const floatx4 *)(bias + co0 + 32 * w + c4);
+    if (residual && blockIdx.y == 0 && r < M && o0 + r < n_out) v += *(const floatx4 *)(residual + (o0 + r) * Co + co0 + 32 * w + c4);
     *(floatx4 *)(o_tile + r * OS + 32 * w + c4) = v;
   }
   if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
@@ -949,7 +956,7 @@ __global__ void __launch_bounds__(128)
 template <int DBG = 0>
 __global__ void __launch_bounds__(64)
     k_conv_tile5(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes, int ksplit) {
@@ -995,6 +1002,7 @@ __global__ void __launch_bounds__(64)
     const int r = i >> 4, c4 = (i & 15) * 4;
     floatx4 v = {0.f, 0.f, 0.f, 0.f};
     if (bias && blockIdx.y == 0) v = *(const floatx4 *)(bias + co0 + c4);
+    if (residual && blockIdx.y == 0 && r < M && o0 + r < n_out) v += *(const floatx4 *)(residual + (o0 + r) * Co + co0 + c4);
     *(floatx4 *)(o_tile + r * OS + c4) = v;
   }
   if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
@@ -1331,7 +1339,7 @@ __device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], con
 // walked in chunks of 32 planes, the loads of chunk c+1 requested before the MFMAs of chunk c.
 __global__ void __launch_bounds__(64)
     k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                  const float *__restrict__ bias, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
+                  const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
                   int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes, unsigned wp_bytes) {
   // chunks of 32 reduction planes: 2 x (8 row + 32 weight) registers in flight + 32 accumulators keep the wave at
   // ~150 VGPRs = three waves per SIMD (with 64-plane chunks it needed 272: one wave per SIMD, and a launch of
@@ -1414,6 +1422,7 @@ __global__ void __launch_bounds__(64)
       for (int q = 0; q < COS; ++q) {
         floatx4 v = acc[g][q];
         if (bias) v += *(const floatx4 *)(bias + co0 + 16 * q + 4 * lq);
+        if (residual) v += *(const floatx4 *)(residual + orow[g] * Co + co0 + 16 * q + 4 * lq);
         *(floatx4 *)(out + orow[g] * Co + co0 + 16 * q + 4 * lq) = v;
       }
     }
@@ -1426,7 +1435,7 @@ __global__ void __launch_bounds__(64)
 template <bool W_IN_LDS>
 __global__ void __launch_bounds__(256)
     k_conv_generic(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
-                   const float *__restrict__ bias, const int2 *__restrict__ rules,
+                   const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
                    const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                    int64_t n_out, int n_gran, int Ci, int Co, int w_transposed, int w_reverse) {
   constexpr int M = SCN_TILE_GRANULE;
@@ -1451,7 +1460,10 @@ __global__ void __launch_bounds__(256)
   const int r = tid >> 3, cg = (tid & 7) * 8;
   float acc[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) acc[c] = (bias && cb + cg + c < Co) ? bias[cb + cg + c] : 0.f;
+  for (int c = 0; c < 8; ++c) {
+    acc[c] = (bias && cb + cg + c < Co) ? bias[cb + cg + c] : 0.f;
+    if (residual && o0 + r < n_out && cb + cg + c < Co) acc[c] += residual[(o0 + r) * Co + cb + cg + c];
+  }
   if (W_IN_LDS && Ci <= 4) {
     // narrow inputs (the stem): the inputs of three offsets are fetched before their FMAs -- one dependent
     // LDS -> global chain per offset made this loop pure latency
@@ -1868,19 +1880,19 @@ static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, in
 }
 
 template <int NW, int COS, int M, int CK>
-static int launch_tile(const float *in, float *out, const float *W, const float *bias,
+static int launch_tile(const float *in, float *out, const float *W, const float *bias, const float *residual,
                        const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                        int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)((n_out + M - 1) / M), (unsigned)(Co / (NW * COS * 16)));
-  k_conv_tile<NW, COS, M, CK><<<grid, 64 * NW, 0, stream>>>(in, out, W, bias, (const int2 *)rules, bases,
+  k_conv_tile<NW, COS, M, CK><<<grid, 64 * NW, 0, stream>>>(in, out, W, bias, residual, (const int2 *)rules, bases,
                                                           K, stride, in_col, n_out, n_gran, Ci, Co);
   SCN_CHECK_LAUNCH();
   return 0;
 }
 
 template <int NW, int COS, int CK, int NWM = 1, int M_ = 0>
-static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias,
+static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias, const float *residual,
                         const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                         int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
                         hipStream_t stream) {
@@ -1893,7 +1905,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_T2(D)                                                                                   \
   k_conv_tile2<NW, COS, CK, D, NWM, M_><<<grid2, 64 * NW * NWM, 0, stream>>>(                             \
-      in, dst, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit, \
+      in, dst, Wp, bias, residual, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit, \
       in_bytes, wp_bytes)
 #ifdef SCN_TUNING
   if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
@@ -1924,7 +1936,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   return 0;
 }
 
-static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const int32_t *rules,
+static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
                         int Ci, int Co, int ksplit, float *part, hipStream_t stream) {
   constexpr int M = 128;
@@ -1935,12 +1947,12 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   float *dst4 = ksplit > 1 ? part : out;
   const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_TILE4(D)                                                                                         \
-  k_conv_tile4<D><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, (const int2 *)rules, bases, K,                     \
+  k_conv_tile4<D><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, (const int2 *)rules, bases, K,                     \
                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
                                              in_bytes, wp_bytes, ksplit)
 #ifdef SCN_TUNING
   if (g_conv_tile5 != 0) {  // one wave per tile, all 64 planes (k_conv_tile5): A/B only, measured slower
-    k_conv_tile5<0><<<grid4, 64, 0, stream>>>(in, dst4, Wp, bias, (const int2 *)rules, bases, K, stride, in_col, n_out,
+    k_conv_tile5<0><<<grid4, 64, 0, stream>>>(in, dst4, Wp, bias, residual, (const int2 *)rules, bases, K, stride, in_col, n_out,
                                              n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
   } else
 #endif
@@ -1975,17 +1987,17 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 }
 
 template <int NW>
-static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias,
+static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias, const float *residual,
                            const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                            int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
                            hipStream_t stream) {
 #ifdef SCN_TUNING
   if (NW == 4 && g_conv_wide && Ci % 64 == 0 && Co % 128 == 0 && ksplit == 1)
-    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, 1, part, stream);
+    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, 1, part, stream);
 #endif
-  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
-  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
-  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
 }
 
 extern "C" {
@@ -2044,7 +2056,7 @@ int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int 
 }
 
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const int32_t *rules, const int32_t *bases, const int32_t *counts, int K,
+                     const float *bias, const float *residual, const int32_t *rules, const int32_t *bases, const int32_t *counts, int K,
                      int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in, int64_t n_out, int Ci,
                      int Co, void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
@@ -2071,17 +2083,17 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
         }
       }
       switch (p.nw) {
-        case 4: return launch_tile<4, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-        case 3: return launch_tile<3, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-        case 2: return launch_tile<2, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-        default: return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        case 4: return launch_tile<4, 1, 64, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        case 3: return launch_tile<3, 1, 64, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        case 2: return launch_tile<2, 1, 64, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        default: return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
       }
     }
     if (p.kind == 5) {
       const int ncb = Co / 64;
       const int64_t nblk = (n_out + 31) / 32 + K;  // every output row in exactly one pair: sum_k ceil(count_k / 32) <= this
       const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
-      k_conv_expand<<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, (const int2 *)rules, counts, K, stride,
+      k_conv_expand<<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, (const int2 *)rules, counts, K, stride,
                                                              in_col, Ci, Co, ncb, in_bytes, wp_bytes);
       SCN_CHECK_LAUNCH();
       return 0;
@@ -2091,22 +2103,22 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     float *part = (float *)workspace;
     if (p.kind == 4)
-      return launch_tile4(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      return launch_tile4(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
     switch (p.nw) {
-      case 4: return launch_tile2_ck<4>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      case 3: return launch_tile2_ck<3>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      case 2: return launch_tile2_ck<2>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      default: return launch_tile2_ck<1>(in, out, Wp, bias, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 4: return launch_tile2_ck<4>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 3: return launch_tile2_ck<3>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 2: return launch_tile2_ck<2>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      default: return launch_tile2_ck<1>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
     }
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)(n_gran < 2048 ? n_gran : 2048), (unsigned)((Co + 63) / 64));  // persistent: weights staged once
   const size_t wbytes = (size_t)K * Ci * 64 * 4;
   if (wbytes <= 40 * 1024)
-    k_conv_generic<true><<<grid, 256, wbytes, stream>>>(in, out, W, bias, (const int2 *)rules, bases, K, stride,
+    k_conv_generic<true><<<grid, 256, wbytes, stream>>>(in, out, W, bias, residual, (const int2 *)rules, bases, K, stride,
                                                         in_col, n_out, n_gran, Ci, Co, w_transposed, w_reverse);
   else
-    k_conv_generic<false><<<grid, 256, 0, stream>>>(in, out, W, bias, (const int2 *)rules, bases, K, stride,
+    k_conv_generic<false><<<grid, 256, 0, stream>>>(in, out, W, bias, residual, (const int2 *)rules, bases, K, stride,
                                                     in_col, n_out, n_gran, Ci, Co, w_transposed, w_reverse);
   SCN_CHECK_LAUNCH();
   return 0;

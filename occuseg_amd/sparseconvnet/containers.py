@@ -46,6 +46,27 @@ class ConcatTable(Sequential):
         return self._modules["0"].input_spatial_size(out_size)
 
 
+class ResidualConcatTable(ConcatTable):
+    """ConcatTable(shortcut, body) of a residual block (sparseconvnet/networkArchitectures.py:222-229) whose body ends
+    in a SubmanifoldConvolution: same children, same state_dict keys, same result as ConcatTable -> AddTable, but the
+    shortcut is handed to that last convolution, which adds it inside its kernel (the output tile starts from the
+    shortcut's rows).  Returns a one-element list, so the AddTable that follows has nothing left to add."""
+
+    def forward(self, input):
+        from .conv import SubmanifoldConvolution
+        children = list(self._modules.values())
+        body = list(children[1]._modules.values()) if len(children) == 2 and isinstance(children[1], Sequential) else []
+        if not body or not isinstance(body[-1], SubmanifoldConvolution):
+            return ConcatTable.forward(self, input)
+        shortcut = children[0](input)
+        x = input
+        for mod in body[:-1]:
+            x = mod(x)
+        if shortcut.features.size(1) != body[-1].nOut or shortcut.features.size(0) != x.features.size(0):
+            return [shortcut, body[-1](x)]
+        return [body[-1](x, residual=shortcut.features)]
+
+
 class JoinTable(torch.nn.Sequential):
     """concatenate feature planes of a list of tensors living on the same sites"""
 

@@ -35,13 +35,14 @@ class _RuleConvFunction(Function):
 
     @staticmethod
     def forward(ctx, features, weight, bias, kind, metadata, in_size, out_size, filter_size, filter_stride,
-                dilated_rate):
+                dilated_rate, residual=None):
         ctx.kind, ctx.scn_meta, ctx.dilated_rate = kind, metadata, dilated_rate
         ctx.sizes = (in_size, out_size, filter_size, filter_stride)
         out = like_empty(features)
         if kind == "submanifold":
+            # residual: out = conv(features) + residual in one kernel (the shortcut of a residual block)
             macs = SCN.SubmanifoldConvolution_updateOutput(in_size, filter_size, metadata, features, out, weight,
-                                                           bias, dilated_rate)
+                                                           bias, dilated_rate, residual=residual)
         elif kind == "conv":
             macs = SCN.Convolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, features,
                                                 out, weight, bias)
@@ -80,7 +81,9 @@ class _RuleConvFunction(Function):
         if direct:
             owner.grad_written(weight)
             grad_weight = None
-        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7
+        # d(out)/d(residual) = identity: the incoming gradient itself
+        grad_residual = grad_output if ctx.needs_input_grad[10] else None
+        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7 + (grad_residual,)
 
 
 class _RuleConv(Module):
@@ -103,13 +106,16 @@ class _RuleConv(Module):
     def output_spatial_size(self, in_size):
         raise NotImplementedError
 
-    def forward(self, input):
+    def forward(self, input, residual=None):
+        """``residual`` (submanifold only; used by the residual blocks of scn.UNet): features added to the output
+        inside the convolution kernel"""
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, self.nOut, input)
+        assert residual is None or self.kind == "submanifold"
         out_size = self.output_spatial_size(input.spatial_size)
         output = SparseConvNetTensor(metadata=input.metadata, spatial_size=out_size)
         output.features = _RuleConvFunction.apply(
             input.features, self.weight, optionalTensor(self, "bias"), self.kind, input.metadata,
-            input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate)
+            input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate, residual)
         return output
 
     def _fmt(self, t):

@@ -4,7 +4,8 @@ Same module tree (hence the same state_dict keys) as sparseconvnet/networkArchit
 per level  block* ; ConcatTable(Identity, BN -> Conv 2/2 -> U(next) -> BN -> Deconv 2/2) ; JoinTable ; block*,
 residual block = ConcatTable(Identity | NiN, BN -> SC3 -> BN -> SC3) -> AddTable.
 """
-from .containers import AddTable, ConcatTable, Identity, JoinTable, NetworkInNetwork, Sequential
+from .containers import (AddTable, ConcatTable, Identity, JoinTable, NetworkInNetwork, ResidualConcatTable,
+                         Sequential)
 from .conv import Convolution, Deconvolution, SubmanifoldConvolution
 from .norm import BatchNormLeakyReLU
 
@@ -20,7 +21,8 @@ def UNet(dimension, reps, nPlanes, residual_blocks=False, downsample=[2, 2], lea
         if residual_blocks:  # ResNet style
             shortcut = Identity() if a == b else NetworkInNetwork(a, b, False)
             body = Sequential().add(bn(a)).add(sc(a, b)).add(bn(b)).add(sc(b, b))
-            m.add(ConcatTable().add(shortcut).add(body)).add(AddTable())
+            # ResidualConcatTable: a ConcatTable whose last convolution adds the shortcut inside its kernel
+            m.add(ResidualConcatTable().add(shortcut).add(body)).add(AddTable())
         else:  # VGG style
             m.add(Sequential().add(bn(a)).add(sc(a, b)))
 

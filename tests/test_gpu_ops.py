@@ -265,3 +265,55 @@ def test_submanifold_forward_variants(gpu, ci, co):
         SCN.SubmanifoldConvolution_backward(size, F3, m, _t(x, gpu), gi, _t(dy, gpu), _t(w, gpu), gw, gb, 1)
         assert_close(gi.cpu().numpy(), d_in, "large submanifold dInput")
         assert_close(gw.cpu().numpy(), d_w, "large submanifold dWeight")
+
+
+@pytest.mark.parametrize("ci,co,n", [(64, 64, 72000), (32, 32, 3000), (128, 64, 3000), (3, 16, 3000)])
+def test_submanifold_forward_with_fused_residual(gpu, ci, co, n):
+    """out = residual + bias + conv(x) inside the kernel (the shortcut of a residual block): every forward kernel
+    (barrier-free tile, LDS-staged tile with and without the offset split, generic) against conv + residual"""
+    from occuseg_amd import SCN
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu, seed=5, n=n, batch=2, extent=60 if n > 10000 else 20)
+    rules, _ = R.submanifold_rules(grid)
+    rng = np.random.default_rng(ci * co)
+    x = rng.normal(size=(grid.n, ci)).astype(np.float32)
+    w = (rng.normal(size=(27, ci, co)) * (2.0 / ci / 27) ** 0.5).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    res = rng.normal(size=(grid.n, co)).astype(np.float32)
+    want, _ = A.conv_forward(x, w, rules, grid.n, b, dtype=np.float64)
+    out = torch.empty(0, device=gpu)
+    SCN.SubmanifoldConvolution_updateOutput(size, F3, m, _t(x, gpu), out, _t(w, gpu), _t(b, gpu), 1, residual=_t(res, gpu))
+    assert_close(out.cpu().numpy(), want + res, "conv + residual %d->%d" % (ci, co))
+
+
+def test_residual_block_fusion_equals_add_table(gpu):
+    """scn.UNet's residual blocks hand the shortcut to their last convolution (ResidualConcatTable); a plain
+    ConcatTable -> AddTable over the SAME modules gives the same outputs and the same gradients"""
+    import occuseg_amd
+    from occuseg_amd import scenes
+    scn = occuseg_amd.install()
+    torch.manual_seed(9)
+    m = 16
+    net = scn.Sequential().add(scn.InputLayer(3, 4096, mode=4)).add(scn.SubmanifoldConvolution(3, 3, m, 3, False)).add(
+        scn.UNet(3, 1, [m, 2 * m], residual_blocks=True)).add(scn.OutputLayer(3)).to(gpu)
+    fused = [mod for mod in net.modules() if isinstance(mod, scn.ResidualConcatTable)]
+    assert len(fused) == 3
+    coords, feats = scenes.batch([1000, 1001], target_sites=4000)
+    batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        out = net(batch)
+        out.square().sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()]
+
+    o1, g1 = run()
+    for mod in fused:
+        mod.__class__ = scn.ConcatTable   # same children, plain behaviour: [shortcut, body] -> AddTable
+    o2, g2 = run()
+    for mod in fused:
+        mod.__class__ = scn.ResidualConcatTable
+    assert_close(o1.cpu().numpy(), o2.cpu().numpy(), "fused residual output", rel=1e-5)
+    for a, b in zip(g1, g2):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), "fused residual grads", rel=1e-4)
