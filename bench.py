@@ -213,6 +213,8 @@ def main():
     # gives the per-step durations for the median.
     prof, prof_extra = [], []
     SCN.PROFILE_KINDS = ("mm",)
+    if rank == 0:  # ~230 events per profiled step (matrix launches) + ~900 for the extra step, created now
+        SCN.warm_event_pool(260 * len(range(0, args.steps, args.event_every)) + 1000)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sites_done = 0
     first = counter[0]
@@ -227,13 +229,13 @@ def main():
     SCN.PROFILE = None
     barrier()
     dt = time.perf_counter() - t0
-    if rank == 0:  # the extra, untimed step: events on batch norm, rule build and io launches only
-        SCN.PROFILE_KINDS = ("bn", "rules", "io")
-        SCN.PROFILE = prof_extra
-        step()
-        SCN.PROFILE = None
-        SCN.PROFILE_KINDS = ("mm", "bn", "rules", "io")
-        torch.cuda.synchronize()
+    # the extra, untimed step (every rank runs it: it holds collectives): events on batch norm, rule build, io launches
+    SCN.PROFILE_KINDS = ("bn", "rules", "io")
+    SCN.PROFILE = prof_extra if rank == 0 else None
+    step()
+    SCN.PROFILE = None
+    SCN.PROFILE_KINDS = ("mm", "bn", "rules", "io")
+    barrier()
 
     t = torch.tensor([dt, float(sites_done)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -301,6 +303,8 @@ def main():
                 torch.cuda.synchronize()
                 alone.append(e0.elapsed_time(e1))
             kernels["rules"]["alone_ms_per_batch"] = min(alone)
+            kernels["rules"]["alone_ms_all"] = alone
+            kernels["rules"]["alone_rulebooks_built"] = len(plan)
             kernels["rules"]["alone_algo_GBs"] = kernels["rules"]["algo_bytes_per_step"] / min(alone) / 1e6
             kernels["rules"]["alone_hbm_frac"] = kernels["rules"]["alone_algo_GBs"] / HBM_PEAK_GBS
             kernels["rules"]["note"] = ("ms_per_step: on the side stream, overlapped with and slowed by the step's "

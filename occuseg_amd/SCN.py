@@ -25,10 +25,25 @@ PROFILE = None
 PROFILE_KINDS = ("mm", "bn", "rules", "io")  # which launches carry events: matrix kernels / batch norm / rule build / io
 
 
+_EVENT_POOL = []  # timing events created ahead of the timed region (creating one inside it costs far more than recording)
+
+
+def warm_event_pool(n):
+    """create (and record once, which is what really creates them) n timing events for _prof_begin/_prof_end to use"""
+    while len(_EVENT_POOL) < n:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _EVENT_POOL.append(ev)
+
+
+def _event():
+    return _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+
+
 def _prof_begin(kind="mm"):
     if PROFILE is None or kind not in PROFILE_KINDS:
         return None
-    ev = torch.cuda.Event(enable_timing=True)
+    ev = _event()
     ev.record()
     return ev
 
@@ -37,7 +52,7 @@ def _prof_end(ev, kernel, flops, nbytes, shape=None):
     """nbytes may be a callable (evaluated when the profile is summarised: pair counts that are not known on the
     host yet when a rulebook build is queued)"""
     if ev is not None:
-        end = torch.cuda.Event(enable_timing=True)
+        end = _event()
         end.record()
         PROFILE.append((kernel, flops, nbytes, ev, end, shape))
 
