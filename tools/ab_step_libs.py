@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of whole train steps with TWO builds of the library in ONE process (interleaved rounds, alternating two
-different batches with the rulebook prefetch on, as bench.py does).  usage: python tools/ab_step_libs.py <libA.so> [<libB.so>]"""
+different batches with the rulebook prefetch on, as bench.py does).  usage: python tools/ab_step_libs.py <lib1.so> [<lib2.so> ...]   (the product library is always the last contestant)"""
 import os
 import sys
 
@@ -11,10 +11,10 @@ import bench
 import occuseg_amd
 from occuseg_amd import SCN, _lib, dp, scenes
 
-path_a = os.path.abspath(sys.argv[1])
-path_b = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else _lib.LIB_PATH
-libs = {"A": _lib._open(path_a, _lib.SIGNATURES), "B": _lib._open(path_b, _lib.SIGNATURES)}
-_lib._lib = libs["B"]
+paths = [os.path.abspath(a) for a in sys.argv[1:]] + [_lib.LIB_PATH]
+names = [chr(ord("A") + i) for i in range(len(paths))]
+libs = {n: _lib._open(p, _lib.SIGNATURES) for n, p in zip(names, paths)}
+_lib._lib = libs[names[-1]]
 scn = occuseg_amd.install()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -40,9 +40,9 @@ def step():
 
 for _ in range(4):
     step()
-res = {"A": [], "B": []}
+res = {n: [] for n in names}
 for rnd in range(5):
-    for name in ("A", "B"):
+    for name in names:
         torch.cuda.synchronize()
         _lib._lib = libs[name]
         SCN.invalidate_weight_cache()
@@ -56,5 +56,5 @@ for rnd in range(5):
         e1.record()
         torch.cuda.synchronize()
         res[name].append(e0.elapsed_time(e1) / 6)
-for name, path in (("A", path_a), ("B", path_b)):
+for name, path in zip(names, paths):
     print("%s (%s): %s  min %.2f ms" % (name, os.path.basename(path), " ".join("%.2f" % t for t in res[name]), min(res[name])))

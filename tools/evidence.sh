@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round evidence on the GPU box (run through gpurun; everything lands under gpurun_out/evidence/, the summaries are then
+# copied to profiles/ by hand):
+#   1. bench.py lines (default, 20 steps)                                    -> bench.json, bench20.json
+#   2. rocprofv3 --kernel-trace --stats of the bench command                 -> kernel_stats.csv
+#   3. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)        -> traffic.json (tools/pmc_traffic.py)
+#   4. rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES (in-step clock and MFMA-pipe occupancy per kernel)
+#   5. PMC groups on the isolated gather-mm layers (tools/pmc_groups.sh)      -> pmc_conv_tile4.txt
+# --pmc runs use --kernel-trace only (the pool refuses PMC together with the hip/hsa trace domains).
+set -u
+E=gpurun_out/evidence
+mkdir -p $E
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python3 bench.py > $E/bench.json 2> $E/bench.err
+python3 bench.py --no-cpu-baseline --steps 20 > $E/bench20.json 2>> $E/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > $E/bench_under_rocprof.json 2> $E/stats.err
+cp $(find $E/stats -name "*kernel_stats.csv" | head -1) $E/kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/fetch -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $E/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/write -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $E/write.err
+python3 tools/pmc_traffic.py $E/fetch $E/write $E/traffic.json > $E/traffic.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $E/clock -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $E/clock.err
+python3 tools/pmc_instep.py $E/clock > $E/instep_clock.txt 2>&1
+bash tools/pmc_groups.sh 1 $E/pmc_tile4
+python3 tools/pmc_summary.py $E/pmc_tile4 k_conv_tile4 > $E/pmc_conv_tile4.txt 2>&1
+python3 tools/pmc_summary.py $E/pmc_tile4 k_dw_tile > $E/pmc_dw_tile.txt 2>&1
+# keep the merge small: raw traces stay on the box
+find $E -name "*.db" -delete
+find $E -name "*kernel_trace.csv" -size +2M -delete
+find $E -name "*counter_collection.csv" -size +8M -delete
+du -sh $E
