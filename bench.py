@@ -293,7 +293,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             alone = []
             plan_key = (4096, 4096, 4096)
-            plan = list(SCN._PLANS.get(plan_key, []))  # the rulebook requests of one forward pass of this network
+            plan = list(SCN._PLANS_USED.get(plan_key, []))  # the rulebook requests of one forward pass of this network
             for b in batches + batches:
                 SCN._PLANS[plan_key] = list(plan)
                 md = SCN.Metadata_3()

@@ -84,6 +84,7 @@ def _need_cuda(t, what):
 # the recorded requests up front, while the queue is still empty, so the host runs ahead of the GPU
 # for the rest of the step.  Purely a scheduling matter: the lazily built result is identical.
 _PLANS = {}
+_PLANS_USED = {}  # spatial size -> the request list of the most recent forward pass that really ran (tools, bench)
 PREBUILD = True
 KEEP_NBR = False  # tests only: keep each submanifold rulebook's neighbour table (`d_global_query_result`) alive
 _COORD_DTYPES = {torch.int32: 0, torch.int64: 1, torch.float32: 2}  # scn_grid_build coords_dtype
@@ -304,6 +305,7 @@ class Metadata_3(object):
     def _record(self, req):
         if req not in self._plan:
             self._plan.append(req)
+        _PLANS_USED[self.inputSpatialSize] = self._plan
 
     def getNActive(self, spatialSize):
         return self.nActive[_size_key(spatialSize)]
