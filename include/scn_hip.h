@@ -136,6 +136,10 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
  *   residual (may be NULL): fp32 [n_out, Co] added to the result, out = residual + bias + sum ...: the output tile
  *   starts from its rows, so the shortcut of a residual block (sparseconvnet/networkArchitectures.py:222-229: AddTable over
  *   ConcatTable(shortcut, body)) costs one read instead of a separate elementwise kernel.  May alias nothing else.
+ *   colstats (may be NULL): fp32 [scn_conv_stats_blocks(...)][2][Co] -- per block of output rows the column sums and sums
+ *   of squares of the RESULT, taken while the output tile is still in LDS / registers; scn_bn_forward_ext finalizes a
+ *   batch norm over this tensor from them without reading the tensor once more.  scn_conv_stats_blocks() == 0: this
+ *   launch cannot emit them (planes not multiples of 16, > 4 GiB fallback): pass NULL.
  *   counts [K] (device) = pairs per list.  out_unique != 0 promises that EVERY output row appears in exactly one pair of
  *   the rulebook (deconvolution and the dInput of a strided convolution: each fine row has one parity class,
  *   sparseconvnet/SCN/CUDA/Deconvolution.cu:48-49; NetworkInNetwork: the identity list): such launches run without any
@@ -156,8 +160,9 @@ size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_o
 int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
 int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int Ci, int Co, void *wpack,
                     void *stream);
+int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const float *residual, const int32_t *rules,
+                     const float *bias, const float *residual, float *colstats, const int32_t *rules,
                      const int32_t *bases, const int32_t *counts,
                      int K, int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in,
                      int64_t n_out, int Ci, int Co, void *wpack, int wpack_ready, void *workspace,
@@ -198,6 +203,15 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
                    float *running_mean, float *running_var, const float *weight,
                    const float *bias, double eps, double momentum, int train, double leakiness,
                    int64_t N, int C, void *temp, void *stream);
+/* training forward with the statistics handed over by the producing kernels: nseg segments of planes (in order, covering
+ * all C), segment i = seg_ncols[i] planes with partial sums seg_partial[i] = [seg_nblk[i]][2][seg_ncols[i]] (device;
+ * the three arrays themselves are HOST arrays).  Only finalize + apply run: 8 instead of 12 bytes per element. */
+int scn_bn_forward_ext(const float *x, float *y, float *save_mean, float *save_invstd,
+                       float *running_mean, float *running_var, const float *weight,
+                       const float *bias, double eps, double momentum, double leakiness,
+                       int64_t N, int C, void *temp, int nseg, const int32_t *seg_ncols_host,
+                       const float *const *seg_partial_host, const int32_t *seg_nblk_host,
+                       void *stream);
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
                     const float *save_mean, const float *save_invstd, const float *weight,
                     const float *bias, float *d_weight, float *d_bias, double leakiness, int64_t N,

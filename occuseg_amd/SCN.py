@@ -518,7 +518,8 @@ def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
     return wpack, 1
 
 
-def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False, residual=None):
+def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False, residual=None,
+          stats_out=None):
     """out = gather-mm-scatter over rb; weight is the module's [K, a, b] tensor, used as [K, Ci, Co]
     (forward) or, with w_transposed, as its per-offset transpose (dInput).  When every output row appears in exactly
     one pair of the rulebook (rb.unique_col == out_col: the fine column of a strided rulebook, the identity list)
@@ -536,9 +537,16 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     uniq = int(rb.unique_col is not None and (rb.unique_col == out_col or rb.unique_col == 2))
     ws_bytes = lib.scn_conv_workspace_bytes(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=inp.device) if ws_bytes else None
+    # column statistics of the result for the batch norm that consumes it (stats_out: a list that receives the tensor)
+    cstats = None
+    if stats_out is not None:
+        nblk = lib.scn_conv_stats_blocks(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
+        if nblk > 0:
+            cstats = torch.empty((nblk, 2, Co), dtype=torch.float32, device=inp.device)
+            stats_out.append(cstats)
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
-                               ptr(bias) if bias is not None and bias.numel() else None, ptr(residual),
+                               ptr(bias) if bias is not None and bias.numel() else None, ptr(residual), ptr(cstats),
                                ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.counts), K, rb.stride, in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
     # algorithmic work of one launch: flops = 2 R Ci Co;
@@ -635,16 +643,18 @@ def OutputLayer_updateGradInput(m, d_input_features, d_output_features):
 
 
 def SubmanifoldConvolution_updateOutput(spatialSize, filterSize, m, input_features, output_features, weight,
-                                        bias, dilated_rate=1, residual=None):
+                                        bias, dilated_rate=1, residual=None, stats_out=None):
     """sparseconvnet/SCN/pybind.cpp:138-142 -> sparseconvnet/SCN/CUDA/Convolution.cpp:105-162.
     Returns the multiply-add count sum_k R_k*Ci*Co (the reference returns 0 on
     its chunk path, sparseconvnet/SCN/CUDA/Convolution.cu:1286,1374 -- treated as a bug).
-    ``residual`` (not in the reference): [N, nOut] tensor added to the result inside the kernel."""
+    ``residual`` (not in the reference): [N, nOut] tensor added to the result inside the kernel.  ``stats_out`` (not in
+    the reference): a list that receives the per-block column sums / sums of squares of the result, which
+    ``BatchNormalization_updateOutput(..., _colstats=...)`` consumes instead of reading the tensor once more."""
     _need_cuda(input_features, "SubmanifoldConvolution_updateOutput")
     rb = m.getSubmanifoldRuleBook(spatialSize, filterSize, dilated_rate)
     n = m.getNActive(spatialSize)
     _conv(input_features.contiguous(), output_features, weight, bias, rb, 0, 1, n,
-          residual=residual.contiguous() if residual is not None else None)
+          residual=residual.contiguous() if residual is not None else None, stats_out=stats_out)
     return float(rb.total_pairs) * weight.size(1) * weight.size(2)
 
 
@@ -677,12 +687,12 @@ def SubmanifoldConvolution_backward(spatialSize, filterSize, m, input_features, 
 
 
 def Convolution_updateOutput(inputSize, outputSize, filterSize, filterStride, m, input_features,
-                             output_features, weight, bias):
+                             output_features, weight, bias, stats_out=None):
     """sparseconvnet/SCN/pybind.cpp:58-63 -> sparseconvnet/SCN/CUDA/Convolution.cpp:36-66"""
     _need_cuda(input_features, "Convolution_updateOutput")
     rb = m.getRuleBook(inputSize, outputSize, filterSize, filterStride)
     n_out = m.getNActive(outputSize)
-    _conv(input_features.contiguous(), output_features, weight, bias, rb, 0, 1, n_out)
+    _conv(input_features.contiguous(), output_features, weight, bias, rb, 0, 1, n_out, stats_out=stats_out)
     return float(rb.total_pairs) * weight.size(1) * weight.size(2)
 
 
@@ -697,13 +707,13 @@ def Convolution_backward(inputSize, outputSize, filterSize, filterStride, m, inp
 
 
 def Deconvolution_updateOutput(inputSize, outputSize, filterSize, filterStride, m, input_features,
-                               output_features, weight, bias):
+                               output_features, weight, bias, stats_out=None):
     """sparseconvnet/SCN/pybind.cpp:82-87 -> sparseconvnet/SCN/CUDA/Deconvolution.cpp:20-49: the conv rulebook
     of (outputSize -> inputSize) with the columns swapped."""
     _need_cuda(input_features, "Deconvolution_updateOutput")
     rb = m.getRuleBook(outputSize, inputSize, filterSize, filterStride)
     n_out = m.getNActive(outputSize)
-    _conv(input_features.contiguous(), output_features, weight, bias, rb, 1, 0, n_out)
+    _conv(input_features.contiguous(), output_features, weight, bias, rb, 1, 0, n_out, stats_out=stats_out)
     return float(rb.total_pairs) * weight.size(1) * weight.size(2)
 
 
@@ -723,8 +733,10 @@ def _bn_temp(C, device):
 
 
 def BatchNormalization_updateOutput(input_features, output_features, saveMean, saveInvStd, runningMean,
-                                    runningVar, weight, bias, eps, momentum, train, leakiness):
-    """sparseconvnet/SCN/sparseconvnet.h:21-26 -> sparseconvnet/SCN/CUDA/BatchNormalization.cpp:21-42"""
+                                    runningVar, weight, bias, eps, momentum, train, leakiness, _colstats=None):
+    """sparseconvnet/SCN/sparseconvnet.h:21-26 -> sparseconvnet/SCN/CUDA/BatchNormalization.cpp:21-42.
+    ``_colstats`` (not in the reference): [(planes, partial sums [blocks, 2, planes]), ...] covering all planes in order,
+    as the producing convolutions emitted them: the statistics pass over the input is skipped."""
     _need_cuda(input_features, "BatchNormalization_updateOutput")
     x = input_features.contiguous()
     N, C = x.shape
@@ -733,6 +745,17 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
     saveInvStd.resize_(C)
     temp = _bn_temp(C, x.device)
     ev = _prof_begin("bn")
+    if train and _colstats:
+        assert sum(n for n, _ in _colstats) == C and all(p.is_contiguous() and p.size(2) == n for n, p in _colstats)
+        nseg = len(_colstats)
+        ncols = (ctypes.c_int32 * nseg)(*[n for n, _ in _colstats])
+        parts = (ctypes.c_void_p * nseg)(*[p.data_ptr() for _, p in _colstats])
+        nblks = (ctypes.c_int32 * nseg)(*[p.size(0) for _, p in _colstats])
+        check(_lib_().scn_bn_forward_ext(ptr(x), ptr(output_features), ptr(saveMean), ptr(saveInvStd), ptr(runningMean),
+                                         ptr(runningVar), ptr(weight), ptr(bias), float(eps), float(momentum),
+                                         float(leakiness), N, C, ptr(temp), nseg, ncols, parts, nblks, stream()))
+        _prof_end(ev, "bn_fwd", 0.0, 8.0 * N * C, (N, C, "ext"))  # x read once, y written
+        return
     check(_lib_().scn_bn_forward(ptr(x), ptr(output_features), ptr(saveMean), ptr(saveInvStd), ptr(runningMean),
                                  ptr(runningVar), ptr(weight), ptr(bias), float(eps), float(momentum), int(train),
                                  float(leakiness), N, C, ptr(temp), stream()))

@@ -56,7 +56,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <int NW, int COS, int M, int CK>
 __global__ void __launch_bounds__(64 * NW)
     k_conv_tile(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
-                const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
+                const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                 int64_t n_out, int n_gran, int Ci, int Co) {
   constexpr int COB = NW * COS * 16;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256)
 template <int NW, int COS, int CK, int DBG = 0, int NWM = 1, int M_ = 0>
 __global__ void __launch_bounds__(64 * NW * NWM)
     k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb, int ksplit,
                  unsigned in_bytes, unsigned wp_bytes) {
@@ -562,6 +562,76 @@ __global__ void __launch_bounds__(64 * NW * NWM)
     const int r = i / (COB / 4), c4 = i % (COB / 4);
     *(float4 *)(dst + (o0 + r) * Co + co0 + c4 * 4) = *(const float4 *)(o_tile + r * OS + c4 * 4);
   }
+  // Column statistics of the finished tile (sum, sum of squares per output plane over the tile's rows) while it is still
+  // in LDS: the batch norm that consumes this tensor takes them instead of reading the tensor once more
+  // (colstats [ntiles][2][Co], one deterministic partial per tile; the fp64 finalize of scn_bn_forward adds them up).
+  if (colstats != nullptr && ksplit == 1) {
+    constexpr int G = NT / COB;  // threads per column
+    const int c = tid % COB, g = tid / COB;
+    float cs = 0.f, css = 0.f;
+    for (int r = g; r < rows; r += G) {
+      const float v = o_tile[r * OS + c];
+      cs += v;
+      css += v * v;
+    }
+    float *red = a_tile;  // free: every wave is past the last phase's closing barrier (or no phase ran)
+    red[(g * COB + c) * 2 + 0] = cs;
+    red[(g * COB + c) * 2 + 1] = css;
+    __syncthreads();
+    if (tid < COB) {
+      cs = 0.f; css = 0.f;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        cs += red[(j * COB + tid) * 2 + 0];
+        css += red[(j * COB + tid) * 2 + 1];
+      }
+      colstats[((int64_t)tile * 2 + 0) * Co + co0 + tid] = cs;
+      colstats[((int64_t)tile * 2 + 1) * Co + co0 + tid] = css;
+    }
+  }
+}
+
+// the same reduction, row blocks of 64 rows per workgroup, with the column statistics of the result (colstats
+// [ceil(n_out / 64)][2][Co]): thread = (row slot, 4-plane column group)
+__global__ void __launch_bounds__(256)
+    k_split_reduce_stats(const float *__restrict__ part, float *__restrict__ out, int64_t n_out, int Co, int ksplit,
+                         float *__restrict__ colstats) {
+  __shared__ float red[2][256 * 4];
+  const int cg4 = Co / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = min(n_out, r0 + 64);
+  const int64_t slab = n_out * Co;
+  for (int cb = 0; cb < cg4; cb += 256) {  // Co <= 1024: one trip
+    const int ncg = min(256, cg4 - cb);
+    const int nslot = 256 / ncg;
+    const int cg = cb + (int)threadIdx.x % ncg, slot = (int)threadIdx.x / ncg;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), css = cs;
+    if (slot < nslot)
+      for (int64_t r = r0 + slot; r < r1; r += nslot) {
+        const int64_t i = r * Co + cg * 4;
+        float4 a = *(const float4 *)(part + i);
+        for (int j = 1; j < ksplit; ++j) {
+          const float4 b = *(const float4 *)(part + (int64_t)j * slab + i);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *(float4 *)(out + i) = a;
+        cs.x += a.x; cs.y += a.y; cs.z += a.z; cs.w += a.w;
+        css.x += a.x * a.x; css.y += a.y * a.y; css.z += a.z * a.z; css.w += a.w * a.w;
+      }
+    __syncthreads();
+    *(float4 *)(red[0] + threadIdx.x * 4) = cs;
+    *(float4 *)(red[1] + threadIdx.x * 4) = css;
+    __syncthreads();
+    if (slot == 0) {
+      for (int j = 1; j < nslot; ++j) {
+        const float4 a = *(const float4 *)(red[0] + (j * ncg + (int)threadIdx.x) * 4);
+        const float4 b = *(const float4 *)(red[1] + (j * ncg + (int)threadIdx.x) * 4);
+        cs.x += a.x; cs.y += a.y; cs.z += a.z; cs.w += a.w;
+        css.x += b.x; css.y += b.y; css.z += b.z; css.w += b.w;
+      }
+      *(float4 *)(colstats + ((int64_t)blockIdx.x * 2 + 0) * Co + cg * 4) = cs;
+      *(float4 *)(colstats + ((int64_t)blockIdx.x * 2 + 1) * Co + cg * 4) = css;
+    }
+  }
 }
 
 // out[i] = part[0][i] + part[1][i] + ... + part[ksplit-1][i], always in this order
@@ -603,7 +673,7 @@ __global__ void __launch_bounds__(256)
 template <int DBG = 0>
 __global__ void __launch_bounds__(128)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes, int ksplit) {
@@ -940,6 +1010,22 @@ __global__ void __launch_bounds__(128)
     const int r = i >> 3, c4 = (i & 7) * 4;
     *(floatx4 *)(dst + (o0 + r) * Co + co0 + 32 * w + c4) = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
   }
+  // column statistics of this wave's 32 planes over the tile's rows (see k_conv_tile2): lane = (plane, half of the rows)
+  if (colstats != nullptr && ksplit == 1) {
+    const int p = lane & 31, half = lane >> 5;
+    float cs = 0.f, css = 0.f;
+    for (int r = half * 64; r < min(rows, half * 64 + 64); ++r) {
+      const float v = o_tile[r * OS + 32 * w + p];
+      cs += v;
+      css += v * v;
+    }
+    cs += __shfl_xor(cs, 32);
+    css += __shfl_xor(css, 32);
+    if (half == 0) {
+      colstats[((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + p] = cs;
+      colstats[((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + p] = css;
+    }
+  }
 }
 
 // ------------------------------ forward, barrier-free, ONE wave per tile (v5) ---
@@ -956,7 +1042,7 @@ __global__ void __launch_bounds__(128)
 template <int DBG = 0>
 __global__ void __launch_bounds__(64)
     k_conv_tile5(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes, int ksplit) {
@@ -1339,7 +1425,7 @@ __device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], con
 // walked in chunks of 32 planes, the loads of chunk c+1 requested before the MFMAs of chunk c.
 __global__ void __launch_bounds__(64)
     k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                  const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
+                  const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
                   int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes, unsigned wp_bytes) {
   // chunks of 32 reduction planes: 2 x (8 row + 32 weight) registers in flight + 32 accumulators keep the wave at
   // ~150 VGPRs = three waves per SIMD (with 64-plane chunks it needed 272: one wave per SIMD, and a launch of
@@ -1424,8 +1510,33 @@ __global__ void __launch_bounds__(64)
         if (bias) v += *(const floatx4 *)(bias + co0 + 16 * q + 4 * lq);
         if (residual) v += *(const floatx4 *)(residual + orow[g] * Co + co0 + 16 * q + 4 * lq);
         *(floatx4 *)(out + orow[g] * Co + co0 + 16 * q + 4 * lq) = v;
+        acc[g][q] = v;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < COS; ++q) acc[g][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+  // column statistics of the wave's 32 output rows (colstats [pair blocks][2][Co], zeroed by the launcher: blocks past the
+  // end of the lists write nothing): sum over the 16 pairs of a group = butterfly over the 16 lanes that share lq
+  if (colstats != nullptr) {
+    const int64_t pb = blockIdx.x / ncb;
+#pragma unroll
+    for (int q = 0; q < COS; ++q) {
+      floatx4 cs = acc[0][q] + acc[1][q];
+      floatx4 css = acc[0][q] * acc[0][q] + acc[1][q] * acc[1][q];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cs[e] += __shfl_xor(cs[e], o);
+          css[e] += __shfl_xor(css[e], o);
+        }
+      if (li == 0) {
+        *(floatx4 *)(colstats + (pb * 2 + 0) * Co + co0 + 16 * q + 4 * lq) = cs;
+        *(floatx4 *)(colstats + (pb * 2 + 1) * Co + co0 + 16 * q + 4 * lq) = css;
       }
     }
+  }
 }
 
 // generic fallback (any Ci, Co; scalar FMA; used by the 3 -> m stem): 32 output rows x 64 planes per
@@ -1435,7 +1546,7 @@ __global__ void __launch_bounds__(64)
 template <bool W_IN_LDS>
 __global__ void __launch_bounds__(256)
     k_conv_generic(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
-                   const float *__restrict__ bias, const float *__restrict__ residual, const int2 *__restrict__ rules,
+                   const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
                    const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                    int64_t n_out, int n_gran, int Ci, int Co, int w_transposed, int w_reverse) {
   constexpr int M = SCN_TILE_GRANULE;
@@ -1880,19 +1991,19 @@ static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, in
 }
 
 template <int NW, int COS, int M, int CK>
-static int launch_tile(const float *in, float *out, const float *W, const float *bias, const float *residual,
+static int launch_tile(const float *in, float *out, const float *W, const float *bias, const float *residual, float *colstats,
                        const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                        int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)((n_out + M - 1) / M), (unsigned)(Co / (NW * COS * 16)));
-  k_conv_tile<NW, COS, M, CK><<<grid, 64 * NW, 0, stream>>>(in, out, W, bias, residual, (const int2 *)rules, bases,
+  k_conv_tile<NW, COS, M, CK><<<grid, 64 * NW, 0, stream>>>(in, out, W, bias, residual, colstats, (const int2 *)rules, bases,
                                                           K, stride, in_col, n_out, n_gran, Ci, Co);
   SCN_CHECK_LAUNCH();
   return 0;
 }
 
 template <int NW, int COS, int CK, int NWM = 1, int M_ = 0>
-static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias, const float *residual,
+static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias, const float *residual, float *colstats,
                         const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                         int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
                         hipStream_t stream) {
@@ -1905,7 +2016,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_T2(D)                                                                                   \
   k_conv_tile2<NW, COS, CK, D, NWM, M_><<<grid2, 64 * NW * NWM, 0, stream>>>(                             \
-      in, dst, Wp, bias, residual, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit, \
+      in, dst, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit, \
       in_bytes, wp_bytes)
 #ifdef SCN_TUNING
   if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
@@ -1927,16 +2038,20 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
 #undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();
   if (ksplit > 1) {
-    const int64_t total4 = n_out * Co / 4;
-    int64_t g = (total4 + 255) / 256;
-    if (g > 2048) g = 2048;
-    k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
+    if (colstats != nullptr) {  // the reduction also yields the column statistics of the result
+      k_split_reduce_stats<<<(unsigned)((n_out + 63) / 64), 256, 0, stream>>>(part, out, n_out, Co, ksplit, colstats);
+    } else {
+      const int64_t total4 = n_out * Co / 4;
+      int64_t g = (total4 + 255) / 256;
+      if (g > 2048) g = 2048;
+      k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
+    }
     SCN_CHECK_LAUNCH();
   }
   return 0;
 }
 
-static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, const int32_t *rules,
+static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, float *colstats, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
                         int Ci, int Co, int ksplit, float *part, hipStream_t stream) {
   constexpr int M = 128;
@@ -1947,12 +2062,12 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   float *dst4 = ksplit > 1 ? part : out;
   const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_TILE4(D)                                                                                         \
-  k_conv_tile4<D><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, (const int2 *)rules, bases, K,                     \
+  k_conv_tile4<D><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,                     \
                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
                                              in_bytes, wp_bytes, ksplit)
 #ifdef SCN_TUNING
   if (g_conv_tile5 != 0) {  // one wave per tile, all 64 planes (k_conv_tile5): A/B only, measured slower
-    k_conv_tile5<0><<<grid4, 64, 0, stream>>>(in, dst4, Wp, bias, residual, (const int2 *)rules, bases, K, stride, in_col, n_out,
+    k_conv_tile5<0><<<grid4, 64, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
                                              n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
   } else
 #endif
@@ -1977,27 +2092,31 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 #undef SCN_LAUNCH_TILE4
   SCN_CHECK_LAUNCH();
   if (ksplit > 1) {
-    const int64_t total4 = n_out * Co / 4;
-    int64_t g = (total4 + 255) / 256;
-    if (g > 2048) g = 2048;
-    k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
+    if (colstats != nullptr) {  // the reduction also yields the column statistics of the result
+      k_split_reduce_stats<<<(unsigned)((n_out + 63) / 64), 256, 0, stream>>>(part, out, n_out, Co, ksplit, colstats);
+    } else {
+      const int64_t total4 = n_out * Co / 4;
+      int64_t g = (total4 + 255) / 256;
+      if (g > 2048) g = 2048;
+      k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
+    }
     SCN_CHECK_LAUNCH();
   }
   return 0;
 }
 
 template <int NW>
-static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias, const float *residual,
+static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias, const float *residual, float *colstats,
                            const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                            int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
                            hipStream_t stream) {
 #ifdef SCN_TUNING
   if (NW == 4 && g_conv_wide && Ci % 64 == 0 && Co % 128 == 0 && ksplit == 1)
-    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, 1, part, stream);
+    return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, 1, part, stream);
 #endif
-  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
-  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
-  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
 }
 
 extern "C" {
@@ -2034,6 +2153,16 @@ size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_o
   return p.ksplit > 1 ? (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4 : 0;
 }
 
+int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique) {
+  if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
+  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
+  if (p.kind == 5) return (n_out + 31) / 32 + K;
+  if (p.kind != 2 && p.kind != 4) return 0;  // generic / fallback kernels do not emit statistics
+  if (p.ksplit > 1) return (n_out + 63) / 64;
+  const int M = p.kind == 4 ? 128 : 32 * p.nw;
+  return (n_out + M - 1) / M;
+}
+
 int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique) {
   if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
   const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
@@ -2056,7 +2185,7 @@ int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int 
 }
 
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const float *residual, const int32_t *rules, const int32_t *bases, const int32_t *counts, int K,
+                     const float *bias, const float *residual, float *colstats, const int32_t *rules, const int32_t *bases, const int32_t *counts, int K,
                      int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in, int64_t n_out, int Ci,
                      int Co, void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
@@ -2083,17 +2212,18 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
         }
       }
       switch (p.nw) {
-        case 4: return launch_tile<4, 1, 64, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-        case 3: return launch_tile<3, 1, 64, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-        case 2: return launch_tile<2, 1, 64, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
-        default: return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        case 4: return launch_tile<4, 1, 64, 64>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        case 3: return launch_tile<3, 1, 64, 64>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        case 2: return launch_tile<2, 1, 64, 64>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
+        default: return launch_tile<1, 1, 64, 64>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, Ci, Co, stream);
       }
     }
     if (p.kind == 5) {
       const int ncb = Co / 64;
       const int64_t nblk = (n_out + 31) / 32 + K;  // every output row in exactly one pair: sum_k ceil(count_k / 32) <= this
       const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
-      k_conv_expand<<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, (const int2 *)rules, counts, K, stride,
+      if (colstats != nullptr) SCN_CHECK_HIP(hipMemsetAsync(colstats, 0, (size_t)nblk * 2 * Co * sizeof(float), stream));
+      k_conv_expand<<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, stride,
                                                              in_col, Ci, Co, ncb, in_bytes, wp_bytes);
       SCN_CHECK_LAUNCH();
       return 0;
@@ -2103,22 +2233,22 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     float *part = (float *)workspace;
     if (p.kind == 4)
-      return launch_tile4(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      return launch_tile4(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
     switch (p.nw) {
-      case 4: return launch_tile2_ck<4>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      case 3: return launch_tile2_ck<3>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      case 2: return launch_tile2_ck<2>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      default: return launch_tile2_ck<1>(in, out, Wp, bias, residual, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 4: return launch_tile2_ck<4>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 3: return launch_tile2_ck<3>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 2: return launch_tile2_ck<2>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      default: return launch_tile2_ck<1>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
     }
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)(n_gran < 2048 ? n_gran : 2048), (unsigned)((Co + 63) / 64));  // persistent: weights staged once
   const size_t wbytes = (size_t)K * Ci * 64 * 4;
   if (wbytes <= 40 * 1024)
-    k_conv_generic<true><<<grid, 256, wbytes, stream>>>(in, out, W, bias, residual, (const int2 *)rules, bases, K, stride,
+    k_conv_generic<true><<<grid, 256, wbytes, stream>>>(in, out, W, bias, residual, colstats, (const int2 *)rules, bases, K, stride,
                                                         in_col, n_out, n_gran, Ci, Co, w_transposed, w_reverse);
   else
-    k_conv_generic<false><<<grid, 256, 0, stream>>>(in, out, W, bias, residual, (const int2 *)rules, bases, K, stride,
+    k_conv_generic<false><<<grid, 256, 0, stream>>>(in, out, W, bias, residual, colstats, (const int2 *)rules, bases, K, stride,
                                                     in_col, n_out, n_gran, Ci, Co, w_transposed, w_reverse);
   SCN_CHECK_LAUNCH();
   return 0;

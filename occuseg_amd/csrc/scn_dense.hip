@@ -98,15 +98,18 @@ __device__ __forceinline__ bool bn_sum_partials(const float *partial, int nblk, 
   return true;
 }
 
-// arithmetic of sparseconvnet/SCN/CPU/BatchNormalization.cpp:19-52 with the row sums finished in fp64
+// arithmetic of sparseconvnet/SCN/CPU/BatchNormalization.cpp:19-52 with the row sums finished in fp64.
+// The partial sums [nblk][2][Cp] may cover a SEGMENT of the planes only (col0 .. col0 + Cp): statistics handed over by
+// the kernel that produced those planes (scn_conv_forward's colstats), one finalize launch per segment.
 __global__ void __launch_bounds__(256)
-    k_bn_finalize(const float *partial, int nblk, int64_t N, int C, float *save_mean,
+    k_bn_finalize(const float *partial, int nblk, int64_t N, int Cp, int col0, int C, float *save_mean,
                   float *save_invstd, float *running_mean, float *running_var,
                   const float *weight, const float *bias, float eps, float momentum,
                   int train, float *wb) {
-  int c;
+  int cl;
   double s = 0, ss = 0;
-  if (!bn_sum_partials(partial, train ? nblk : 0, C, c, s, ss)) return;
+  if (!bn_sum_partials(partial, train ? nblk : 0, Cp, cl, s, ss)) return;
+  const int c = col0 + cl;
   float mean, invstd;
   if (train) {
     const double m = s / (double)N;
@@ -353,28 +356,43 @@ extern "C" {
 
 size_t scn_bn_temp_bytes(int C) { return ((size_t)BN_MAX_BLOCKS * 2 * C + 5 * (size_t)C) * 4 + 256; }
 
-int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invstd,
-                   float *running_mean, float *running_var, const float *weight,
-                   const float *bias, double eps, double momentum, int train, double leakiness,
-                   int64_t N, int C, void *temp, void *stream_) {
-  hipStream_t stream = as_stream(stream_);
+static int bn_forward_impl(const float *x, float *y, float *save_mean, float *save_invstd,
+                           float *running_mean, float *running_var, const float *weight,
+                           const float *bias, double eps, double momentum, int train, double leakiness,
+                           int64_t N, int C, void *temp, int nseg, const int32_t *seg_ncols,
+                           const float *const *seg_partial, const int32_t *seg_nblk, hipStream_t stream) {
   SCN_REQUIRE(C > 0 && N >= 0, "scn_bn_forward: bad shape");
   float *partial = (float *)temp;
   float *wb = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
-  const int nblk = bn_blocks(N);
   const bool v4 = (C % 4) == 0;
-  if (train) {
+  if (train && nseg > 0) {
+    // statistics handed over by the producing kernels: only the finalize runs, once per segment of planes
     SCN_REQUIRE(N > 0, "scn_bn_forward: training batch norm over zero active sites");
-    const int cg = v4 ? C / 4 : C;
-    dim3 grid(nblk, (cg + 255) / 256);
-    if (v4) k_bn_stats<4><<<grid, 256, 0, stream>>>(x, N, C, partial);
-    else k_bn_stats<1><<<grid, 256, 0, stream>>>(x, N, C, partial);
+    int col0 = 0;
+    for (int i = 0; i < nseg; ++i) {
+      SCN_REQUIRE(seg_ncols[i] > 0 && seg_nblk[i] > 0 && seg_partial[i] != nullptr, "scn_bn_forward_ext: bad segment");
+      k_bn_finalize<<<(seg_ncols[i] + 15) / 16, 256, 0, stream>>>(seg_partial[i], seg_nblk[i], N, seg_ncols[i], col0, C,
+                                                                  save_mean, save_invstd, running_mean, running_var,
+                                                                  weight, bias, (float)eps, (float)momentum, 1, wb);
+      SCN_CHECK_LAUNCH();
+      col0 += seg_ncols[i];
+    }
+    SCN_REQUIRE(col0 == C, "scn_bn_forward_ext: the segments must cover all planes");
+  } else {
+    const int nblk = bn_blocks(N);
+    if (train) {
+      SCN_REQUIRE(N > 0, "scn_bn_forward: training batch norm over zero active sites");
+      const int cg = v4 ? C / 4 : C;
+      dim3 grid(nblk, (cg + 255) / 256);
+      if (v4) k_bn_stats<4><<<grid, 256, 0, stream>>>(x, N, C, partial);
+      else k_bn_stats<1><<<grid, 256, 0, stream>>>(x, N, C, partial);
+      SCN_CHECK_LAUNCH();
+    }
+    k_bn_finalize<<<(C + 15) / 16, 256, 0, stream>>>(partial, nblk, N, C, 0, C, save_mean, save_invstd,
+                                                      running_mean, running_var, weight, bias,
+                                                      (float)eps, (float)momentum, train, wb);
     SCN_CHECK_LAUNCH();
   }
-  k_bn_finalize<<<(C + 15) / 16, 256, 0, stream>>>(partial, nblk, N, C, save_mean, save_invstd,
-                                                    running_mean, running_var, weight, bias,
-                                                    (float)eps, (float)momentum, train, wb);
-  SCN_CHECK_LAUNCH();
   if (N > 0) {
     const int64_t total = N * C;
     if (v4) k_bn_apply<4><<<grid_for(total / 4), 256, 0, stream>>>(x, y, total / 4, C, wb, (float)leakiness);
@@ -382,6 +400,24 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
     SCN_CHECK_LAUNCH();
   }
   return 0;
+}
+
+int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invstd,
+                   float *running_mean, float *running_var, const float *weight,
+                   const float *bias, double eps, double momentum, int train, double leakiness,
+                   int64_t N, int C, void *temp, void *stream_) {
+  return bn_forward_impl(x, y, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, train,
+                         leakiness, N, C, temp, 0, nullptr, nullptr, nullptr, as_stream(stream_));
+}
+
+int scn_bn_forward_ext(const float *x, float *y, float *save_mean, float *save_invstd,
+                       float *running_mean, float *running_var, const float *weight,
+                       const float *bias, double eps, double momentum, double leakiness,
+                       int64_t N, int C, void *temp, int nseg, const int32_t *seg_ncols_host,
+                       const float *const *seg_partial_host, const int32_t *seg_nblk_host, void *stream_) {
+  SCN_REQUIRE(nseg >= 1 && nseg <= 8, "scn_bn_forward_ext: 1..8 segments");
+  return bn_forward_impl(x, y, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, 1,
+                         leakiness, N, C, temp, nseg, seg_ncols_host, seg_partial_host, seg_nblk_host, as_stream(stream_));
 }
 
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,

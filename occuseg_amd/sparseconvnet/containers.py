@@ -71,7 +71,11 @@ class JoinTable(torch.nn.Sequential):
     """concatenate feature planes of a list of tensors living on the same sites"""
 
     def forward(self, input):
-        return _like(input[0], torch.cat([t.features for t in input], 1))
+        out = _like(input[0], torch.cat([t.features for t in input], 1))
+        stats = [t.get_colstats() for t in input]
+        if all(stats):  # the statistics of a concatenation are the concatenation of the statistics
+            out.set_colstats([seg for st in stats for seg in st])
+        return out
 
     def input_spatial_size(self, out_size):
         return out_size
@@ -79,6 +83,8 @@ class JoinTable(torch.nn.Sequential):
 
 class AddTable(torch.nn.Sequential):
     def forward(self, input):
+        if len(input) == 1:  # ResidualConcatTable already added the shortcut inside the last convolution
+            return input[0]
         total = input[0].features
         for t in input[1:]:
             total = total + t.features

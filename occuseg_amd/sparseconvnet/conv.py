@@ -30,25 +30,28 @@ def grad_owner(*params):
     return owner
 
 
+EMIT_COLSTATS = True  # A/B switch: convolutions hand their output's column statistics to the following batch norm
+
+
 class _RuleConvFunction(Function):
     """kind: 'submanifold' | 'conv' | 'deconv'"""
 
     @staticmethod
     def forward(ctx, features, weight, bias, kind, metadata, in_size, out_size, filter_size, filter_stride,
-                dilated_rate, residual=None):
+                dilated_rate, residual=None, stats_out=None):
         ctx.kind, ctx.scn_meta, ctx.dilated_rate = kind, metadata, dilated_rate
         ctx.sizes = (in_size, out_size, filter_size, filter_stride)
         out = like_empty(features)
         if kind == "submanifold":
             # residual: out = conv(features) + residual in one kernel (the shortcut of a residual block)
             macs = SCN.SubmanifoldConvolution_updateOutput(in_size, filter_size, metadata, features, out, weight,
-                                                           bias, dilated_rate, residual=residual)
+                                                           bias, dilated_rate, residual=residual, stats_out=stats_out)
         elif kind == "conv":
             macs = SCN.Convolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, features,
-                                                out, weight, bias)
+                                                out, weight, bias, stats_out=stats_out)
         else:
             macs = SCN.Deconvolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, features,
-                                                  out, weight, bias)
+                                                  out, weight, bias, stats_out=stats_out)
         counters.add(macs, out.nelement())
         ctx.save_for_backward(features, weight, bias)
         return out
@@ -83,7 +86,7 @@ class _RuleConvFunction(Function):
             grad_weight = None
         # d(out)/d(residual) = identity: the incoming gradient itself
         grad_residual = grad_output if ctx.needs_input_grad[10] else None
-        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7 + (grad_residual,)
+        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7 + (grad_residual, None)
 
 
 class _RuleConv(Module):
@@ -113,9 +116,14 @@ class _RuleConv(Module):
         assert residual is None or self.kind == "submanifold"
         out_size = self.output_spatial_size(input.spatial_size)
         output = SparseConvNetTensor(metadata=input.metadata, spatial_size=out_size)
+        # training: the kernel also emits the column statistics of its result (taken from the output tile while it is in
+        # LDS) for the batch norm that usually follows
+        sink = [] if (self.training and EMIT_COLSTATS) else None
         output.features = _RuleConvFunction.apply(
             input.features, self.weight, optionalTensor(self, "bias"), self.kind, input.metadata,
-            input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate, residual)
+            input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate, residual, sink)
+        if sink:
+            output.set_colstats([(self.nOut, sink[0])])
         return output
 
     def _fmt(self, t):

@@ -16,13 +16,13 @@ from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTen
 
 class _BatchNormFunction(Function):
     @staticmethod
-    def forward(ctx, features, weight, bias, running_mean, running_var, eps, momentum, train, leakiness):
+    def forward(ctx, features, weight, bias, running_mean, running_var, eps, momentum, train, leakiness, colstats=None):
         ctx.train, ctx.leakiness = train, leakiness
         out = like_empty(features)
         save_mean = like_empty(features)
         save_invstd = like_empty(features)
         SCN.BatchNormalization_updateOutput(features, out, save_mean, save_invstd, running_mean, running_var,
-                                            weight, bias, eps, momentum, train, leakiness)
+                                            weight, bias, eps, momentum, train, leakiness, _colstats=colstats)
         ctx.save_for_backward(features, out, weight, bias, running_mean, running_var, save_mean, save_invstd)
         return out
 
@@ -46,8 +46,8 @@ class _BatchNormFunction(Function):
         if direct:
             owner.grad_written(weight)
             owner.grad_written(bias)
-            return (grad_input, None, None) + (None,) * 6
-        return (grad_input, optionalTensorReturn(grad_weight), optionalTensorReturn(grad_bias)) + (None,) * 6
+            return (grad_input, None, None) + (None,) * 7
+        return (grad_input, optionalTensorReturn(grad_weight), optionalTensorReturn(grad_bias)) + (None,) * 7
 
 
 class BatchNormalization(Module):
@@ -65,9 +65,13 @@ class BatchNormalization(Module):
         assert input.features.nelement() == 0 or input.features.size(1) == self.nPlanes, \
             (self.nPlanes, input.features.shape)
         output = SparseConvNetTensor(metadata=input.metadata, spatial_size=input.spatial_size)
+        # statistics the producing convolution(s) emitted for exactly this tensor (training only): no second pass over it
+        ext = input.get_colstats() if self.training and hasattr(input, "get_colstats") else None
+        if ext and sum(n for n, _ in ext) != self.nPlanes:
+            ext = None
         output.features = _BatchNormFunction.apply(
             input.features, optionalTensor(self, "weight"), optionalTensor(self, "bias"), self.running_mean,
-            self.running_var, self.eps, self.momentum, self.training, self.leakiness)
+            self.running_var, self.eps, self.momentum, self.training, self.leakiness, ext)
         return output
 
     def input_spatial_size(self, out_size):

@@ -23,6 +23,19 @@ class SparseConvNetTensor(object):
         self.features = features
         self.metadata = metadata
         self.spatial_size = spatial_size
+        self._colstats = None  # (key of the features tensor, [(planes, partial column sums), ...]) -- see set_colstats
+
+    def set_colstats(self, segments):
+        """column statistics of ``features`` emitted by the kernel(s) that produced it (not in the reference): valid
+        only for exactly this features tensor in exactly this version"""
+        f = self.features
+        self._colstats = ((f.data_ptr(), f._version, tuple(f.shape)), list(segments)) if segments else None
+
+    def get_colstats(self):
+        if self._colstats is None or self.features is None:
+            return None
+        f = self.features
+        return self._colstats[1] if self._colstats[0] == (f.data_ptr(), f._version, tuple(f.shape)) else None
 
     def get_spatial_locations(self, spatial_size=None):
         """LongTensor [N,4]: coordinates and batch index of the active sites"""

@@ -317,3 +317,105 @@ def test_residual_block_fusion_equals_add_table(gpu):
     assert_close(o1.cpu().numpy(), o2.cpu().numpy(), "fused residual output", rel=1e-5)
     for a, b in zip(g1, g2):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), "fused residual grads", rel=1e-4)
+
+
+@pytest.mark.parametrize("case", ["tile4", "tile2", "split", "expand", "nw1"])
+def test_conv_column_statistics_for_batchnorm(gpu, case):
+    """scn_conv_forward's colstats: per block of output rows the column sums / sums of squares of the RESULT, taken from
+    the output tile while it is in LDS (or registers) -- every emitting kernel against a torch reduction of the output,
+    and the batch norm finalized from them against the ordinary two-pass batch norm."""
+    from occuseg_amd import SCN
+    from oracle import rules as R
+    big = case == "tile4"
+    m, size, grid, _, _ = _setup(gpu, seed=21, n=72000 if big else (900 if case == "split" else 9000), batch=2,
+                                 extent=60 if big else 26)
+    ci, co = {"tile4": (64, 64), "tile2": (64, 128), "split": (128, 128), "expand": (128, 64), "nw1": (32, 16)}[case]
+    rng = np.random.default_rng(3)
+    stats = []
+    out = torch.empty(0, device=gpu)
+    if case == "expand":  # deconvolution: coarse -> fine, one contribution per fine row
+        rbk = m.getRuleBook(size, size // 2, F2, F2)
+        n_coarse = m.getNActive(size // 2)
+        x = torch.randn(n_coarse, ci, device=gpu)
+        w = torch.randn(8, ci, co, device=gpu) * 0.1
+        b = torch.randn(co, device=gpu)
+        SCN.Deconvolution_updateOutput(size // 2, size, F2, F2, m, x, out, w, b, stats_out=stats)
+        assert rbk.unique_col == 0
+    else:
+        x = torch.randn(grid.n, ci, device=gpu)
+        w = torch.randn(27, ci, co, device=gpu) * 0.05
+        b = torch.randn(co, device=gpu)
+        res = torch.randn(grid.n, co, device=gpu)
+        SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x, out, w, b, 1, residual=res, stats_out=stats)
+    assert len(stats) == 1 and stats[0].shape[1:] == (2, co)
+    cs = stats[0].double().sum(0).cpu().numpy()
+    o64 = out.double()
+    assert_close(cs[0], o64.sum(0).cpu().numpy(), case + " column sums", rel=1e-5, scale=float(o64.abs().sum(0).max()))
+    assert_close(cs[1], (o64 * o64).sum(0).cpu().numpy(), case + " column sums of squares", rel=1e-5)
+    # batch norm from the handed-over statistics == batch norm with its own statistics pass
+    g, beta = torch.rand(co, device=gpu) + 0.5, torch.randn(co, device=gpu)
+    ys = []
+    for ext in (None, [(co, stats[0])]):
+        y, sm, si = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+        rm, rv = torch.zeros(co, device=gpu), torch.ones(co, device=gpu)
+        SCN.BatchNormalization_updateOutput(out, y, sm, si, rm, rv, g, beta, 1e-4, 0.9, True, 0.0, _colstats=ext)
+        ys.append((y, sm, si, rm, rv))
+    for a, bb, what in zip(ys[0], ys[1], ("y", "mean", "invstd", "running_mean", "running_var")):
+        assert_close(bb.cpu().numpy(), a.cpu().numpy(), "bn from colstats: " + what, rel=2e-5)
+    # two producers (a concatenation): segments in order
+    if case == "tile2":
+        cat = torch.cat([out, out], 1).contiguous()
+        y2 = torch.empty(0, device=gpu)
+        SCN.BatchNormalization_updateOutput(cat, y2, torch.empty(0, device=gpu), torch.empty(0, device=gpu),
+                                            torch.zeros(2 * co, device=gpu), torch.ones(2 * co, device=gpu),
+                                            torch.cat([g, g]), torch.cat([beta, beta]), 1e-4, 0.9, True, 0.0,
+                                            _colstats=[(co, stats[0]), (co, stats[0])])
+        assert torch.equal(y2[:, :co], ys[1][0]) and torch.equal(y2[:, co:], ys[1][0])
+
+
+def test_network_with_and_without_statistics_handover(gpu):
+    """the UNet with the convolutions handing their column statistics to the batch norms (default) against the same
+    network with every batch norm reading its input twice: same outputs / gradients to rounding, and both bitwise
+    reproducible"""
+    import occuseg_amd
+    from occuseg_amd import scenes
+    from occuseg_amd.sparseconvnet import conv as conv_mod
+    scn = occuseg_amd.install()
+    torch.manual_seed(4)
+    mm = 32
+    net = scn.Sequential().add(scn.InputLayer(3, 4096, mode=4)).add(scn.SubmanifoldConvolution(3, 3, mm, 3, False)).add(
+        scn.UNet(3, 1, [mm, 2 * mm, 3 * mm, 4 * mm], residual_blocks=True)).add(scn.BatchNormReLU(mm)).add(
+        scn.OutputLayer(3)).to(gpu)
+    coords, feats = scenes.batch([1000, 1001], target_sites=8000)
+    batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
+    bns = [mod for mod in net.modules() if isinstance(mod, scn.BatchNormalization)]
+    used = []
+    hooks = [b.register_forward_pre_hook(lambda mod, inp: used.append(inp[0].get_colstats() is not None)) for b in bns]
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        for b in bns:
+            b.running_mean.zero_()
+            b.running_var.fill_(1)
+        out = net(batch)
+        out.square().sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()]
+
+    o1, g1 = run()
+    n_ext = sum(used)
+    assert n_ext >= len(bns) - 1, (n_ext, len(bns))  # all but the stem's (generic kernel: no statistics)
+    o1b, _ = run()
+    assert torch.equal(o1, o1b)
+    try:
+        conv_mod.EMIT_COLSTATS = False
+        del used[:]
+        o2, g2 = run()
+        assert not any(used)
+    finally:
+        conv_mod.EMIT_COLSTATS = True
+        for h in hooks:
+            h.remove()
+    assert_close(o1.cpu().numpy(), o2.cpu().numpy(), "statistics hand-over: output", rel=2e-5)
+    for a, b in zip(g1, g2):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), "statistics hand-over: grads", rel=2e-4)
