@@ -591,14 +591,14 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   }
 }
 
-// the same reduction, row blocks of 64 rows per workgroup, with the column statistics of the result (colstats
-// [ceil(n_out / 64)][2][Co]): thread = (row slot, 4-plane column group)
+// the same reduction, row blocks of 16 rows per workgroup, with the column statistics of the result (colstats
+// [ceil(n_out / 16)][2][Co]): thread = (row slot, 4-plane column group)
 __global__ void __launch_bounds__(256)
     k_split_reduce_stats(const float *__restrict__ part, float *__restrict__ out, int64_t n_out, int Co, int ksplit,
                          float *__restrict__ colstats) {
   __shared__ float red[2][256 * 4];
   const int cg4 = Co / 4;
-  const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = min(n_out, r0 + 64);
+  const int64_t r0 = (int64_t)blockIdx.x * 16, r1 = min(n_out, r0 + 16);
   const int64_t slab = n_out * Co;
   for (int cb = 0; cb < cg4; cb += 256) {  // Co <= 1024: one trip
     const int ncg = min(256, cg4 - cb);
@@ -2039,7 +2039,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   SCN_CHECK_LAUNCH();
   if (ksplit > 1) {
     if (colstats != nullptr) {  // the reduction also yields the column statistics of the result
-      k_split_reduce_stats<<<(unsigned)((n_out + 63) / 64), 256, 0, stream>>>(part, out, n_out, Co, ksplit, colstats);
+      k_split_reduce_stats<<<(unsigned)((n_out + 15) / 16), 256, 0, stream>>>(part, out, n_out, Co, ksplit, colstats);
     } else {
       const int64_t total4 = n_out * Co / 4;
       int64_t g = (total4 + 255) / 256;
@@ -2093,7 +2093,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   SCN_CHECK_LAUNCH();
   if (ksplit > 1) {
     if (colstats != nullptr) {  // the reduction also yields the column statistics of the result
-      k_split_reduce_stats<<<(unsigned)((n_out + 63) / 64), 256, 0, stream>>>(part, out, n_out, Co, ksplit, colstats);
+      k_split_reduce_stats<<<(unsigned)((n_out + 15) / 16), 256, 0, stream>>>(part, out, n_out, Co, ksplit, colstats);
     } else {
       const int64_t total4 = n_out * Co / 4;
       int64_t g = (total4 + 255) / 256;
@@ -2158,7 +2158,7 @@ int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out
   const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
   if (p.kind == 5) return (n_out + 31) / 32 + K;
   if (p.kind != 2 && p.kind != 4) return 0;  // generic / fallback kernels do not emit statistics
-  if (p.ksplit > 1) return (n_out + 63) / 64;
+  if (p.ksplit > 1) return (n_out + 15) / 16;
   const int M = p.kind == 4 ? 128 : 32 * p.nw;
   return (n_out + M - 1) / M;
 }

@@ -356,6 +356,19 @@ extern "C" {
 
 size_t scn_bn_temp_bytes(int C) { return ((size_t)BN_MAX_BLOCKS * 2 * C + 5 * (size_t)C) * 4 + 256; }
 
+// [nblk][2][Cp] -> [NF][2][Cp]: fold f sums the partials f, f + NF, f + 2 NF, ... (fp64, fixed order).  A convolution over
+// 600k sites hands over one partial per 128-row tile (4,701 of them; 18,727 per-wave partials from k_conv_expand): the
+// 16-lane finalize would walk them serially on C/16 workgroups, which costs more than the statistics pass it replaces.
+constexpr int BN_FOLD = 64;
+__global__ void __launch_bounds__(256) k_bn_fold(const float *__restrict__ partial, int nblk, int Cp, float *__restrict__ out) {
+  const int f = blockIdx.y;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < 2 * Cp; c += gridDim.x * 256) {
+    double a = 0;
+    for (int b = f; b < nblk; b += BN_FOLD) a += (double)partial[(int64_t)b * 2 * Cp + c];
+    out[(int64_t)f * 2 * Cp + c] = (float)a;
+  }
+}
+
 static int bn_forward_impl(const float *x, float *y, float *save_mean, float *save_invstd,
                            float *running_mean, float *running_var, const float *weight,
                            const float *bias, double eps, double momentum, int train, double leakiness,
@@ -371,7 +384,16 @@ static int bn_forward_impl(const float *x, float *y, float *save_mean, float *sa
     int col0 = 0;
     for (int i = 0; i < nseg; ++i) {
       SCN_REQUIRE(seg_ncols[i] > 0 && seg_nblk[i] > 0 && seg_partial[i] != nullptr, "scn_bn_forward_ext: bad segment");
-      k_bn_finalize<<<(seg_ncols[i] + 15) / 16, 256, 0, stream>>>(seg_partial[i], seg_nblk[i], N, seg_ncols[i], col0, C,
+      const float *pp = seg_partial[i];
+      int pn = seg_nblk[i];
+      if (pn > 4 * BN_FOLD) {  // many partials: fold them 64-fold first (the workspace's partial area is free here)
+        float *folded = partial + (size_t)2 * BN_FOLD * col0;
+        k_bn_fold<<<dim3((2 * seg_ncols[i] + 255) / 256, BN_FOLD), 256, 0, stream>>>(pp, pn, seg_ncols[i], folded);
+        SCN_CHECK_LAUNCH();
+        pp = folded;
+        pn = BN_FOLD;
+      }
+      k_bn_finalize<<<(seg_ncols[i] + 15) / 16, 256, 0, stream>>>(pp, pn, N, seg_ncols[i], col0, C,
                                                                   save_mean, save_invstd, running_mean, running_var,
                                                                   weight, bias, (float)eps, (float)momentum, 1, wb);
       SCN_CHECK_LAUNCH();

@@ -31,6 +31,11 @@ def step():
 def apply(name, val):
     if name.startswith("tune"):
         _lib.use_tuning_build().scn_set_tuning(int(name[4:]), int(val))
+    elif "." in name:  # e.g. conv.EMIT_COLSTATS=1,0 : a switch of occuseg_amd.sparseconvnet.<module>
+        import importlib
+        mod, attr = name.split(".")
+        m = importlib.import_module("occuseg_amd.sparseconvnet." + mod)
+        setattr(m, attr, type(getattr(m, attr))(int(val)))
     else:
         setattr(SCN, name, type(getattr(SCN, name))(int(val)))
 
