@@ -591,49 +591,6 @@ __global__ void __launch_bounds__(64 * NW * NWM)
   }
 }
 
-// the same reduction, row blocks of 16 rows per workgroup, with the column statistics of the result (colstats
-// [ceil(n_out / 16)][2][Co]): thread = (row slot, 4-plane column group)
-__global__ void __launch_bounds__(256)
-    k_split_reduce_stats(const float *__restrict__ part, float *__restrict__ out, int64_t n_out, int Co, int ksplit,
-                         float *__restrict__ colstats) {
-  __shared__ float red[2][256 * 4];
-  const int cg4 = Co / 4;
-  const int64_t r0 = (int64_t)blockIdx.x * 16, r1 = min(n_out, r0 + 16);
-  const int64_t slab = n_out * Co;
-  for (int cb = 0; cb < cg4; cb += 256) {  // Co <= 1024: one trip
-    const int ncg = min(256, cg4 - cb);
-    const int nslot = 256 / ncg;
-    const int cg = cb + (int)threadIdx.x % ncg, slot = (int)threadIdx.x / ncg;
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), css = cs;
-    if (slot < nslot)
-      for (int64_t r = r0 + slot; r < r1; r += nslot) {
-        const int64_t i = r * Co + cg * 4;
-        float4 a = *(const float4 *)(part + i);
-        for (int j = 1; j < ksplit; ++j) {
-          const float4 b = *(const float4 *)(part + (int64_t)j * slab + i);
-          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-        *(float4 *)(out + i) = a;
-        cs.x += a.x; cs.y += a.y; cs.z += a.z; cs.w += a.w;
-        css.x += a.x * a.x; css.y += a.y * a.y; css.z += a.z * a.z; css.w += a.w * a.w;
-      }
-    __syncthreads();
-    *(float4 *)(red[0] + threadIdx.x * 4) = cs;
-    *(float4 *)(red[1] + threadIdx.x * 4) = css;
-    __syncthreads();
-    if (slot == 0) {
-      for (int j = 1; j < nslot; ++j) {
-        const float4 a = *(const float4 *)(red[0] + (j * ncg + (int)threadIdx.x) * 4);
-        const float4 b = *(const float4 *)(red[1] + (j * ncg + (int)threadIdx.x) * 4);
-        cs.x += a.x; cs.y += a.y; cs.z += a.z; cs.w += a.w;
-        css.x += b.x; css.y += b.y; css.z += b.z; css.w += b.w;
-      }
-      *(float4 *)(colstats + ((int64_t)blockIdx.x * 2 + 0) * Co + cg * 4) = cs;
-      *(float4 *)(colstats + ((int64_t)blockIdx.x * 2 + 1) * Co + cg * 4) = css;
-    }
-  }
-}
-
 // out[i] = part[0][i] + part[1][i] + ... + part[ksplit-1][i], always in this order
 __global__ void __launch_bounds__(256)
     k_split_reduce(const float *__restrict__ part, float *__restrict__ out, int64_t total4, int ksplit) {
@@ -1443,7 +1400,14 @@ __global__ void __launch_bounds__(64)
     if (blk < nb) break;
     blk -= nb;
   }
-  if (k >= K) return;
+  if (k >= K) {  // past the end of the lists: nothing to compute, but this block's statistics slot must read zero
+    if (colstats != nullptr) {
+      const int64_t pb = blockIdx.x / ncb;
+      colstats[(pb * 2 + 0) * Co + co0 + lane] = 0.f;
+      colstats[(pb * 2 + 1) * Co + co0 + lane] = 0.f;
+    }
+    return;
+  }
   const int p0 = blk * PB;
   const int2 *rk = rules + (int64_t)k * stride;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
@@ -1516,8 +1480,8 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
       for (int q = 0; q < COS; ++q) acc[g][q] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
-  // column statistics of the wave's 32 output rows (colstats [pair blocks][2][Co], zeroed by the launcher: blocks past the
-  // end of the lists write nothing): sum over the 16 pairs of a group = butterfly over the 16 lanes that share lq
+  // column statistics of the wave's 32 output rows (colstats [pair blocks][2][Co]; blocks past the end of the lists
+  // wrote zeros above): sum over the 16 pairs of a group = butterfly over the 16 lanes that share lq
   if (colstats != nullptr) {
     const int64_t pb = blockIdx.x / ncb;
 #pragma unroll
@@ -2038,14 +2002,10 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
 #undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();
   if (ksplit > 1) {
-    if (colstats != nullptr) {  // the reduction also yields the column statistics of the result
-      k_split_reduce_stats<<<(unsigned)((n_out + 15) / 16), 256, 0, stream>>>(part, out, n_out, Co, ksplit, colstats);
-    } else {
-      const int64_t total4 = n_out * Co / 4;
-      int64_t g = (total4 + 255) / 256;
-      if (g > 2048) g = 2048;
-      k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
-    }
+    const int64_t total4 = n_out * Co / 4;
+    int64_t g = (total4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
     SCN_CHECK_LAUNCH();
   }
   return 0;
@@ -2092,14 +2052,10 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 #undef SCN_LAUNCH_TILE4
   SCN_CHECK_LAUNCH();
   if (ksplit > 1) {
-    if (colstats != nullptr) {  // the reduction also yields the column statistics of the result
-      k_split_reduce_stats<<<(unsigned)((n_out + 15) / 16), 256, 0, stream>>>(part, out, n_out, Co, ksplit, colstats);
-    } else {
-      const int64_t total4 = n_out * Co / 4;
-      int64_t g = (total4 + 255) / 256;
-      if (g > 2048) g = 2048;
-      k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
-    }
+    const int64_t total4 = n_out * Co / 4;
+    int64_t g = (total4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    k_split_reduce<<<(unsigned)g, 256, 0, stream>>>(part, out, total4, ksplit);
     SCN_CHECK_LAUNCH();
   }
   return 0;
@@ -2158,7 +2114,8 @@ int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out
   const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
   if (p.kind == 5) return (n_out + 31) / 32 + K;
   if (p.kind != 2 && p.kind != 4) return 0;  // generic / fallback kernels do not emit statistics
-  if (p.ksplit > 1) return (n_out + 15) / 16;
+  if (p.ksplit > 1) return 0;  // coarse levels: the batch norm's own statistics pass over a few thousand rows is cheaper
+                               // than a reduction kernel that also reduces columns (A/B: +0.2 ms per step)
   const int M = p.kind == 4 ? 128 : 32 * p.nw;
   return (n_out + M - 1) / M;
 }
@@ -2222,7 +2179,6 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
       const int ncb = Co / 64;
       const int64_t nblk = (n_out + 31) / 32 + K;  // every output row in exactly one pair: sum_k ceil(count_k / 32) <= this
       const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
-      if (colstats != nullptr) SCN_CHECK_HIP(hipMemsetAsync(colstats, 0, (size_t)nblk * 2 * Co * sizeof(float), stream));
       k_conv_expand<<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, stride,
                                                              in_col, Ci, Co, ncb, in_bytes, wp_bytes);
       SCN_CHECK_LAUNCH();

@@ -347,6 +347,9 @@ def test_conv_column_statistics_for_batchnorm(gpu, case):
         b = torch.randn(co, device=gpu)
         res = torch.randn(grid.n, co, device=gpu)
         SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x, out, w, b, 1, residual=res, stats_out=stats)
+    if case == "split":  # launches that split their offsets (coarse levels) emit none: the batch norm reads its input itself
+        assert stats == [] and SCN._lib_().scn_conv_workspace_bytes(27, grid.n, grid.n, grid.n, ci, co, 0) > 0
+        return
     assert len(stats) == 1 and stats[0].shape[1:] == (2, co)
     cs = stats[0].double().sum(0).cpu().numpy()
     o64 = out.double()
@@ -404,7 +407,7 @@ def test_network_with_and_without_statistics_handover(gpu):
 
     o1, g1 = run()
     n_ext = sum(used)
-    assert n_ext >= len(bns) - 1, (n_ext, len(bns))  # all but the stem's (generic kernel: no statistics)
+    assert n_ext >= len(bns) // 2, (n_ext, len(bns))  # all but the stem's (generic kernel) and the coarse, split levels
     o1b, _ = run()
     assert torch.equal(o1, o1b)
     try:
