@@ -319,17 +319,17 @@ def test_residual_block_fusion_equals_add_table(gpu):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), "fused residual grads", rel=1e-4)
 
 
-@pytest.mark.parametrize("case", ["tile4", "tile2", "split", "expand", "nw1"])
+@pytest.mark.parametrize("case", ["tile4", "tile2", "split", "expand"])
 def test_conv_column_statistics_for_batchnorm(gpu, case):
     """scn_conv_forward's colstats: per block of output rows the column sums / sums of squares of the RESULT, taken from
     the output tile while it is in LDS (or registers) -- every emitting kernel against a torch reduction of the output,
     and the batch norm finalized from them against the ordinary two-pass batch norm."""
     from occuseg_amd import SCN
     from oracle import rules as R
-    big = case == "tile4"
+    big = case in ("tile4", "tile2")  # >= 512 output tiles: no offset split (tile2: C_i = 32 is not tile4's)
     m, size, grid, _, _ = _setup(gpu, seed=21, n=72000 if big else (900 if case == "split" else 9000), batch=2,
                                  extent=60 if big else 26)
-    ci, co = {"tile4": (64, 64), "tile2": (64, 128), "split": (128, 128), "expand": (128, 64), "nw1": (32, 16)}[case]
+    ci, co = {"tile4": (64, 64), "tile2": (32, 64), "split": (128, 128), "expand": (128, 64)}[case]
     rng = np.random.default_rng(3)
     stats = []
     out = torch.empty(0, device=gpu)
@@ -385,11 +385,11 @@ def test_network_with_and_without_statistics_handover(gpu):
     from occuseg_amd.sparseconvnet import conv as conv_mod
     scn = occuseg_amd.install()
     torch.manual_seed(4)
-    mm = 32
+    mm = 64
     net = scn.Sequential().add(scn.InputLayer(3, 4096, mode=4)).add(scn.SubmanifoldConvolution(3, 3, mm, 3, False)).add(
-        scn.UNet(3, 1, [mm, 2 * mm, 3 * mm, 4 * mm], residual_blocks=True)).add(scn.BatchNormReLU(mm)).add(
+        scn.UNet(3, 1, [mm, 2 * mm], residual_blocks=True)).add(scn.BatchNormReLU(mm)).add(
         scn.OutputLayer(3)).to(gpu)
-    coords, feats = scenes.batch([1000, 1001], target_sites=8000)
+    coords, feats = scenes.batch([1000, 1001], target_sites=40000)  # level 0: >= 512 tiles (no split), level 1: split
     batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
     bns = [mod for mod in net.modules() if isinstance(mod, scn.BatchNormalization)]
     used = []
@@ -407,7 +407,9 @@ def test_network_with_and_without_statistics_handover(gpu):
 
     o1, g1 = run()
     n_ext = sum(used)
-    assert n_ext >= len(bns) // 2, (n_ext, len(bns))  # all but the stem's (generic kernel) and the coarse, split levels
+    # level 0: every batch norm but the first (the stem runs on the generic kernel) takes the statistics of its producer(s),
+    # the concatenation [encoder features | deconvolution] from two of them; the split launches of level 1 emit none
+    assert 4 <= n_ext < len(bns), (n_ext, len(bns))
     o1b, _ = run()
     assert torch.equal(o1, o1b)
     try:
