@@ -387,8 +387,8 @@ def test_network_with_and_without_statistics_handover(gpu):
     torch.manual_seed(4)
     mm = 64
     net = scn.Sequential().add(scn.InputLayer(3, 4096, mode=4)).add(scn.SubmanifoldConvolution(3, 3, mm, 3, False)).add(
-        scn.UNet(3, 1, [mm, 2 * mm], residual_blocks=True)).add(scn.BatchNormReLU(mm)).add(
-        scn.OutputLayer(3)).to(gpu)
+        scn.UNet(3, 1, [mm, 2 * mm], residual_blocks=True, leakiness=1)).add(scn.BatchNormalization(mm)).add(
+        scn.OutputLayer(3)).to(gpu)  # leakiness 1: no activation mask that a last-bit difference of a statistic could flip
     coords, feats = scenes.batch([1000, 1001], target_sites=40000)  # level 0: >= 512 tiles (no split), level 1: split
     batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
     bns = [mod for mod in net.modules() if isinstance(mod, scn.BatchNormalization)]
