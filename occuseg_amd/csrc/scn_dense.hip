@@ -255,6 +255,144 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ------------------------------------------------ batch norm, few rows ---
+// The coarse UNet levels (a few hundred to a few thousand sites) spent their batch norms in launch overhead: three
+// launches per pass, each a few microseconds for a tensor that fits in L2.  One launch per pass here: a workgroup owns
+// 16 planes (4 column groups of 4) x all rows -- 64 row slots -- reduces them (per-thread fp32, fp64 across the 64
+// slots), finalizes (same arithmetic as k_bn_finalize / k_bn_bwd_finalize), and applies with the rows coming back from L2.
+constexpr int64_t BN_SMALL_ROWS = 16384;
+
+__device__ __forceinline__ void bn_small_reduce(float4 a, float4 b, double (&s0)[4], double (&s1)[4], bool &owner) {
+  __shared__ float red[2][64][16];
+  const int cgl = threadIdx.x & 3, slot = threadIdx.x >> 2;
+  *(float4 *)&red[0][slot][cgl * 4] = a;
+  *(float4 *)&red[1][slot][cgl * 4] = b;
+  __syncthreads();
+  owner = slot == 0;
+  if (owner) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s0[e] = 0; s1[e] = 0; }
+    for (int j = 0; j < 64; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0[e] += (double)red[0][j][cgl * 4 + e];
+        s1[e] += (double)red[1][j][cgl * 4 + e];
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_bn_small_fwd(const float *__restrict__ x, float *__restrict__ y, int64_t N, int C, float *save_mean,
+                   float *save_invstd, float *running_mean, float *running_var, const float *weight,
+                   const float *bias, float eps, float momentum, float leak) {
+  __shared__ float wb[2][16];
+  const int cgl = threadIdx.x & 3, slot = threadIdx.x >> 2;
+  const int c0 = blockIdx.x * 16 + cgl * 4;
+  const bool live = c0 < C;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (live)
+    for (int64_t r = slot; r < N; r += 64) {
+      const float4 v = *(const float4 *)(x + r * C + c0);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      b.x += v.x * v.x; b.y += v.y * v.y; b.z += v.z * v.z; b.w += v.w * v.w;
+    }
+  double s[4], ss[4];
+  bool owner;
+  bn_small_reduce(a, b, s, ss, owner);
+  if (owner && live) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      const double m = s[e] / (double)N;
+      const double var_n = ss[e] - m * m * (double)N;
+      const float mean = (float)m;
+      running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * mean;
+      running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)(var_n / (double)(N - 1));
+      const float invstd = (float)(1.0 / sqrt(var_n / (double)N + (double)eps));
+      save_mean[c] = mean;
+      save_invstd[c] = invstd;
+      const float w = invstd * (weight ? weight[c] : 1.f);
+      wb[0][cgl * 4 + e] = w;
+      wb[1][cgl * 4 + e] = fmaf(-mean, w, bias ? bias[c] : 0.f);
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const float4 w = *(const float4 *)&wb[0][cgl * 4], bb = *(const float4 *)&wb[1][cgl * 4];
+  for (int64_t r = slot; r < N; r += 64) {
+    const float4 v = *(const float4 *)(x + r * C + c0);
+    float4 o;
+    o.x = fmaf(v.x, w.x, bb.x); o.y = fmaf(v.y, w.y, bb.y); o.z = fmaf(v.z, w.z, bb.z); o.w = fmaf(v.w, w.w, bb.w);
+    o.x = o.x > 0 ? o.x : o.x * leak; o.y = o.y > 0 ? o.y : o.y * leak;
+    o.z = o.z > 0 ? o.z : o.z * leak; o.w = o.w > 0 ? o.w : o.w * leak;
+    *(float4 *)(y + r * C + c0) = o;
+  }
+}
+
+// backward, mask recomputed from x (SCN_BN_MASK_FROM_X): d_out is read twice and never written
+__global__ void __launch_bounds__(256)
+    k_bn_small_bwd(const float *__restrict__ x, const float *__restrict__ d_out, float *__restrict__ d_x, int64_t N, int C,
+                   const float *save_mean, const float *save_invstd, const float *weight, const float *bias,
+                   float *d_weight, float *d_bias, float leak, int accumulate) {
+  __shared__ float coef[3][16];
+  const int cgl = threadIdx.x & 3, slot = threadIdx.x >> 2;
+  const int c0 = blockIdx.x * 16 + cgl * 4;
+  const bool live = c0 < C;
+  float m[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      m[e] = save_mean[c0 + e];
+      w[e] = save_invstd[c0 + e] * (weight ? weight[c0 + e] : 1.f);
+      bb[e] = fmaf(-m[e], w[e], bias ? bias[c0 + e] : 0.f);
+    }
+  }
+  auto masked = [&](const float4 &xv, float4 d) {
+    if (leak != 1.f) {
+      d.x *= fmaf(xv.x, w[0], bb[0]) > 0 ? 1.f : leak; d.y *= fmaf(xv.y, w[1], bb[1]) > 0 ? 1.f : leak;
+      d.z *= fmaf(xv.z, w[2], bb[2]) > 0 ? 1.f : leak; d.w *= fmaf(xv.w, w[3], bb[3]) > 0 ? 1.f : leak;
+    }
+    return d;
+  };
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (live)
+    for (int64_t r = slot; r < N; r += 64) {
+      const float4 xv = *(const float4 *)(x + r * C + c0);
+      const float4 d = masked(xv, *(const float4 *)(d_out + r * C + c0));
+      a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+      b.x += (xv.x - m[0]) * d.x; b.y += (xv.y - m[1]) * d.y; b.z += (xv.z - m[2]) * d.z; b.w += (xv.w - m[3]) * d.w;
+    }
+  double s[4], dp[4];
+  bool owner;
+  bn_small_reduce(a, b, s, dp, owner);
+  if (owner && live) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      const float invstd = save_invstd[c];
+      if (d_bias) d_bias[c] = (accumulate ? d_bias[c] : 0.f) + (float)s[e];
+      if (d_weight) d_weight[c] = (accumulate ? d_weight[c] : 0.f) + (float)(dp[e] * (double)invstd);
+      coef[0][cgl * 4 + e] = (float)(s[e] / (double)N);
+      coef[1][cgl * 4 + e] = (float)(dp[e] * (double)invstd * (double)invstd / (double)N);
+      coef[2][cgl * 4 + e] = invstd * (weight ? weight[c] : 1.f);
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const float4 gm = *(const float4 *)&coef[0][cgl * 4], kk = *(const float4 *)&coef[1][cgl * 4],
+               sc = *(const float4 *)&coef[2][cgl * 4];
+  for (int64_t r = slot; r < N; r += 64) {
+    const float4 xv = *(const float4 *)(x + r * C + c0);
+    const float4 d = masked(xv, *(const float4 *)(d_out + r * C + c0));
+    float4 o;
+    o.x = (d.x - gm.x - (xv.x - m[0]) * kk.x) * sc.x;
+    o.y = (d.y - gm.y - (xv.y - m[1]) * kk.y) * sc.y;
+    o.z = (d.z - gm.z - (xv.z - m[2]) * kk.z) * sc.z;
+    o.w = (d.w - gm.w - (xv.w - m[3]) * kk.w) * sc.w;
+    *(float4 *)(d_x + r * C + c0) = o;
+  }
+}
+
 // ------------------------------------------------------ input / output ---
 // out[s] = sum_j mult * in[order[q0+j]]  (sparseconvnet/SCN/CUDA/IOLayers.cu:17-31)
 __global__ void k_input_fwd(const float *feats, float *out, const int32_t *order,
@@ -400,6 +538,12 @@ static int bn_forward_impl(const float *x, float *y, float *save_mean, float *sa
       col0 += seg_ncols[i];
     }
     SCN_REQUIRE(col0 == C, "scn_bn_forward_ext: the segments must cover all planes");
+  } else if (train && v4 && N > 1 && N <= BN_SMALL_ROWS) {
+    // few rows (coarse UNet levels): statistics, finalize and apply in ONE launch
+    k_bn_small_fwd<<<(C + 15) / 16, 256, 0, stream>>>(x, y, N, C, save_mean, save_invstd, running_mean, running_var,
+                                                      weight, bias, (float)eps, (float)momentum, (float)leakiness);
+    SCN_CHECK_LAUNCH();
+    return 0;
   } else {
     const int nblk = bn_blocks(N);
     if (train) {
@@ -458,6 +602,12 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
   const int cg = v4 ? C / 4 : C;
   dim3 grid(nblk, (cg + 255) / 256);
   const float leak = (float)leakiness;
+  if (from_x && v4 && N <= BN_SMALL_ROWS) {  // few rows: one launch (see k_bn_small_bwd)
+    k_bn_small_bwd<<<(C + 15) / 16, 256, 0, stream>>>(x, d_out, d_x, N, C, save_mean, save_invstd, weight, bias, d_weight,
+                                                      d_bias, leak, accumulate);
+    SCN_CHECK_LAUNCH();
+    return 0;
+  }
   float *d_masked = rewrite_d_out ? d_out : d_x;  // pass 2 reads element i of it before writing element i of d_x
   if (from_x) {
     if (v4) k_bn_bwd_stats<4, true><<<grid, 256, 0, stream>>>(x, y, d_out, nullptr, save_mean, save_invstd, weight, bias, N, C, leak, partial);

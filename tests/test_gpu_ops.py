@@ -143,6 +143,18 @@ def test_batchnorm(gpu, n, c, leak):
                                             gg2, gb2, leak, _rewrite_d_output=False)
             assert torch.equal(gi2, gi) and torch.equal(gg2, gg) and torch.equal(gb2, gb)
             assert np.array_equal(dyt2.cpu().numpy(), dy)
+            # ... and with the mask recomputed from x instead of read from y (SCN_BN_MASK_FROM_X; up to 16384 rows this
+            # is the single-launch kernel): y is not even passed, d_output_features untouched, accumulate variant too
+            dyt3, gi3 = _t(dy, gpu), torch.empty(0, device=gpu)
+            gg3, gb3 = torch.ones(c, device=gpu), torch.ones(c, device=gpu)
+            SCN.BatchNormalization_backward(_t(x, gpu), gi3, torch.empty(0, device=gpu), dyt3, sm, si, rmt, rvt,
+                                            _t(g, gpu), _t(b, gpu), gg3, gb3, leak, _mask_from_x=True, _accumulate=True)
+            assert_close(gi3.cpu().numpy(), d_in, "bn dInput (mask from x)", scale=max(term, float(np.abs(d_in).max())))
+            assert_close(gg3.cpu().numpy() - 1, d_g, "bn dWeight (mask from x, accumulated)",
+                         scale=max(1.0, float(np.abs(d_g).max())))
+            assert_close(gb3.cpu().numpy() - 1, d_b, "bn dBias (mask from x, accumulated)",
+                         scale=max(1.0, float(np.abs(d_b).max())))
+            assert np.array_equal(dyt3.cpu().numpy(), dy)
 
 
 def test_batchnorm_no_affine(gpu):
