@@ -260,7 +260,8 @@ __global__ void __launch_bounds__(256)
 // launches per pass, each a few microseconds for a tensor that fits in L2.  One launch per pass here: a workgroup owns
 // 16 planes (4 column groups of 4) x all rows -- 64 row slots -- reduces them (per-thread fp32, fp64 across the 64
 // slots), finalizes (same arithmetic as k_bn_finalize / k_bn_bwd_finalize), and applies with the rows coming back from L2.
-constexpr int64_t BN_SMALL_ROWS = 16384;
+constexpr int64_t BN_SMALL_ROWS = 2048;  // measured: at 7k rows x 256 planes the 16 workgroups of this kernel stream slower than
+                                         // the three full-chip launches (bn 6.0 against 5.0 ms per step with the limit at 16384)
 
 __device__ __forceinline__ void bn_small_reduce(float4 a, float4 b, double (&s0)[4], double (&s1)[4], bool &owner) {
   __shared__ float red[2][64][16];

@@ -143,7 +143,7 @@ def test_batchnorm(gpu, n, c, leak):
                                             gg2, gb2, leak, _rewrite_d_output=False)
             assert torch.equal(gi2, gi) and torch.equal(gg2, gg) and torch.equal(gb2, gb)
             assert np.array_equal(dyt2.cpu().numpy(), dy)
-            # ... and with the mask recomputed from x instead of read from y (SCN_BN_MASK_FROM_X; up to 16384 rows this
+            # ... and with the mask recomputed from x instead of read from y (SCN_BN_MASK_FROM_X; up to 2048 rows this
             # is the single-launch kernel): y is not even passed, d_output_features untouched, accumulate variant too
             dyt3, gi3 = _t(dy, gpu), torch.empty(0, device=gpu)
             gg3, gb3 = torch.ones(c, device=gpu), torch.ones(c, device=gpu)
