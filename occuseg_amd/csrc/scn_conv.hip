@@ -985,6 +985,336 @@ __global__ void __launch_bounds__(128)
   }
 }
 
+// ------------------------ forward, barrier-free, THREE waves per SIMD (v6) ---
+// k_conv_tile4's division of labour (two waves per tile, 32 planes each, rows gathered straight into MFMA fragment
+// registers, output tile in LDS, pass table) on a register and LDS diet, because occupancy is what the kernel responds to:
+// with unused LDS added to k_conv_tile4 launches, 2 / 3 / 4 workgroups per CU run the L0-L1 layers at 58 / 78 / 94
+// TFLOP/s (tools/bench_conv.py --extra-lds).  k_conv_tile4 cannot go further: 248 registers (two waves per SIMD) and a
+// 39 KB tile (four per CU).  Here:
+//   * ONE row register set, reloaded in place: the 16-byte piece R[g][sp] of pass p is consumed by eight consecutive
+//     MFMAs and requested again for pass p+1 right after them (a full pass of latency budget for every piece); the pair
+//     indices are converted at the top of the pass and their registers reloaded at once.  No rotating sets, hence no
+//     unrolling and no register copies at the back edge.
+//   * the result of a group goes to the output tile while the OTHER group's MFMAs run (group 0 during group 1 of the
+//     same pass, group 1 during group 0 of the next): no copy of the accumulators, one 8-register read buffer.
+//   * M = 96 rows: 26 KB of tile + 3 KB of pass table = five workgroups per CU (M = 128: four, as before).
+// vmcnt is an in-order FIFO: at the top of a pass everything but the 8 row loads of the previous pass has landed
+// (indices of pass p+1, weights of pass p); inside the pass each row piece is awaited with the number of loads issued
+// after it -- 9 (7 younger pieces + 2 index loads), or 17 in a pass that also requests the next phase's weights, which
+// is why the pass body exists in two versions.  tools/check_asm_loads.py walks both through every branch.
+template <int M, int DBG = 0>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))
+    k_conv_tile6(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
+                 const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
+                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
+                 unsigned in_bytes, unsigned wp_bytes, int ksplit) {
+  constexpr int COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
+  constexpr int TMAX = KMAX * (M / 32) * SCN_TILE4_MAX_CHUNKS + 8;  // passes per tile: <= M / 32 per (offset, chunk); + sentinels
+  __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
+  __shared__ __attribute__((aligned(8))) unsigned ptab[TMAX][2];  // as in k_conv_tile4
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ru_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)rules, 0, (int)(K * stride * 8), 0x00020000);
+
+  int lin;
+  {  // workgroup -> tile: chunks of consecutive tiles per XCD, dealt round robin (see k_conv_tile4)
+    const int total = ntiles * ncb;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int CH = 64 * ncb;
+    const int full = (total / (8 * CH)) * (8 * CH);
+    if (bid < full) {
+      lin = ((j / CH) * 8 + xcd) * CH + j % CH;
+    } else {
+      const int rest = total - full, b2 = bid - full, x2 = b2 & 7, j2 = b2 >> 3;
+      const int q = rest >> 3, r = rest & 7;
+      lin = full + (x2 < r ? x2 * (q + 1) : r * (q + 1) + (x2 - r) * q) + j2;
+    }
+  }
+  const int tile = lin / ncb;
+  const int co0 = (lin % ncb) * COB;
+  const int64_t o0 = (int64_t)tile * M;
+  const int g0 = tile * (M / SCN_TILE_GRANULE);
+  const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
+  const int nch = Ci / CK;
+
+  for (int i = lane; i < (M + 1) * 8; i += 64) {  // each wave initialises ITS 32 planes of the output tile
+    const int r = i >> 3, c4 = (i & 7) * 4;
+    floatx4 v = {0.f, 0.f, 0.f, 0.f};
+    if (bias && blockIdx.y == 0) v = *(const floatx4 *)(bias + co0 + 32 * w + c4);
+    if (residual && blockIdx.y == 0 && r < M && o0 + r < n_out) v += *(const floatx4 *)(residual + (o0 + r) * Co + co0 + 32 * w + c4);
+    *(floatx4 *)(o_tile + r * OS + 32 * w + c4) = v;
+  }
+  if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
+    int s = 0, c = 0;
+    if (tid < K && tid % ksplit == (int)blockIdx.y) {
+      s = bases[(int64_t)tid * (n_gran + 1) + g0];
+      c = bases[(int64_t)tid * (n_gran + 1) + g1] - s;
+    }
+    const int npl = (c + 31) >> 5;
+    int pos = npl * nch;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(pos, o);
+      if (lane >= o) pos += y;
+    }
+    const int total = __shfl(pos, 63);
+    pos -= npl * nch;
+    const unsigned first = (unsigned)(((int64_t)tid * stride + s) * 8);
+    for (int chn = 0; chn < nch; ++chn)
+      for (int j = 0; j < npl; ++j) {
+        ptab[pos][0] = first + (unsigned)j * 256u;
+        ptab[pos][1] = (unsigned)(c - 32 * j) | (unsigned)chn << 8 | (unsigned)tid << 12 | (j == 0 ? 1u << 20 : 0u);
+        ++pos;
+      }
+    if (tid < 8) {
+      ptab[total + tid][0] = 0u;
+      ptab[total + tid][1] = 0u;
+    }
+  }
+  __syncthreads();  // the only barrier
+  auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+  struct Ent { unsigned base, meta; };  // meta & 255: pairs left (0: no such pass)
+  auto entry = [&](int p) __attribute__((always_inline)) {
+    const uint2 v = *(const uint2 *)ptab[p];
+    return Ent{(unsigned)uni((int)v.x), (unsigned)uni((int)v.y)};
+  };
+  auto rem = [](const Ent &e) __attribute__((always_inline)) { return (int)(e.meta & 255u); };
+  auto index_offsets = [&](const Ent &e, unsigned (&vo)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vo[i] = (16 * i < rem(e)) ? (unsigned)min(16 * i + li, rem(e) - 1) * 8u : 0u;
+  };
+  auto addr = [&](const Ent &e, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned src = in_col ? pr[i].y : pr[i].x;
+      const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
+      off[i] = (16 * i < rem(e)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : 0u;
+      orow[i] = (16 * i + li < rem(e)) ? dst * OS : M * OS;
+    }
+  };
+  auto load_idx = [&](const Ent &e, const unsigned (&vo)[2], u32x2 (&pr)[2]) __attribute__((always_inline)) {
+    const int base = (int)e.base;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(pr[i]) : "v"(vo[i]), "s"(ru_rsrc), "s"(base) : "memory");
+  };
+  auto load_piece = [&](floatx4 &dst, int sp, unsigned voff, int so) __attribute__((always_inline)) {
+    if (sp == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    else if (sp == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    else if (sp == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+  };
+  auto load_weights = [&](int sp, unsigned voff, int so, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wr[0][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "+v"(wr[1][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
+  };
+  auto weight_offsets = [&](const Ent &e, int (&so)[NS16]) __attribute__((always_inline)) {
+    const int k = (int)(e.meta >> 12) & 255, chn = (int)(e.meta >> 8) & 15;
+    const int blk = (k * (Ci / 16) + chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS;
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp) so[sp] = (blk + sp * (Co / 16)) * 1024;
+  };
+  auto tile_ptr = [&](int orow, int q) __attribute__((always_inline)) {
+    return (floatx4 *)__builtin_assume_aligned(o_tile + orow + 32 * w + 16 * q + 4 * lq, 16);
+  };
+#define SCN_ROWS6(R) "v"(R[0][0]), "v"(R[0][1]), "v"(R[0][2]), "v"(R[0][3]), "v"(R[1][0]), "v"(R[1][1]), "v"(R[1][2]), "v"(R[1][3])
+
+  Ent E0 = entry(0);
+  if (rem(E0) > 0) {
+    // ---- state at the top of pass p: rows(p) requested into R during pass p-1; weights(p) in wc, or requested into wn
+    // during pass p-1 when p starts a phase; indices of pass p+1 requested into pr; orc = output-tile rows of pass p;
+    // acc[1] / op1 = result and rows of group 1 of pass p-1, not yet in the tile; E0..E2 = table entries p..p+2;
+    // ioff = index-load offsets of pass p+2.
+    u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
+    unsigned ioff[2];
+    floatx4 R[2][NS16], wc[COS][NS16], wn[COS][NS16], acc[2][COS];
+    // the loads are tied ("+v") to their destination variables: that is what makes hipcc reload them IN PLACE
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp) R[g][sp] = wc[g][sp] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const unsigned wlane = (unsigned)lane * 16u;
+    int orc[2], op1 = M * OS;
+#pragma unroll
+    for (int q = 0; q < COS; ++q) acc[1][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    Ent E1 = entry(1), E2 = entry(2);
+    int pnext = 3;
+    {  // prologue (once per tile).  Load order = the steady state's: weights, indices, rows.
+      unsigned off[2];
+      int so[NS16];
+      index_offsets(E0, ioff);
+      load_idx(E0, ioff, pr);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      addr(E0, pr, off, orc);
+      weight_offsets(E0, so);
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp) load_weights(sp, (unsigned)lane * 16u, so[sp], wc);
+      index_offsets(E1, ioff);
+      __builtin_amdgcn_sched_barrier(0);
+      load_idx(E1, ioff, pr);
+      const int rso = (int)((E0.meta >> 8) & 15u) * (CK * 4);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int sp = 0; sp < NS16; ++sp) load_piece(R[g][sp], sp, off[g], rso);
+      __builtin_amdgcn_sched_barrier(0);
+      index_offsets(E2, ioff);
+    }
+
+    do {  // one pass per iteration; single exit
+      const bool two = rem(E0) > 16;
+      unsigned offn[2];
+      int orn[2], w_so[NS16];
+      floatx4 old[COS];
+      Ent E3 = E2;
+      // T0: the indices of pass p+1 have landed (and, in the first pass, the weights); the 8 row loads of pass p may still fly
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(8)" ::"v"(pr[0]), "v"(pr[1]), "v"(wc[0][0]), "v"(wc[0][1]), "v"(wc[0][2]), "v"(wc[0][3]),
+                   "v"(wc[1][0]), "v"(wc[1][1]), "v"(wc[1][2]), "v"(wc[1][3]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      addr(E1, pr, offn, orn);
+      // (pins the conversion HERE: hipcc otherwise sinks the output-row half to the end of the pass, which keeps the old
+      //  indices alive and moves their in-place reload into a copy)
+      asm volatile("" : "+v"(offn[0]), "+v"(offn[1]), "+v"(orn[0]), "+v"(orn[1]));
+      const int rson = (int)((E1.meta >> 8) & 15u) * (CK * 4);
+      weight_offsets(E1, w_so);
+      __builtin_amdgcn_sched_barrier(0);
+      // weights of pass p+1 when it starts a phase.  The 8 loads are issued in EVERY pass -- with EXEC = 0 when they are
+      // not needed -- so that the number of loads between any row piece and its wait does not depend on the pass.
+      asm volatile(
+          "s_bitcmp1_b32 %[meta], 20\n\t"
+          "s_cselect_b64 exec, -1, 0\n\t"
+          "buffer_load_dwordx4 %[w00], %[vo], %[rs], %[s0] offen\n\t"
+          "buffer_load_dwordx4 %[w10], %[vo], %[rs], %[s0] offen offset:1024\n\t"
+          "buffer_load_dwordx4 %[w01], %[vo], %[rs], %[s1] offen\n\t"
+          "buffer_load_dwordx4 %[w11], %[vo], %[rs], %[s1] offen offset:1024\n\t"
+          "buffer_load_dwordx4 %[w02], %[vo], %[rs], %[s2] offen\n\t"
+          "buffer_load_dwordx4 %[w12], %[vo], %[rs], %[s2] offen offset:1024\n\t"
+          "buffer_load_dwordx4 %[w03], %[vo], %[rs], %[s3] offen\n\t"
+          "buffer_load_dwordx4 %[w13], %[vo], %[rs], %[s3] offen offset:1024\n\t"
+          "s_mov_b64 exec, -1"
+          : [w00] "=&v"(wn[0][0]), [w10] "=&v"(wn[1][0]), [w01] "=&v"(wn[0][1]), [w11] "=&v"(wn[1][1]),
+            [w02] "=&v"(wn[0][2]), [w12] "=&v"(wn[1][2]), [w03] "=&v"(wn[0][3]), [w13] "=&v"(wn[1][3])
+          : [meta] "s"(E1.meta), [vo] "v"(wlane), [rs] "s"(wp_rsrc), [s0] "s"(w_so[0]), [s1] "s"(w_so[1]), [s2] "s"(w_so[2]), [s3] "s"(w_so[3])
+          : "memory", "scc");
+      load_idx(E2, ioff, pr);
+      __builtin_amdgcn_sched_barrier(0);
+      // group 0; beside its MFMAs: group 1 of the previous pass goes to the output tile, table entry p+3
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[0][sp]) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          const int q = h & 1, c = h >> 1;
+          const float a = c == 0 ? wc[q][sp].x : c == 1 ? wc[q][sp].y : c == 2 ? wc[q][sp].z : wc[q][sp].w;
+          const float bv = c == 0 ? R[0][sp].x : c == 1 ? R[0][sp].y : c == 2 ? R[0][sp].z : R[0][sp].w;
+          if (sp == 0 && c == 0) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[0][q], 0, 0, 0);
+          if (h == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (sp == 0) {
+#pragma unroll
+              for (int q2 = 0; q2 < COS; ++q2) old[q2] = *tile_ptr(op1, q2);
+            } else if (sp == 1) {
+#pragma unroll
+              for (int q2 = 0; q2 < COS; ++q2) *tile_ptr(op1, q2) = old[q2] + acc[1][q2];
+            } else if (sp == 2) {
+              E3 = entry(pnext);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_piece(R[0][sp], sp, offn[0], rson);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // group 1 (if the pass has one); beside its MFMAs: group 0 of this pass goes to the output tile.  The row loads
+      // stay OUTSIDE the branch: a variable that both sides of a branch redefine is copied at the join (hipcc).
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[1][sp]) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) {
+#pragma unroll
+          for (int h = 0; h < 8; ++h) {
+            const int q = h & 1, c = h >> 1;
+            const float a = c == 0 ? wc[q][sp].x : c == 1 ? wc[q][sp].y : c == 2 ? wc[q][sp].z : wc[q][sp].w;
+            const float bv = c == 0 ? R[1][sp].x : c == 1 ? R[1][sp].y : c == 2 ? R[1][sp].z : R[1][sp].w;
+            if (sp == 0 && c == 0) acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[1][q], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (sp == 0) {
+#pragma unroll
+          for (int q2 = 0; q2 < COS; ++q2) old[q2] = *tile_ptr(orc[0], q2);
+        } else if (sp == 1) {
+#pragma unroll
+          for (int q2 = 0; q2 < COS; ++q2) *tile_ptr(orc[0], q2) = old[q2] + acc[0][q2];
+        }
+        load_piece(R[1][sp], sp, offn[1], rson);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the next pass starts a phase: its weights (requested at the top of this pass) become current
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(10)" ::"v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]), "v"(wn[0][3]),
+                   "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if ((E1.meta >> 20) & 1u) {
+#pragma unroll
+        for (int q = 0; q < COS; ++q)
+#pragma unroll
+          for (int sp = 0; sp < NS16; ++sp) wc[q][sp] = wn[q][sp];
+      }
+      op1 = orc[1];
+      orc[0] = orn[0];
+      orc[1] = orn[1];
+      E0 = E1; E1 = E2; E2 = E3;
+      index_offsets(E2, ioff);
+      ++pnext;
+    } while (rem(E0) > 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS6(R), "v"(pr[0]), "v"(pr[1]), "v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]), "v"(wn[0][3]),
+                 "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < COS; ++q) *tile_ptr(op1, q) += acc[1][q];  // group 1 of the last pass
+  }
+#undef SCN_ROWS6
+  // each wave stores its own 32 planes: no barrier needed
+  const int rows = (int)min((int64_t)M, n_out - o0);
+  float *dst = out + (int64_t)blockIdx.y * n_out * Co;
+  for (int i = lane; i < rows * 8; i += 64) {
+    const int r = i >> 3, c4 = (i & 7) * 4;
+    *(floatx4 *)(dst + (o0 + r) * Co + co0 + 32 * w + c4) = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
+  }
+  if (colstats != nullptr && ksplit == 1) {  // column statistics of this wave's 32 planes: lane = (plane, half of the rows)
+    const int p = lane & 31, half = lane >> 5;
+    float cs = 0.f, css = 0.f;
+    for (int r = half * (M / 2); r < min(rows, half * (M / 2) + M / 2); ++r) {
+      const float v = o_tile[r * OS + 32 * w + p];
+      cs += v;
+      css += v * v;
+    }
+    cs += __shfl_xor(cs, 32);
+    css += __shfl_xor(css, 32);
+    if (half == 0) {
+      colstats[((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + p] = cs;
+      colstats[((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + p] = css;
+    }
+  }
+}
+
 // ------------------------------ forward, barrier-free, ONE wave per tile (v5) ---
 // k_conv_tile4 with the other division of labour: the workgroup is a single wave that owns all 64 output planes of
 // the 128-row tile (four 16-plane slices), so every gathered row is fetched once instead of once per wave, and a pass
@@ -1886,6 +2216,8 @@ SCN_KNOB g_conv_small_tile4 = 0;  // tuning key 7: 1 = launches with few tiles u
                                   // k_conv_tile2 (A/B on the train step: 53.14 against 52.79 ms, so off)
 SCN_KNOB g_conv_tile5 = 0;      // tuning key 9: 1 = k_conv_tile5 (one wave per tile, 64 planes) where k_conv_tile4 would run
 SCN_KNOB g_conv_expand = 1;     // tuning key 8: 0 = launches with one contribution per output row use the tile kernels (A/B)
+SCN_KNOB g_conv_tile6 = 0;      // tuning key 11: 96 / 128 = k_conv_tile6 with that many rows per tile where k_conv_tile4 would run unsplit
+SCN_KNOB g_conv_extra_lds = 0;  // tuning key 10: bytes of unused dynamic LDS added to k_conv_tile4 launches (occupancy probe)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 // Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.
@@ -2011,18 +2343,31 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   return 0;
 }
 
+// rows per tile of a kind-4 launch
+static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ? 96 : 128; }
+
 static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, float *colstats, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
                         int Ci, int Co, int ksplit, float *part, hipStream_t stream) {
-  constexpr int M = 128;
+  const int M = tile4_rows(ksplit);
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / 64;
   const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
   float *dst4 = ksplit > 1 ? part : out;
   const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
+  if (M != 128 || g_conv_tile6 == 128) {
+    if (M == 96)
+      k_conv_tile6<96><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
+                                                  n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+    else
+      k_conv_tile6<128><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
+                                                   n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+    SCN_CHECK_LAUNCH();
+    return 0;
+  }
 #define SCN_LAUNCH_TILE4(D)                                                                                         \
-  k_conv_tile4<D><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,                     \
+  k_conv_tile4<D><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,                     \
                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
                                              in_bytes, wp_bytes, ksplit)
 #ifdef SCN_TUNING
@@ -2097,6 +2442,8 @@ int scn_set_tuning(int key, int value) {
   if (key == 7) { g_conv_small_tile4 = value; return 0; }
   if (key == 8) { g_conv_expand = value; return 0; }
   if (key == 9) { g_conv_tile5 = value; return 0; }
+  if (key == 11 && (value == 0 || value == 96 || value == 128)) { g_conv_tile6 = value; return 0; }
+  if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
 #endif
@@ -2116,7 +2463,7 @@ int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out
   if (p.kind != 2 && p.kind != 4) return 0;  // generic / fallback kernels do not emit statistics
   if (p.ksplit > 1) return 0;  // coarse levels: the batch norm's own statistics pass over a few thousand rows is cheaper
                                // than a reduction kernel that also reduces columns (A/B: +0.2 ms per step)
-  const int M = p.kind == 4 ? 128 : 32 * p.nw;
+  const int M = p.kind == 4 ? tile4_rows(p.ksplit) : 32 * p.nw;
   return (n_out + M - 1) / M;
 }
 

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--sites", type=int, default=150000)
     ap.add_argument("--m", type=int, default=64)
     ap.add_argument("--dw", action="store_true")
+    ap.add_argument("--extra-lds", default="0", help="comma list: unused dynamic LDS bytes per k_conv_tile4 workgroup (occupancy probe)")
     ap.add_argument("--dw-variants", default="101,0,101,0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -54,14 +55,15 @@ def main():
                 out = torch.empty(0, device=dev)
                 flops = 2.0 * rb.total_pairs * ci * co
                 line = "L%d N=%d nu=%.1f SC %d->%d GF=%.1f:" % (lv, n, rb.total_pairs / n, ci, co, flops / 1e9)
-                for v in args.variants.split(","):
+                for v, xl in [(v, xl) for v in args.variants.split(",") for xl in args.extra_lds.split(",")]:
+                    lib.scn_set_tuning(10, int(xl))
                     lib.scn_set_tuning(0, int(v) % 10)
                     SCN.invalidate_weight_cache()  # variant 1 packs the weights in a different layout
                     lib.scn_set_tuning(1, (int(v) // 10) % 1000)
                     lib.scn_set_tuning(2, (int(v) // 10000) % 10)
                     lib.scn_set_tuning(4, int(v) // 100000)
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
-                    line += "  v%s %.3f ms %.1f TF" % (v, ms, flops / ms / 1e9)
+                    line += "  v%s%s %.3f ms %.1f TF" % (v, "" if xl == "0" else "+%sB" % xl, ms, flops / ms / 1e9)
                 for dv in ([int(v) for v in args.dw_variants.split(',')] if args.dw else []):
                     lib.scn_set_tuning(1, dv % 1000)
                     lib.scn_set_tuning(5, dv // 1000 if dv >= 1000 else 256)

@@ -118,7 +118,7 @@ def main():
                                   stderr=subprocess.DEVNULL)
             text = open(out).read()
     lines = text.split("\n")
-    starts = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3scn12k_conv_tile[45]\S*:", ln)]
+    starts = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3scn12k_conv_tile[456]\S*:", ln)]
     errors = []
     n = 0
     for st in starts:
