@@ -61,6 +61,7 @@ TUNING_SIGNATURES = {
     "scn_set_tuning": (c_int, [c_int, c_int]),
     "scn_debug_stamps": (c_int, [_P]),
     "scn_peak_mfma_f32": (c_int, [_P, c_int, ctypes.POINTER(c_double), _P]),
+    "scn_mfma_probe": (c_int, [_P, _P, c_int, c_int, ctypes.POINTER(c_double), _P]),
     "scn_peak_copy": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
     "scn_peak_read": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
 }

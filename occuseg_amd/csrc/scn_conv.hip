@@ -1011,8 +1011,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
                  unsigned in_bytes, unsigned wp_bytes, int ksplit) {
   constexpr int COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
   constexpr int TMAX = KMAX * (M / 32) * SCN_TILE4_MAX_CHUNKS + 8;  // passes per tile: <= M / 32 per (offset, chunk); + sentinels
-  __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
-  __shared__ __attribute__((aligned(8))) unsigned ptab[TMAX][2];  // as in k_conv_tile4
+  // dynamic LDS (the launcher passes tile6_lds_bytes<M>()): with a static 39 KB array hipcc concludes that three waves per
+  // SIMD are out of reach anyway and allocates 250 registers with the accumulators in AGPRs
+  extern __shared__ __attribute__((aligned(16))) float lds6[];
+  float *o_tile = lds6;                                             // [(M + 1) * OS], row M: sink for padded pairs
+  unsigned (*ptab)[2] = (unsigned (*)[2])(lds6 + (M + 1) * OS);     // [TMAX][2], as in k_conv_tile4
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1098,13 +1101,18 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
       orow[i] = (16 * i + li < rem(e)) ? dst * OS : M * OS;
     }
   };
+  // timing-only builds (tuning library): DBG & 1 no output-tile update, & 2 no row loads, & 4 no weight loads, & 8 no index
+  // loads (any of 2 / 4 / 8: no waits either), & 16 all pieces before the first MFMA instead of in the gaps
+  constexpr bool NOWAIT = (DBG & 14) != 0;
   auto load_idx = [&](const Ent &e, const unsigned (&vo)[2], u32x2 (&pr)[2]) __attribute__((always_inline)) {
+    if (DBG & 8) return;
     const int base = (int)e.base;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(pr[i]) : "v"(vo[i]), "s"(ru_rsrc), "s"(base) : "memory");
   };
   auto load_piece = [&](floatx4 &dst, int sp, unsigned voff, int so) __attribute__((always_inline)) {
+    if (DBG & 2) return;
     if (sp == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
     else if (sp == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
     else if (sp == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
@@ -1170,48 +1178,93 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
 
     do {  // one pass per iteration; single exit
       const bool two = rem(E0) > 16;
-      unsigned offn[2];
-      int orn[2], w_so[NS16];
+      unsigned offn[2] = {0u, 0u}, ioffn[2] = {0u, 0u};
+      int orn[2] = {0, 0}, w_so[NS16] = {0, 0, 0, 0}, rson = 0;
       floatx4 old[COS];
+      u32x2 e3v = {0u, 0u};
       Ent E3 = E2;
-      // T0: the indices of pass p+1 have landed (and, in the first pass, the weights); the 8 row loads of pass p may still fly
+      const unsigned wmeta = E1.meta;
+      // the 8 weight loads of pass p+1 are issued in EVERY pass, with EXEC = 0 unless that pass starts a phase: the number
+      // of loads between any row piece and its wait must not depend on the pass.
+      auto load_w2 = [&](int sp) __attribute__((always_inline)) {
+        if (DBG & 4) return;
+        asm volatile(
+            "s_bitcmp1_b32 %[meta], 20\n\t"
+            "s_cselect_b64 exec, -1, 0\n\t"
+            "buffer_load_dwordx4 %[w0], %[vo], %[rs], %[so] offen\n\t"
+            "buffer_load_dwordx4 %[w1], %[vo], %[rs], %[so] offen offset:1024\n\t"
+            "s_mov_b64 exec, -1"
+            : [w0] "=&v"(wn[0][sp]), [w1] "=&v"(wn[1][sp])
+            : [meta] "s"(wmeta), [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[sp])
+            : "memory", "scc");
+      };
+      // everything of a pass that is not an MFMA, cut into pieces of a few independent instructions; piece g is issued
+      // after MFMA g of group 0 (32 gaps; a dependent pair -- LDS read and its use -- never shares a gap)
+      auto piece = [&](int g) __attribute__((always_inline)) {
+        if (g == 0 || g == 2) {  // row offsets of pass p+1 from its (landed) pair indices
+          const int i = g >> 1;
+          const unsigned src = in_col ? pr[i].y : pr[i].x;
+          offn[i] = (16 * i < rem(E1)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : 0u;
+        } else if (g == 1 || g == 3) {  // output-tile rows of pass p+1
+          const int i = g >> 1;
+          const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
+          orn[i] = (16 * i + li < rem(E1)) ? dst * OS : M * OS;
+        } else if (g == 4) {
+          rson = (int)((E1.meta >> 8) & 15u) * (CK * 4);
+          weight_offsets(E1, w_so);
+          // (pins the conversion HERE: hipcc otherwise sinks parts of it to the end of the pass, keeping the old indices
+          //  alive and turning their in-place reload into a copy)
+          asm volatile("" : "+v"(offn[0]), "+v"(offn[1]), "+v"(orn[0]), "+v"(orn[1]));
+        } else if (g == 7) {
+          load_piece(R[0][0], 0, offn[0], rson);
+        } else if (g >= 8 && g <= 11) {
+          load_w2(g - 8);
+        } else if (g == 12) {  // group 1 of the previous pass -> output tile: read ...
+#pragma unroll
+          for (int q = 0; q < COS; ++q) old[q] = (DBG & 1) ? floatx4{0.f, 0.f, 0.f, 0.f} : *tile_ptr(op1, q);
+        } else if (g == 15) {
+          load_piece(R[0][1], 1, offn[0], rson);
+        } else if (g == 16) {  // indices of pass p+2, in place
+          load_idx(E2, ioff, pr);
+        } else if (g == 17) {  // table entry p+3: read ...
+          e3v = *(const u32x2 *)ptab[pnext];
+        } else if (g == 19 || g == 20) {  // ... add, write
+          const int q = g - 19;
+          if (DBG & 1) asm volatile("" ::"v"(acc[1][q])); else *tile_ptr(op1, q) = old[q] + acc[1][q];
+        } else if (g == 22) {  // ... to scalars
+          E3 = Ent{(unsigned)uni((int)e3v.x), (unsigned)uni((int)e3v.y)};
+        } else if (g == 23) {
+          load_piece(R[0][2], 2, offn[0], rson);
+        } else if (g == 24) {
+          index_offsets(E3, ioffn);
+          asm volatile("" : "+v"(ioffn[0]), "+v"(ioffn[1]));  // (pinned here, not sunk to the end of the pass)
+        } else if (g == 27) {  // group 0 of this pass -> output tile: read (add and write beside group 1)
+#pragma unroll
+          for (int q = 0; q < COS; ++q) old[q] = (DBG & 1) ? floatx4{0.f, 0.f, 0.f, 0.f} : *tile_ptr(orc[0], q);
+        } else if (g == 31) {
+          load_piece(R[0][3], 3, offn[0], rson);
+        }
+      };
+      // top: the indices of pass p+1 and the first row piece have landed (6 younger loads: R0[2], R0[3], R1[0..3])
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(8)" ::"v"(pr[0]), "v"(pr[1]), "v"(wc[0][0]), "v"(wc[0][1]), "v"(wc[0][2]), "v"(wc[0][3]),
-                   "v"(wc[1][0]), "v"(wc[1][1]), "v"(wc[1][2]), "v"(wc[1][3]) : "memory");
+      if (!NOWAIT) asm volatile("s_waitcnt vmcnt(6)" ::"v"(pr[0]), "v"(pr[1]), "v"(R[0][0]), "v"(R[0][1]) : "memory");
       __builtin_amdgcn_sched_barrier(0);
-      addr(E1, pr, offn, orn);
-      // (pins the conversion HERE: hipcc otherwise sinks the output-row half to the end of the pass, which keeps the old
-      //  indices alive and moves their in-place reload into a copy)
-      asm volatile("" : "+v"(offn[0]), "+v"(offn[1]), "+v"(orn[0]), "+v"(orn[1]));
-      const int rson = (int)((E1.meta >> 8) & 15u) * (CK * 4);
-      weight_offsets(E1, w_so);
-      __builtin_amdgcn_sched_barrier(0);
-      // weights of pass p+1 when it starts a phase.  The 8 loads are issued in EVERY pass -- with EXEC = 0 when they are
-      // not needed -- so that the number of loads between any row piece and its wait does not depend on the pass.
-      asm volatile(
-          "s_bitcmp1_b32 %[meta], 20\n\t"
-          "s_cselect_b64 exec, -1, 0\n\t"
-          "buffer_load_dwordx4 %[w00], %[vo], %[rs], %[s0] offen\n\t"
-          "buffer_load_dwordx4 %[w10], %[vo], %[rs], %[s0] offen offset:1024\n\t"
-          "buffer_load_dwordx4 %[w01], %[vo], %[rs], %[s1] offen\n\t"
-          "buffer_load_dwordx4 %[w11], %[vo], %[rs], %[s1] offen offset:1024\n\t"
-          "buffer_load_dwordx4 %[w02], %[vo], %[rs], %[s2] offen\n\t"
-          "buffer_load_dwordx4 %[w12], %[vo], %[rs], %[s2] offen offset:1024\n\t"
-          "buffer_load_dwordx4 %[w03], %[vo], %[rs], %[s3] offen\n\t"
-          "buffer_load_dwordx4 %[w13], %[vo], %[rs], %[s3] offen offset:1024\n\t"
-          "s_mov_b64 exec, -1"
-          : [w00] "=&v"(wn[0][0]), [w10] "=&v"(wn[1][0]), [w01] "=&v"(wn[0][1]), [w11] "=&v"(wn[1][1]),
-            [w02] "=&v"(wn[0][2]), [w12] "=&v"(wn[1][2]), [w03] "=&v"(wn[0][3]), [w13] "=&v"(wn[1][3])
-          : [meta] "s"(E1.meta), [vo] "v"(wlane), [rs] "s"(wp_rsrc), [s0] "s"(w_so[0]), [s1] "s"(w_so[1]), [s2] "s"(w_so[2]), [s3] "s"(w_so[3])
-          : "memory", "scc");
-      load_idx(E2, ioff, pr);
-      __builtin_amdgcn_sched_barrier(0);
-      // group 0; beside its MFMAs: group 1 of the previous pass goes to the output tile, table entry p+3
+      if (DBG & 16) {
+#pragma unroll
+        for (int g = 0; g < 32; ++g)
+          if ((g & 7) != 7) piece(g);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int sp = 0; sp < NS16; ++sp) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[0][sp]) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if (sp > 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (NOWAIT) {
+          } else if (sp == 1) asm volatile("s_waitcnt vmcnt(9)" ::"v"(R[0][sp]) : "memory");
+          else if (sp == 2) asm volatile("s_waitcnt vmcnt(15)" ::"v"(R[0][sp]) : "memory");
+          else asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[0][sp]) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
           const int q = h & 1, c = h >> 1;
@@ -1219,30 +1272,18 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
           const float bv = c == 0 ? R[0][sp].x : c == 1 ? R[0][sp].y : c == 2 ? R[0][sp].z : R[0][sp].w;
           if (sp == 0 && c == 0) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           else acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[0][q], 0, 0, 0);
-          if (h == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (sp == 0) {
-#pragma unroll
-              for (int q2 = 0; q2 < COS; ++q2) old[q2] = *tile_ptr(op1, q2);
-            } else if (sp == 1) {
-#pragma unroll
-              for (int q2 = 0; q2 < COS; ++q2) *tile_ptr(op1, q2) = old[q2] + acc[1][q2];
-            } else if (sp == 2) {
-              E3 = entry(pnext);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(DBG & 16)) piece(sp * 8 + h);
+          else if (h == 7) piece(sp * 8 + 7);  // (the in-place row load stays behind its MFMAs)
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        load_piece(R[0][sp], sp, offn[0], rson);
-        __builtin_amdgcn_sched_barrier(0);
       }
-      // group 1 (if the pass has one); beside its MFMAs: group 0 of this pass goes to the output tile.  The row loads
-      // stay OUTSIDE the branch: a variable that both sides of a branch redefine is copied at the join (hipcc).
+      // group 1 (if the pass has one).  Its row loads and the weight hand-over stay OUTSIDE the branch: a variable that
+      // both sides of a branch redefine is copied at the join (hipcc), and these registers have loads in flight.
 #pragma unroll
       for (int sp = 0; sp < NS16; ++sp) {
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[1][sp]) : "memory");
+        if (!NOWAIT) asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[1][sp]) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (two) {
 #pragma unroll
@@ -1252,25 +1293,27 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
             const float bv = c == 0 ? R[1][sp].x : c == 1 ? R[1][sp].y : c == 2 ? R[1][sp].z : R[1][sp].w;
             if (sp == 0 && c == 0) acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             else acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[1][q], 0, 0, 0);
+            if (sp == 0 && (h == 3 || h == 5)) {  // group 0 -> output tile: add, write (its MFMAs ended 4 MFMAs ago)
+              __builtin_amdgcn_sched_barrier(0);
+              asm volatile("" : "+v"(old[h == 3 ? 0 : 1]));  // (keeps hipcc from hoisting the add above the branch, right behind the MFMAs)
+              if (DBG & 1) asm volatile("" ::"v"(acc[0][h == 3 ? 0 : 1])); else *tile_ptr(orc[0], h == 3 ? 0 : 1) = old[h == 3 ? 0 : 1] + acc[0][h == 3 ? 0 : 1];
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
+        } else if (sp == 0) {
+#pragma unroll
+          for (int q = 0; q < COS; ++q) { if (DBG & 1) asm volatile("" ::"v"(acc[0][q])); else *tile_ptr(orc[0], q) = old[q] + acc[0][q]; }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (sp == 0) {
-#pragma unroll
-          for (int q2 = 0; q2 < COS; ++q2) old[q2] = *tile_ptr(orc[0], q2);
-        } else if (sp == 1) {
-#pragma unroll
-          for (int q2 = 0; q2 < COS; ++q2) *tile_ptr(orc[0], q2) = old[q2] + acc[0][q2];
-        }
         load_piece(R[1][sp], sp, offn[1], rson);
+        if (sp == 0) {  // the weights requested in gaps 8-11 have landed (6 younger loads)
+          __builtin_amdgcn_sched_barrier(0);
+          if (!NOWAIT) asm volatile("s_waitcnt vmcnt(6)" ::"v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]), "v"(wn[0][3]),
+                       "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]) : "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the next pass starts a phase: its weights (requested at the top of this pass) become current
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(10)" ::"v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]), "v"(wn[0][3]),
-                   "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if ((E1.meta >> 20) & 1u) {
+      if ((E1.meta >> 20) & 1u) {  // the next pass starts a phase: its weights become current
 #pragma unroll
         for (int q = 0; q < COS; ++q)
 #pragma unroll
@@ -1279,8 +1322,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
       op1 = orc[1];
       orc[0] = orn[0];
       orc[1] = orn[1];
+      ioff[0] = ioffn[0];
+      ioff[1] = ioffn[1];
       E0 = E1; E1 = E2; E2 = E3;
-      index_offsets(E2, ioff);
       ++pnext;
     } while (rem(E0) > 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -2343,6 +2387,9 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   return 0;
 }
 
+template <int M>
+constexpr size_t tile6_lds_bytes() { return (size_t)((M + 1) * 68 + (KMAX * (M / 32) * SCN_TILE4_MAX_CHUNKS + 8) * 2) * 4; }
+
 // rows per tile of a kind-4 launch
 static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ? 96 : 128; }
 
@@ -2358,11 +2405,28 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
   if (M != 128 || g_conv_tile6 == 128) {
     if (M == 96)
-      k_conv_tile6<96><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
+      k_conv_tile6<96><<<grid4, 128, tile6_lds_bytes<96>() + (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
                                                   n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
-    else
-      k_conv_tile6<128><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
-                                                   n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+    else {
+#define SCN_LAUNCH_TILE6(D)                                                                                                       \
+  k_conv_tile6<128, D><<<grid4, 128, tile6_lds_bytes<128>() + (size_t)g_conv_extra_lds, stream>>>(                                 \
+      in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,  \
+      in_bytes, wp_bytes, ksplit)
+#ifdef SCN_TUNING
+      switch (g_conv_dbg) {  // timing-only builds (tools/ablate_tile6.py)
+        case 1: SCN_LAUNCH_TILE6(1); break;
+        case 3: SCN_LAUNCH_TILE6(3); break;
+        case 4: SCN_LAUNCH_TILE6(4); break;
+        case 15: SCN_LAUNCH_TILE6(15); break;
+        case 16: SCN_LAUNCH_TILE6(16); break;
+        case 31: SCN_LAUNCH_TILE6(31); break;
+        default: SCN_LAUNCH_TILE6(0);
+      }
+#else
+      SCN_LAUNCH_TILE6(0);
+#endif
+#undef SCN_LAUNCH_TILE6
+    }
     SCN_CHECK_LAUNCH();
     return 0;
   }

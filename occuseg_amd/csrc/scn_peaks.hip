@@ -46,6 +46,88 @@ __global__ void __launch_bounds__(256) k_peak_read(const float4 *__restrict__ sr
   }
   if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[blockIdx.x & 63] = acc.x;
 }
+
+// ---- MFMA issue probe (tools/mfma_probe.py): what a wave's instruction stream around its MFMAs costs.
+// MODE: 0 two alternating accumulators, back to back   1 eight accumulators   2 as 0, A / B operands from 32 + 16 different
+// registers   3 as 2 + one independent v_add between MFMAs   4 as 2 + three v_add   5 as 2 + one s_add   6 as 2 + a
+// (never taken) scalar branch every 8 MFMAs   7 as 2 + one ds_read_b128 every 4 MFMAs (unused result)
+// 8 as 2 + one buffer_load_dwordx4 with EXEC = 0 every 4 MFMAs   9 as 2 + one L2-hit buffer_load_dwordx4 every 4 MFMAs
+template <int MODE>
+__global__ void __launch_bounds__(256) k_mfma_probe(float *sink, const float *src, int iters, int never) {
+  __shared__ float lds[4096];
+  asm volatile("" ::: "a255");  // (mode 10 reads it)
+  floatx4 acc[8];
+  float a[32], b[16], f[4] = {0.f, 0.f, 0.f, 0.f};
+  floatx4 junk = {0.f, 0.f, 0.f, 0.f};
+  int sc = never;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 32; ++i) a[i] = (float)(threadIdx.x + i) * 1e-9f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) b[i] = (float)(blockIdx.x + i) * 1e-9f;
+  lds[threadIdx.x] = a[0];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 1 << 20, 0x00020000);
+  const unsigned voff = (threadIdx.x & 63) * 16;
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {  // 64 MFMAs per trip
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+      const int ai = MODE >= 2 ? (m & 31) : 0, bi = MODE >= 2 ? ((m >> 1) & 15) : 0;
+      const int ci = MODE == 1 ? (m & 7) : (m & 1);
+      acc[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ai], b[bi], acc[ci], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE == 3) f[m & 3] += 1.0f;
+      if (MODE == 4) { f[0] += 1.0f; f[1] += 2.0f; f[2] += 3.0f; }
+      if (MODE == 5) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) : : "scc");
+      if (MODE == 6 && (m & 7) == 7) { if (sc == 12345) sink[1] = 0.f; }
+      if (MODE == 7 && (m & 3) == 3) asm volatile("ds_read_b128 %0, %1" : "=v"(junk) : "v"(voff) : "memory");
+      if (MODE == 8 && (m & 3) == 3)
+        asm volatile("s_mov_b64 exec, 0\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen\n\ts_mov_b64 exec, -1" : "+v"(junk) : "v"(voff), "s"(rs) : "memory");
+      if (MODE == 9 && (m & 3) == 3)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(junk) : "v"(voff), "s"(rs) : "memory");
+      // 10-17: one instruction per MFMA
+      if (MODE == 10) asm volatile("v_accvgpr_read_b32 %0, a255" : "=v"(f[m & 3]));
+      if (MODE == 11) asm volatile("v_mov_b64 %0, %1" : "=v"(*(double *)&junk) : "v"(*(double *)&a[(m & 15) * 2]));
+      if (MODE == 12) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(f[m & 3]) : "v"(voff), "v"(a[m & 31]));
+      if (MODE == 13) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(f[m & 3]) : "v"(voff), "v"(a[m & 31]), "v"(voff));
+      if (MODE == 14) asm volatile("ds_add_f32 %0, %1" ::"v"(voff), "v"(a[m & 31]) : "memory");
+      if (MODE == 15) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sc) : "v"(a[m & 31]));
+      if (MODE == 16) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(double *)&junk) : "v"(*(double *)&a[(m & 15) * 2]), "v"(*(double *)&b[(m & 7) * 2]));
+      if (MODE == 17) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(f[m & 3]) : "v"(voff), "v"(a[m & 31]));
+      if (MODE == 18) asm volatile("s_nop 0");
+      // 20-23: the same VALU count as mode 13 (one per MFMA), clustered: 2 per 2, 4 per 4, 16 per 16, 64 per 64 MFMAs
+      if (MODE >= 20 && MODE <= 23) {
+        constexpr int CL = MODE == 20 ? 2 : MODE == 21 ? 4 : MODE == 22 ? 16 : 64;
+        if ((m % CL) == CL - 1) {
+#pragma unroll
+          for (int u = 0; u < CL; ++u) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(f[u & 3]) : "v"(voff), "v"(a[(m + u) & 31]), "v"(voff));
+        }
+      }
+      // 24: half as many (one per 2 MFMAs, single)   25: quarter (one per 4 MFMAs)   26: 16 per 64 clustered
+      if (MODE == 24 && (m & 1)) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(f[m & 3]) : "v"(voff), "v"(a[m & 31]), "v"(voff));
+      if (MODE == 25 && (m & 3) == 3) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(f[m & 3]) : "v"(voff), "v"(a[m & 31]), "v"(voff));
+      if (MODE == 26 && m == 63) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(f[u & 3]) : "v"(voff), "v"(a[u & 31]), "v"(voff));
+      }
+      // 27: 16 v_pk_add_f32 per 64 clustered   28: ds_read_b128 x4 + 8 v_pk_add + ds_write_b128 x4 per 64 MFMAs (a tile update)
+      if (MODE == 27 && m == 63) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(double *)&f[(u & 1) * 2]) : "v"(*(double *)&a[(u & 15) * 2]), "v"(*(double *)&b[(u & 7) * 2]));
+      }
+      if (MODE == 19 && (m & 3) == 3) asm volatile("ds_write_b128 %0, %1" ::"v"(voff), "v"(acc[0]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(junk) : "memory");
+    if (MODE == 8 || MODE == 9) asm volatile("s_waitcnt vmcnt(0)" ::"v"(junk) : "memory");
+  }
+  floatx4 s = acc[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) s += acc[i];
+  s += junk;
+  if (s.x + f[0] + f[1] + f[2] + f[3] + (float)sc == 123.456f) sink[0] = s.x + s.y + s.z + s.w;
+}
 }  // namespace scn
 using namespace scn;
 
@@ -70,6 +152,40 @@ int scn_peak_mfma_f32(float *scratch_dev, int waves_per_simd, double *tflops_hos
   float ms = 0.f;
   SCN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
   const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  *tflops_host = flops / ((double)ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return 0;
+}
+
+
+// fraction of the f32-MFMA issue rate (one v_mfma_f32_16x16x4_f32 per 32 cycles and SIMD) that `waves_per_simd` waves per SIMD
+// reach with stream MODE (see k_mfma_probe), at the clock the kernel itself measures
+int scn_mfma_probe(float *scratch_dev, const float *src_dev, int mode, int waves_per_simd, double *tflops_host, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  int dev = 0, cus = 0;
+  SCN_CHECK_HIP(hipGetDevice(&dev));
+  SCN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int iters = 3000;
+  const int blocks = cus * waves_per_simd;
+  hipEvent_t e0, e1;
+  SCN_CHECK_HIP(hipEventCreate(&e0));
+  SCN_CHECK_HIP(hipEventCreate(&e1));
+#define SCN_PROBE(M) case M: k_mfma_probe<M><<<blocks, 256, 0, stream>>>(scratch_dev, src_dev, n, 0); break
+  for (int rep = 0; rep < 2; ++rep) {
+    const int n = rep == 0 ? 50 : iters;
+    if (rep == 1) SCN_CHECK_HIP(hipEventRecord(e0, stream));
+    switch (mode) {
+      SCN_PROBE(0); SCN_PROBE(1); SCN_PROBE(2); SCN_PROBE(3); SCN_PROBE(4); SCN_PROBE(5); SCN_PROBE(6); SCN_PROBE(7); SCN_PROBE(8); SCN_PROBE(9); SCN_PROBE(10); SCN_PROBE(11); SCN_PROBE(12); SCN_PROBE(13); SCN_PROBE(14); SCN_PROBE(15); SCN_PROBE(16); SCN_PROBE(17); SCN_PROBE(18); SCN_PROBE(19); SCN_PROBE(20); SCN_PROBE(21); SCN_PROBE(22); SCN_PROBE(23); SCN_PROBE(24); SCN_PROBE(25); SCN_PROBE(26); SCN_PROBE(27);
+      default: return fail(2, "scn_mfma_probe: unknown mode%s", "");
+    }
+  }
+#undef SCN_PROBE
+  SCN_CHECK_HIP(hipEventRecord(e1, stream));
+  SCN_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SCN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4.0 * (double)iters * 64.0 * 2.0 * 16 * 16 * 4;
   *tflops_host = flops / ((double)ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

@@ -118,7 +118,9 @@ def main():
                                   stderr=subprocess.DEVNULL)
             text = open(out).read()
     lines = text.split("\n")
-    starts = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3scn12k_conv_tile[456]\S*:", ln)]
+    # (the timing-only instantiations of k_conv_tile6, DBG != 0, drop loads and waits on purpose: not checked)
+    starts = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3scn12k_conv_tile[456]\S*:", ln)
+              and not re.match(r"^_ZN3scn12k_conv_tile6ILi\d+ELi[1-9]", ln)]
     errors = []
     n = 0
     for st in starts:
