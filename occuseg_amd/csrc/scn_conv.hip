@@ -985,28 +985,33 @@ __global__ void __launch_bounds__(128)
   }
 }
 
-// ------------------------ forward, barrier-free, THREE waves per SIMD (v6) ---
+// ------------------- forward, barrier-free, few vector-ALU instructions (v6) ---
 // k_conv_tile4's division of labour (two waves per tile, 32 planes each, rows gathered straight into MFMA fragment
-// registers, output tile in LDS, pass table) on a register and LDS diet, because occupancy is what the kernel responds to:
-// with unused LDS added to k_conv_tile4 launches, 2 / 3 / 4 workgroups per CU run the L0-L1 layers at 58 / 78 / 94
-// TFLOP/s (tools/bench_conv.py --extra-lds).  k_conv_tile4 cannot go further: 248 registers (two waves per SIMD) and a
-// 39 KB tile (four per CU).  Here:
-//   * ONE row register set, reloaded in place: the 16-byte piece R[g][sp] of pass p is consumed by eight consecutive
-//     MFMAs and requested again for pass p+1 right after them (a full pass of latency budget for every piece); the pair
-//     indices are converted at the top of the pass and their registers reloaded at once.  No rotating sets, hence no
-//     unrolling and no register copies at the back edge.
-//   * the result of a group goes to the output tile while the OTHER group's MFMAs run (group 0 during group 1 of the
-//     same pass, group 1 during group 0 of the next): no copy of the accumulators, one 8-register read buffer.
-//   * M = 96 rows: 26 KB of tile + 3 KB of pass table = five workgroups per CU (M = 128: four, as before).
-// vmcnt is an in-order FIFO: at the top of a pass everything but the 8 row loads of the previous pass has landed
-// (indices of pass p+1, weights of pass p); inside the pass each row piece is awaited with the number of loads issued
-// after it -- 9 (7 younger pieces + 2 index loads), or 17 in a pass that also requests the next phase's weights, which
-// is why the pass body exists in two versions.  tools/check_asm_loads.py walks both through every branch.
-template <int M, int DBG = 0>
+// registers, output tile in LDS, pass table), rebuilt around one measurement (tools/mfma_probe.py): beside
+// v_mfma_f32_16x16x4_f32 every vector-ALU instruction -- v_mov, v_cndmask, v_mad, v_accvgpr_read, v_pk_add alike -- takes
+// 8 cycles of matrix-pipe time when it sits in a cluster of its kind and 12-14 when it stands alone between two MFMAs,
+// with one wave per SIMD or with four; scalar instructions, branches, LDS and memory instructions cost 0-3 %.  k_conv_tile4
+// issues ~90 vector-ALU instructions per pass of 32-64 MFMAs: that, not latency, is where a third of its matrix pipe
+// goes.  Here a pass issues ~20, in three clusters:
+//   * ONE row register set, reloaded in place (the 16-byte piece R[g][sp] of pass p is consumed by eight consecutive
+//     MFMAs and requested again for pass p+1 right after them); indices converted and reloaded in place too: no
+//     rotating register sets, no copies, no unrolling;
+//   * addresses are one v_mad_u32_u24 each (row byte offset, output-tile byte address); lanes past the end of a list are
+//     not redirected to a sink row (v_cmp + v_cndmask) but masked out of the output-tile WRITE with an EXEC mask made
+//     by scalar instructions; absent groups are skipped by scalar branches;
+//   * the accumulators are not copied or zeroed (first MFMA of a chain takes C = 0) and go to the output tile while
+//     the OTHER group's MFMAs run;
+//   * two weight register sets that swap roles from phase to phase -- the pass loop exists twice, one copy per role --
+//     instead of 16 v_mov_b64 per phase.
+// vmcnt is an in-order FIFO and every pass issues the same 18 loads in the same order (R0[0], 8 weight, R0[1], 2 index,
+// R0[2], R0[3], R1[0..3]; the weight loads with EXEC = 0 unless the next pass starts a phase), so every wait is a
+// constant: tools/check_asm_loads.py proves on the emitted assembly that no instruction touches a register with a load
+// in flight.
+template <int M, bool INCOL, int DBG = 0>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))
     k_conv_tile6(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
-                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                 const int32_t *__restrict__ bases, int K, int64_t stride,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes, int ksplit) {
   constexpr int COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
@@ -1014,8 +1019,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
   // dynamic LDS (the launcher passes tile6_lds_bytes<M>()): with a static 39 KB array hipcc concludes that three waves per
   // SIMD are out of reach anyway and allocates 250 registers with the accumulators in AGPRs
   extern __shared__ __attribute__((aligned(16))) float lds6[];
-  float *o_tile = lds6;                                             // [(M + 1) * OS], row M: sink for padded pairs
-  unsigned (*ptab)[2] = (unsigned (*)[2])(lds6 + (M + 1) * OS);     // [TMAX][2], as in k_conv_tile4
+  float *o_tile = lds6;                                          // [M * OS]
+  unsigned (*ptab)[2] = (unsigned (*)[2])(lds6 + M * OS);        // [TMAX][2], as in k_conv_tile4
+  typedef __attribute__((address_space(3))) floatx4 lds_floatx4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds6;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1046,11 +1053,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
   const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
   const int nch = Ci / CK;
 
-  for (int i = lane; i < (M + 1) * 8; i += 64) {  // each wave initialises ITS 32 planes of the output tile
+  for (int i = lane; i < M * 8; i += 64) {  // each wave initialises ITS 32 planes of the output tile
     const int r = i >> 3, c4 = (i & 7) * 4;
     floatx4 v = {0.f, 0.f, 0.f, 0.f};
     if (bias && blockIdx.y == 0) v = *(const floatx4 *)(bias + co0 + 32 * w + c4);
-    if (residual && blockIdx.y == 0 && r < M && o0 + r < n_out) v += *(const floatx4 *)(residual + (o0 + r) * Co + co0 + 32 * w + c4);
+    if (residual && blockIdx.y == 0 && o0 + r < n_out) v += *(const floatx4 *)(residual + (o0 + r) * Co + co0 + 32 * w + c4);
     *(floatx4 *)(o_tile + r * OS + 32 * w + c4) = v;
   }
   if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
@@ -1088,22 +1095,24 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     return Ent{(unsigned)uni((int)v.x), (unsigned)uni((int)v.y)};
   };
   auto rem = [](const Ent &e) __attribute__((always_inline)) { return (int)(e.meta & 255u); };
+  // per-lane constants
+  const unsigned li8[2] = {(unsigned)li * 8u, (unsigned)(li + 16) * 8u};  // byte offset of the lane's pair in a pass
+  const unsigned lq16 = (unsigned)lq * 16u, ci4 = (unsigned)Ci * 4u;
+  // output-tile byte address of (row dst, this lane's planes) = dst * (OS * 4) + cbase   (mod 2^32: dst - o0 is what counts)
+  const unsigned cbase = lds0 + (unsigned)(32 * w + 4 * lq) * 4u - (unsigned)o0 * (unsigned)(OS * 4);
+  const unsigned wlane = (unsigned)lane * 16u;
+  // v_mad_u32_u24: full rate (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate); rows and sites are < 2^24 (conv_plan)
+  auto mad24 = [](unsigned a, unsigned b, unsigned c) __attribute__((always_inline)) { return __umul24(a, b) + c; };
+  // index-load offsets of a pass: the lane's pair, clamped to the last pair of the list (lanes past the end repeat it; their
+  // contribution never reaches the output tile)
   auto index_offsets = [&](const Ent &e, unsigned (&vo)[2]) __attribute__((always_inline)) {
+    const unsigned last = (unsigned)(rem(e) - 1) * 8u;  // rem == 0 (no such pass): no clamp, reads the first pairs of `rules`
 #pragma unroll
-    for (int i = 0; i < 2; ++i) vo[i] = (16 * i < rem(e)) ? (unsigned)min(16 * i + li, rem(e) - 1) * 8u : 0u;
-  };
-  auto addr = [&](const Ent &e, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const unsigned src = in_col ? pr[i].y : pr[i].x;
-      const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
-      off[i] = (16 * i < rem(e)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : 0u;
-      orow[i] = (16 * i + li < rem(e)) ? dst * OS : M * OS;
-    }
+    for (int i = 0; i < 2; ++i) vo[i] = min(li8[i], last);
   };
   // timing-only builds (tuning library): DBG & 1 no output-tile update, & 2 no row loads, & 4 no weight loads, & 8 no index
-  // loads (any of 2 / 4 / 8: no waits either), & 16 all pieces before the first MFMA instead of in the gaps
-  constexpr bool NOWAIT = (DBG & 14) != 0;
+  // loads (any of 2 / 4 / 8: no waits either)
+  constexpr bool NOWAIT = (DBG & 30) != 0;  // & 16: all loads, no waits
   auto load_idx = [&](const Ent &e, const unsigned (&vo)[2], u32x2 (&pr)[2]) __attribute__((always_inline)) {
     if (DBG & 8) return;
     const int base = (int)e.base;
@@ -1118,52 +1127,77 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     else if (sp == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
     else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:192" : "+v"(dst) : "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
   };
-  auto load_weights = [&](int sp, unsigned voff, int so, floatx4 (&wr)[COS][NS16]) __attribute__((always_inline)) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wr[0][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "+v"(wr[1][sp]) : "v"(voff), "s"(wp_rsrc), "s"(so) : "memory");
-  };
   auto weight_offsets = [&](const Ent &e, int (&so)[NS16]) __attribute__((always_inline)) {
     const int k = (int)(e.meta >> 12) & 255, chn = (int)(e.meta >> 8) & 15;
     const int blk = (k * (Ci / 16) + chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS;
 #pragma unroll
     for (int sp = 0; sp < NS16; ++sp) so[sp] = (blk + sp * (Co / 16)) * 1024;
   };
-  auto tile_ptr = [&](int orow, int q) __attribute__((always_inline)) {
-    return (floatx4 *)__builtin_assume_aligned(o_tile + orow + 32 * w + 16 * q + 4 * lq, 16);
+  // EXEC mask of the lanes whose pair exists: group g of a pass with `r` pairs left holds min(max(r - 16 g, 0), 16)
+  auto lane_mask = [](int r, int g) __attribute__((always_inline)) {
+    const int n = min(max(r - 16 * g, 0), 16);
+    return (unsigned)((1u << n) - 1u) * 0x10001u;  // lanes li + 16 lq, lq = 0..3: the same 16 bits in all four quarters
+  };
+  // the two 16-plane fragments of one group -> output tile, lanes outside `mask` not written
+  auto tile_write = [&](unsigned addr, unsigned mask, const floatx4 &d0, const floatx4 &d1) __attribute__((always_inline)) {
+    if (DBG & 64)  // timing only: every lane written, EXEC never written
+      asm volatile("ds_write_b128 %[a], %[d0]\n\tds_write_b128 %[a], %[d1] offset:64" : : [a] "v"(addr), [d0] "v"(d0), [d1] "v"(d1) : "memory");
+    else
+    asm volatile(
+        "s_mov_b32 exec_lo, %[m]\n\t"
+        "s_mov_b32 exec_hi, %[m]\n\t"
+        "ds_write_b128 %[a], %[d0]\n\t"
+        "ds_write_b128 %[a], %[d1] offset:64\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : [a] "v"(addr), [m] "s"(__builtin_amdgcn_readfirstlane((int)mask)), [d0] "v"(d0), [d1] "v"(d1)
+        : "memory");
+  };
+  auto tile_read = [&](unsigned addr, floatx4 (&old)[COS]) __attribute__((always_inline)) {
+    const lds_floatx4 *p = (const lds_floatx4 *)(size_t)addr;
+    old[0] = p[0];
+    old[1] = p[4];
   };
 #define SCN_ROWS6(R) "v"(R[0][0]), "v"(R[0][1]), "v"(R[0][2]), "v"(R[0][3]), "v"(R[1][0]), "v"(R[1][1]), "v"(R[1][2]), "v"(R[1][3])
+#define SCN_W6(W) "v"(W[0][0]), "v"(W[0][1]), "v"(W[0][2]), "v"(W[0][3]), "v"(W[1][0]), "v"(W[1][1]), "v"(W[1][2]), "v"(W[1][3])
 
   Ent E0 = entry(0);
   if (rem(E0) > 0) {
-    // ---- state at the top of pass p: rows(p) requested into R during pass p-1; weights(p) in wc, or requested into wn
-    // during pass p-1 when p starts a phase; indices of pass p+1 requested into pr; orc = output-tile rows of pass p;
-    // acc[1] / op1 = result and rows of group 1 of pass p-1, not yet in the tile; E0..E2 = table entries p..p+2;
-    // ioff = index-load offsets of pass p+2.
+    // ---- state at the top of pass p: rows(p) requested into R during pass p-1; weights(p) in (or on their way into) the
+    // current weight set; indices of pass p+1 requested into pr; orc / mc = output-tile addresses and lane masks of pass p;
+    // acc[1] / op1 / mp1 = result, address and mask of group 1 of pass p-1, not yet in the tile; E0..E2 = table entries
+    // p..p+2; ioff = index-load offsets of pass p+2.
     u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
     unsigned ioff[2];
-    floatx4 R[2][NS16], wc[COS][NS16], wn[COS][NS16], acc[2][COS];
-    // the loads are tied ("+v") to their destination variables: that is what makes hipcc reload them IN PLACE
+    floatx4 R[2][NS16], wA[COS][NS16], wB[COS][NS16], acc[2][COS];
+    unsigned orc[2], op1 = lds0, mc[2], mp1 = 0u;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int sp = 0; sp < NS16; ++sp) R[g][sp] = wc[g][sp] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const unsigned wlane = (unsigned)lane * 16u;
-    int orc[2], op1 = M * OS;
+      for (int sp = 0; sp < NS16; ++sp) R[g][sp] = wA[g][sp] = wB[g][sp] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < COS; ++q) acc[1][q] = floatx4{0.f, 0.f, 0.f, 0.f};
     Ent E1 = entry(1), E2 = entry(2);
     int pnext = 3;
     {  // prologue (once per tile).  Load order = the steady state's: weights, indices, rows.
-      unsigned off[2];
       int so[NS16];
       index_offsets(E0, ioff);
       load_idx(E0, ioff, pr);
       asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]) : "memory");
       __builtin_amdgcn_sched_barrier(0);
-      addr(E0, pr, off, orc);
+      unsigned off[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        off[i] = mad24(INCOL ? pr[i].y : pr[i].x, ci4, lq16);
+        orc[i] = mad24(INCOL ? pr[i].x : pr[i].y, (unsigned)(OS * 4), cbase);
+        mc[i] = lane_mask(rem(E0), i);
+      }
       weight_offsets(E0, so);
 #pragma unroll
-      for (int sp = 0; sp < NS16; ++sp) load_weights(sp, (unsigned)lane * 16u, so[sp], wc);
+      for (int sp = 0; sp < NS16; ++sp) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wA[0][sp]) : "v"(wlane), "s"(wp_rsrc), "s"(so[sp]) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "+v"(wA[1][sp]) : "v"(wlane), "s"(wp_rsrc), "s"(so[sp]) : "memory");
+      }
       index_offsets(E1, ioff);
       __builtin_amdgcn_sched_barrier(0);
       load_idx(E1, ioff, pr);
@@ -1176,85 +1210,35 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
       index_offsets(E2, ioff);
     }
 
-    do {  // one pass per iteration; single exit
+    // one pass: weights of the current phase in wc; a phase that starts with the NEXT pass gets its weights into wn
+    auto pass = [&](floatx4 (&wc)[COS][NS16], floatx4 (&wn)[COS][NS16]) __attribute__((always_inline)) {
       const bool two = rem(E0) > 16;
-      unsigned offn[2] = {0u, 0u}, ioffn[2] = {0u, 0u};
-      int orn[2] = {0, 0}, w_so[NS16] = {0, 0, 0, 0}, rson = 0;
+      unsigned offn[2], orn[2], ioffn[2];
       floatx4 old[COS];
-      u32x2 e3v = {0u, 0u};
-      Ent E3 = E2;
-      const unsigned wmeta = E1.meta;
-      // the 8 weight loads of pass p+1 are issued in EVERY pass, with EXEC = 0 unless that pass starts a phase: the number
-      // of loads between any row piece and its wait must not depend on the pass.
-      auto load_w2 = [&](int sp) __attribute__((always_inline)) {
-        if (DBG & 4) return;
-        asm volatile(
-            "s_bitcmp1_b32 %[meta], 20\n\t"
-            "s_cselect_b64 exec, -1, 0\n\t"
-            "buffer_load_dwordx4 %[w0], %[vo], %[rs], %[so] offen\n\t"
-            "buffer_load_dwordx4 %[w1], %[vo], %[rs], %[so] offen offset:1024\n\t"
-            "s_mov_b64 exec, -1"
-            : [w0] "=&v"(wn[0][sp]), [w1] "=&v"(wn[1][sp])
-            : [meta] "s"(wmeta), [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[sp])
-            : "memory", "scc");
-      };
-      // everything of a pass that is not an MFMA, cut into pieces of a few independent instructions; piece g is issued
-      // after MFMA g of group 0 (32 gaps; a dependent pair -- LDS read and its use -- never shares a gap)
-      auto piece = [&](int g) __attribute__((always_inline)) {
-        if (g == 0 || g == 2) {  // row offsets of pass p+1 from its (landed) pair indices
-          const int i = g >> 1;
-          const unsigned src = in_col ? pr[i].y : pr[i].x;
-          offn[i] = (16 * i < rem(E1)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : 0u;
-        } else if (g == 1 || g == 3) {  // output-tile rows of pass p+1
-          const int i = g >> 1;
-          const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
-          orn[i] = (16 * i + li < rem(E1)) ? dst * OS : M * OS;
-        } else if (g == 4) {
-          rson = (int)((E1.meta >> 8) & 15u) * (CK * 4);
-          weight_offsets(E1, w_so);
-          // (pins the conversion HERE: hipcc otherwise sinks parts of it to the end of the pass, keeping the old indices
-          //  alive and turning their in-place reload into a copy)
-          asm volatile("" : "+v"(offn[0]), "+v"(offn[1]), "+v"(orn[0]), "+v"(orn[1]));
-        } else if (g == 7) {
-          load_piece(R[0][0], 0, offn[0], rson);
-        } else if (g >= 8 && g <= 11) {
-          load_w2(g - 8);
-        } else if (g == 12) {  // group 1 of the previous pass -> output tile: read ...
-#pragma unroll
-          for (int q = 0; q < COS; ++q) old[q] = (DBG & 1) ? floatx4{0.f, 0.f, 0.f, 0.f} : *tile_ptr(op1, q);
-        } else if (g == 15) {
-          load_piece(R[0][1], 1, offn[0], rson);
-        } else if (g == 16) {  // indices of pass p+2, in place
-          load_idx(E2, ioff, pr);
-        } else if (g == 17) {  // table entry p+3: read ...
-          e3v = *(const u32x2 *)ptab[pnext];
-        } else if (g == 19 || g == 20) {  // ... add, write
-          const int q = g - 19;
-          if (DBG & 1) asm volatile("" ::"v"(acc[1][q])); else *tile_ptr(op1, q) = old[q] + acc[1][q];
-        } else if (g == 22) {  // ... to scalars
-          E3 = Ent{(unsigned)uni((int)e3v.x), (unsigned)uni((int)e3v.y)};
-        } else if (g == 23) {
-          load_piece(R[0][2], 2, offn[0], rson);
-        } else if (g == 24) {
-          index_offsets(E3, ioffn);
-          asm volatile("" : "+v"(ioffn[0]), "+v"(ioffn[1]));  // (pinned here, not sunk to the end of the pass)
-        } else if (g == 27) {  // group 0 of this pass -> output tile: read (add and write beside group 1)
-#pragma unroll
-          for (int q = 0; q < COS; ++q) old[q] = (DBG & 1) ? floatx4{0.f, 0.f, 0.f, 0.f} : *tile_ptr(orc[0], q);
-        } else if (g == 31) {
-          load_piece(R[0][3], 3, offn[0], rson);
-        }
-      };
-      // top: the indices of pass p+1 and the first row piece have landed (6 younger loads: R0[2], R0[3], R1[0..3])
+      int w_so[NS16];
+      // ---- top: the indices of pass p+1, the first two row pieces and the weights have landed (6 younger loads: R0[2],
+      // R0[3], R1[0..3])
       __builtin_amdgcn_sched_barrier(0);
-      if (!NOWAIT) asm volatile("s_waitcnt vmcnt(6)" ::"v"(pr[0]), "v"(pr[1]), "v"(R[0][0]), "v"(R[0][1]) : "memory");
+      if (!NOWAIT) asm volatile("s_waitcnt vmcnt(6)" ::"v"(pr[0]), "v"(pr[1]), "v"(R[0][0]), "v"(R[0][1]), SCN_W6(wc) : "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (DBG & 16) {
+      // vector-ALU cluster 1: addresses of pass p+1, output-tile fragment of group 1 of pass p-1
 #pragma unroll
-        for (int g = 0; g < 32; ++g)
-          if ((g & 7) != 7) piece(g);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 2; ++i) {
+        offn[i] = mad24(INCOL ? pr[i].y : pr[i].x, ci4, lq16);
+        orn[i] = mad24(INCOL ? pr[i].x : pr[i].y, (unsigned)(OS * 4), cbase);
       }
+      // (pins the conversion HERE: hipcc otherwise sinks parts of it to the end of the pass, keeping the old indices alive
+      //  and turning their in-place reload into a copy)
+      asm volatile("" : "+v"(offn[0]), "+v"(offn[1]), "+v"(orn[0]), "+v"(orn[1]));
+      if (!(DBG & 1)) tile_read(op1, old);
+      const u32x2 e3v = *(const u32x2 *)ptab[pnext];
+      const int rson = (int)((E1.meta >> 8) & 15u) * (CK * 4);
+      const unsigned mn0 = lane_mask(rem(E1), 0), mn1 = lane_mask(rem(E1), 1);
+      weight_offsets(E1, w_so);
+      Ent E3 = E2;
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- group 0.  Between its MFMAs: memory and LDS instructions only, except one vector-ALU cluster after the first
+      // eight (group 1 of the previous pass -> output tile, table entry p+3 to scalars, index offsets of pass p+3)
 #pragma unroll
       for (int sp = 0; sp < NS16; ++sp) {
         if (sp > 0) {
@@ -1273,13 +1257,53 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
           if (sp == 0 && c == 0) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           else acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[0][q], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (!(DBG & 16)) piece(sp * 8 + h);
-          else if (h == 7) piece(sp * 8 + 7);  // (the in-place row load stays behind its MFMAs)
+          if (sp == 1 && h < 4 && !(DBG & 4)) {  // the 8 weight loads of pass p+1, EXEC = 0 unless it starts a phase
+            if ((DBG & 128) && (h & 1)) {  // timing only: half of the weight loads
+            } else if (DBG & 256)  // timing only: one dword per lane instead of four
+              asm volatile(
+                  "buffer_load_dword %[w0], %[vo], %[rs], %[so] offen\n\t"
+                  "buffer_load_dword %[w1], %[vo], %[rs], %[so] offen offset:1024"
+                  : [w0] "+v"(wn[0][h].x), [w1] "+v"(wn[1][h].x)
+                  : [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[h])
+                  : "memory");
+            else if (DBG & 32)  // timing only: always loaded, EXEC never written
+              asm volatile(
+                  "buffer_load_dwordx4 %[w0], %[vo], %[rs], %[so] offen\n\t"
+                  "buffer_load_dwordx4 %[w1], %[vo], %[rs], %[so] offen offset:1024"
+                  : [w0] "+v"(wn[0][h]), [w1] "+v"(wn[1][h])
+                  : [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[h])
+                  : "memory");
+            else
+            asm volatile(
+                "s_bitcmp1_b32 %[meta], 20\n\t"
+                "s_cselect_b64 exec, -1, 0\n\t"
+                "buffer_load_dwordx4 %[w0], %[vo], %[rs], %[so] offen\n\t"
+                "buffer_load_dwordx4 %[w1], %[vo], %[rs], %[so] offen offset:1024\n\t"
+                "s_mov_b64 exec, -1"
+                : [w0] "+v"(wn[0][h]), [w1] "+v"(wn[1][h])
+                : [meta] "s"(E1.meta), [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[h])
+                : "memory", "scc");
+          } else if (sp == 2 && h == 0) {
+            load_idx(E2, ioff, pr);  // indices of pass p+2, in place
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_piece(R[0][sp], sp, offn[0], rson);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sp == 0) {  // vector-ALU cluster 2
+          if (DBG & 1) asm volatile("" ::"v"(acc[1][0]), "v"(acc[1][1])); else tile_write(op1, mp1, old[0] + acc[1][0], old[1] + acc[1][1]);
+          E3 = Ent{(unsigned)uni((int)e3v.x), (unsigned)uni((int)e3v.y)};
+          index_offsets(E3, ioffn);
+          asm volatile("" : "+v"(ioffn[0]), "+v"(ioffn[1]));  // (pinned here, not sunk to the end of the pass)
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (sp == 2) {
+          if (!(DBG & 1)) tile_read(orc[0], old);  // group 0 of this pass: its old fragment, added beside group 1
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // group 1 (if the pass has one).  Its row loads and the weight hand-over stay OUTSIDE the branch: a variable that
-      // both sides of a branch redefine is copied at the join (hipcc), and these registers have loads in flight.
+      // ---- group 1 (if the pass has one).  Its row loads stay OUTSIDE the branch: a variable that both sides of a branch
+      // redefine is copied at the join (hipcc), and these registers have loads in flight.
 #pragma unroll
       for (int sp = 0; sp < NS16; ++sp) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1293,48 +1317,40 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
             const float bv = c == 0 ? R[1][sp].x : c == 1 ? R[1][sp].y : c == 2 ? R[1][sp].z : R[1][sp].w;
             if (sp == 0 && c == 0) acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             else acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[1][q], 0, 0, 0);
-            if (sp == 0 && (h == 3 || h == 5)) {  // group 0 -> output tile: add, write (its MFMAs ended 4 MFMAs ago)
-              __builtin_amdgcn_sched_barrier(0);
-              asm volatile("" : "+v"(old[h == 3 ? 0 : 1]));  // (keeps hipcc from hoisting the add above the branch, right behind the MFMAs)
-              if (DBG & 1) asm volatile("" ::"v"(acc[0][h == 3 ? 0 : 1])); else *tile_ptr(orc[0], h == 3 ? 0 : 1) = old[h == 3 ? 0 : 1] + acc[0][h == 3 ? 0 : 1];
-              __builtin_amdgcn_sched_barrier(0);
-            }
           }
-        } else if (sp == 0) {
-#pragma unroll
-          for (int q = 0; q < COS; ++q) { if (DBG & 1) asm volatile("" ::"v"(acc[0][q])); else *tile_ptr(orc[0], q) = old[q] + acc[0][q]; }
         }
         __builtin_amdgcn_sched_barrier(0);
         load_piece(R[1][sp], sp, offn[1], rson);
-        if (sp == 0) {  // the weights requested in gaps 8-11 have landed (6 younger loads)
-          __builtin_amdgcn_sched_barrier(0);
-          if (!NOWAIT) asm volatile("s_waitcnt vmcnt(6)" ::"v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]), "v"(wn[0][3]),
-                       "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]) : "memory");
-        }
         __builtin_amdgcn_sched_barrier(0);
+        if (sp == 0) {  // vector-ALU cluster 3: group 0 -> output tile (its MFMAs ended eight MFMAs ago, if there is a group 1)
+          if (DBG & 1) asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1])); else tile_write(orc[0], mc[0], old[0] + acc[0][0], old[1] + acc[0][1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      if ((E1.meta >> 20) & 1u) {  // the next pass starts a phase: its weights become current
-#pragma unroll
-        for (int q = 0; q < COS; ++q)
-#pragma unroll
-          for (int sp = 0; sp < NS16; ++sp) wc[q][sp] = wn[q][sp];
-      }
-      op1 = orc[1];
-      orc[0] = orn[0];
-      orc[1] = orn[1];
-      ioff[0] = ioffn[0];
-      ioff[1] = ioffn[1];
+      op1 = orc[1]; mp1 = mc[1];
+      orc[0] = orn[0]; orc[1] = orn[1];
+      mc[0] = mn0; mc[1] = mn1;
+      ioff[0] = ioffn[0]; ioff[1] = ioffn[1];
       E0 = E1; E1 = E2; E2 = E3;
       ++pnext;
+    };
+    // The pass loop, once per role of the two weight sets; a copy runs the passes of ONE phase and hands over.  Past the
+    // end of the table the passes are empty ones (no lane writes), so the second copy may run one of those.
+    do {
+      do { pass(wA, wB); } while (rem(E0) > 0 && !((E0.meta >> 20) & 1u));
+      do { pass(wB, wA); } while (rem(E0) > 0 && !((E0.meta >> 20) & 1u));
     } while (rem(E0) > 0);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS6(R), "v"(pr[0]), "v"(pr[1]), "v"(wn[0][0]), "v"(wn[0][1]), "v"(wn[0][2]), "v"(wn[0][3]),
-                 "v"(wn[1][0]), "v"(wn[1][1]), "v"(wn[1][2]), "v"(wn[1][3]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS6(R), "v"(pr[0]), "v"(pr[1]), SCN_W6(wA), SCN_W6(wB) : "memory");
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < COS; ++q) *tile_ptr(op1, q) += acc[1][q];  // group 1 of the last pass
+    {  // group 1 of the last pass
+      floatx4 old[COS];
+      tile_read(op1, old);
+      tile_write(op1, mp1, old[0] + acc[1][0], old[1] + acc[1][1]);
+    }
   }
 #undef SCN_ROWS6
+#undef SCN_W6
   // each wave stores its own 32 planes: no barrier needed
   const int rows = (int)min((int64_t)M, n_out - o0);
   float *dst = out + (int64_t)blockIdx.y * n_out * Co;
@@ -2026,40 +2042,54 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int b = 0; b < TJ; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // Staging is software pipelined and branch free: the pair indices of step s+2 and the rows of step
-  // s+1 are requested into registers before the MFMAs of step s; rows past the end of the chunk are
-  // clamped to its last pair and multiplied by zero.
+  // Staging is software pipelined: the pair indices of step s+2 and the rows of step s+1 are requested into registers
+  // before the MFMAs of step s.  Beside f32 MFMAs every vector-ALU instruction costs 8-12 cycles of matrix-pipe time
+  // (tools/mfma_probe.py), and the first version of this loop issued one per MFMA (64-bit pair addresses, a clamp per
+  // pair, rows past the end multiplied by zero).  Now: pair indices through a buffer load whose per-lane offset is a
+  // constant and whose step offset is scalar (no clamp: what lies behind a list is never used), one v_mad_u32_u24 per
+  // row load, and rows past the end of the chunk -- only the LAST step of a chunk can have any -- are fetched from an
+  // out-of-range offset (the range check returns zeros) instead of being multiplied by zero.
   constexpr int NI = PS * (CIB / 4) / 256;  // 16-byte chunks of input rows per thread and step
   constexpr int ND = PS * (COB / 4) / 256;
   static_assert(NI >= 1 && ND >= 1, "tile too small for 256 threads");
-  int2 pi_[NI], pd_[ND];
+  const __amdgpu_buffer_rsrc_t ru_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)rk, 0, (int)(stride * 8), 0x00020000);
+  unsigned pi_[NI], pd_[ND];  // the input-side / the dOut-side member of the thread's pairs
   floatx4 ri[NI], rd[ND];
+  unsigned pio[NI], pdo[ND], cio[NI], cdo[ND];  // per-lane constants: byte offset of the thread's pair / of its 16-byte chunk
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { pio[j] = (unsigned)((tid + j * 256) / (CIB / 4)) * 8u; cio[j] = (unsigned)((tid + j * 256) % (CIB / 4)) * 16u; }
+#pragma unroll
+  for (int j = 0; j < ND; ++j) { pdo[j] = (unsigned)((tid + j * 256) / (COB / 4)) * 8u; cdo[j] = (unsigned)((tid + j * 256) % (COB / 4)) * 16u; }
+  const unsigned ci4 = (unsigned)Ci * 4u, co4 = (unsigned)Co * 4u;
   auto load_pairs = [&](int pb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) pi_[j] = rk[min(pb + (tid + j * 256) / (CIB / 4), p1 - 1)];
+    for (int j = 0; j < NI; ++j) pi_[j] = __builtin_amdgcn_raw_buffer_load_b32(ru_rsrc, pio[j], pb * 8 + 4 * in_col, 0);
 #pragma unroll
-    for (int j = 0; j < ND; ++j) pd_[j] = rk[min(pb + (tid + j * 256) / (COB / 4), p1 - 1)];
+    for (int j = 0; j < ND; ++j) pd_[j] = __builtin_amdgcn_raw_buffer_load_b32(ru_rsrc, pdo[j], pb * 8 + 4 - 4 * in_col, 0);
   };
-  auto load_rows = [&](int pb) __attribute__((always_inline)) {
+  auto load_rows = [&](int pb, bool partial) __attribute__((always_inline)) {
+    if (!partial) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int idx = tid + j * 256, row = idx / (CIB / 4), ch = idx % (CIB / 4);
-      const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-          in_rsrc, (ABL & 1) ? (unsigned)(ch * 16) : (unsigned)(in_col ? pi_[j].y : pi_[j].x) * (unsigned)(Ci * 4) + (unsigned)(ch * 16), ci0 * 4, 0));
-      ri[j] = v * ((pb + row < p1) ? 1.f : 0.f);
-    }
+      for (int j = 0; j < NI; ++j)
+        ri[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+            in_rsrc, (ABL & 1) ? cio[j] : __umul24(pi_[j], ci4) + cio[j], ci0 * 4, 0));
 #pragma unroll
-    for (int j = 0; j < ND; ++j) {
-      const int idx = tid + j * 256, row = idx / (COB / 4), ch = idx % (COB / 4);
-      const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-          do_rsrc, (ABL & 1) ? (unsigned)(ch * 16) : (unsigned)(in_col ? pd_[j].x : pd_[j].y) * (unsigned)(Co * 4) + (unsigned)(ch * 16), co0 * 4, 0));
-      rd[j] = v * ((pb + row < p1) ? 1.f : 0.f);
+      for (int j = 0; j < ND; ++j)
+        rd[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+            do_rsrc, (ABL & 1) ? cdo[j] : __umul24(pd_[j], co4) + cdo[j], co0 * 4, 0));
+    } else {  // last step of the chunk
+      const unsigned left = (unsigned)(p1 - pb) * 8u;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        ri[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+            in_rsrc, pio[j] < left ? __umul24(pi_[j], ci4) + cio[j] : 0xffffff00u, ci0 * 4, 0));
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+        rd[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+            do_rsrc, pdo[j] < left ? __umul24(pd_[j], co4) + cdo[j] : 0xffffff00u, co0 * 4, 0));
     }
   };
-  load_pairs(p0);
-  load_rows(p0);
-  load_pairs(p0 + PS);
-  for (int pb = p0; pb < p1; pb += PS) {
+  auto stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int idx = tid + j * 256;
@@ -2070,11 +2100,8 @@ __global__ void __launch_bounds__(256)
       const int idx = tid + j * 256;
       *(floatx4 *)(do_t + (idx / (COB / 4)) * DS + (idx % (COB / 4)) * 4) = rd[j];
     }
-    __syncthreads();
-    if (pb + PS < p1) {
-      load_rows(pb + PS);       // indices were requested one step ago
-      load_pairs(pb + 2 * PS);  // clamped: harmless past the end
-    }
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int ps = 0; ps < PS / 4; ++ps) {
       float a[TI], b[TJ];
@@ -2089,8 +2116,33 @@ __global__ void __launch_bounds__(256)
         for (int tb = 0; tb < TJ; ++tb)
           acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
+  };
+  // steps 0 .. S-1 of PS pairs; only step S-1 can be partial.  The loop runs the steps whose successor is full (its
+  // rows are requested without masks), then -- outside, so that no variable is defined on both sides of a branch inside
+  // the loop (hipcc copies those at the join) -- step S-2 with the masked request for step S-1, then step S-1.
+  const int S = (p1 - p0 + PS - 1) / PS;
+  load_pairs(p0);
+  load_rows(p0, S == 1);
+  load_pairs(p0 + PS);
+  int pb = p0;
+  for (; pb < p0 + (S - 2) * PS; pb += PS) {
+    stage();
+    __syncthreads();
+    load_rows(pb + PS, false);  // indices were requested one step ago
+    load_pairs(pb + 2 * PS);
+    compute();
     __syncthreads();
   }
+  if (S >= 2) {
+    stage();
+    __syncthreads();
+    load_rows(pb + PS, true);
+    compute();
+    __syncthreads();
+  }
+  stage();
+  __syncthreads();
+  compute();
   // D[row = ci][col = co]: lane holds rows 4 lq + r, column li
 #pragma unroll
   for (int ta = 0; ta < TI; ++ta)
@@ -2388,7 +2440,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
 }
 
 template <int M>
-constexpr size_t tile6_lds_bytes() { return (size_t)((M + 1) * 68 + (KMAX * (M / 32) * SCN_TILE4_MAX_CHUNKS + 8) * 2) * 4; }
+constexpr size_t tile6_lds_bytes() { return (size_t)(M * 68 + (KMAX * (M / 32) * SCN_TILE4_MAX_CHUNKS + 8) * 2) * 4; }
 
 // rows per tile of a kind-4 launch
 static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ? 96 : 128; }
@@ -2404,29 +2456,39 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   float *dst4 = ksplit > 1 ? part : out;
   const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
   if (M != 128 || g_conv_tile6 == 128) {
-    if (M == 96)
-      k_conv_tile6<96><<<grid4, 128, tile6_lds_bytes<96>() + (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
-                                                  n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
-    else {
-#define SCN_LAUNCH_TILE6(D)                                                                                                       \
-  k_conv_tile6<128, D><<<grid4, 128, tile6_lds_bytes<128>() + (size_t)g_conv_extra_lds, stream>>>(                                 \
-      in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,  \
+#define SCN_LAUNCH_TILE6(MM, IC)                                                                                            \
+  k_conv_tile6<MM, IC><<<grid4, 128, tile6_lds_bytes<MM>() + (size_t)g_conv_extra_lds, stream>>>(                            \
+      in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, n_out, n_gran, Ci, Co, ntiles, ncb,   \
       in_bytes, wp_bytes, ksplit)
+    if (M == 96) { if (in_col) SCN_LAUNCH_TILE6(96, true); else SCN_LAUNCH_TILE6(96, false); }
+    else if (in_col) SCN_LAUNCH_TILE6(128, true);
+    else {
 #ifdef SCN_TUNING
+#define SCN_LAUNCH_TILE6D(D)                                                                                                \
+  k_conv_tile6<128, false, D><<<grid4, 128, tile6_lds_bytes<128>() + (size_t)g_conv_extra_lds, stream>>>(                   \
+      in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, n_out, n_gran, Ci, Co, ntiles, ncb,   \
+      in_bytes, wp_bytes, ksplit)
       switch (g_conv_dbg) {  // timing-only builds (tools/ablate_tile6.py)
-        case 1: SCN_LAUNCH_TILE6(1); break;
-        case 3: SCN_LAUNCH_TILE6(3); break;
-        case 4: SCN_LAUNCH_TILE6(4); break;
-        case 15: SCN_LAUNCH_TILE6(15); break;
-        case 16: SCN_LAUNCH_TILE6(16); break;
-        case 31: SCN_LAUNCH_TILE6(31); break;
-        default: SCN_LAUNCH_TILE6(0);
+        case 1: SCN_LAUNCH_TILE6D(1); break;
+        case 3: SCN_LAUNCH_TILE6D(3); break;
+        case 4: SCN_LAUNCH_TILE6D(4); break;
+        case 14: SCN_LAUNCH_TILE6D(14); break;
+        case 15: SCN_LAUNCH_TILE6D(15); break;
+        case 16: SCN_LAUNCH_TILE6D(16); break;
+        case 20: SCN_LAUNCH_TILE6D(20); break;
+        case 32: SCN_LAUNCH_TILE6D(32); break;
+        case 64: SCN_LAUNCH_TILE6D(64); break;
+        case 96: SCN_LAUNCH_TILE6D(96); break;
+        case 144: SCN_LAUNCH_TILE6D(144); break;
+        case 272: SCN_LAUNCH_TILE6D(272); break;
+        default: SCN_LAUNCH_TILE6D(0);
       }
+#undef SCN_LAUNCH_TILE6D
 #else
-      SCN_LAUNCH_TILE6(0);
+      SCN_LAUNCH_TILE6(128, false);
 #endif
-#undef SCN_LAUNCH_TILE6
     }
+#undef SCN_LAUNCH_TILE6
     SCN_CHECK_LAUNCH();
     return 0;
   }
@@ -2628,7 +2690,9 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_dweight: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_dweight: in_col/out_col must be 0/1 or 1/0");
   if (stride <= 0) return 0;
-  const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 32) || n_dout * Co * 4 >= ((int64_t)1 << 32);
+  // (k_dw_tile: 32-bit byte offsets, row numbers through v_mad_u32_u24, 31-bit byte offsets into one rule list)
+  const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 32) || n_dout * Co * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
+                    n_dout >= (1 << 24) || stride >= (1 << 28);
   if (Ci % 32 == 0 && Co % 32 == 0 && !huge) {
     const unsigned in_bytes = (unsigned)(n_in * Ci * 4), do_bytes = (unsigned)(n_dout * Co * 4);
     // slices per list: enough workgroups per (k, plane block) to fill the chip, few enough that the float atomics of

@@ -75,7 +75,10 @@ __global__ void __launch_bounds__(256) k_mfma_probe(float *sink, const float *sr
     for (int m = 0; m < 64; ++m) {
       const int ai = MODE >= 2 ? (m & 31) : 0, bi = MODE >= 2 ? ((m >> 1) & 15) : 0;
       const int ci = MODE == 1 ? (m & 7) : (m & 1);
-      acc[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ai], b[bi], acc[ci], 0, 0, 0);
+      // 28 / 29: the MFMA itself from inline asm with the accumulator in VGPRs / in AGPRs
+      if (MODE == 28) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[ci]) : "v"(a[ai]), "v"(b[bi]));
+      else if (MODE == 29) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[ci]) : "v"(a[ai]), "v"(b[bi]));
+      else acc[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ai], b[bi], acc[ci], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (MODE == 3) f[m & 3] += 1.0f;
       if (MODE == 4) { f[0] += 1.0f; f[1] += 2.0f; f[2] += 3.0f; }
@@ -176,7 +179,7 @@ int scn_mfma_probe(float *scratch_dev, const float *src_dev, int mode, int waves
     const int n = rep == 0 ? 50 : iters;
     if (rep == 1) SCN_CHECK_HIP(hipEventRecord(e0, stream));
     switch (mode) {
-      SCN_PROBE(0); SCN_PROBE(1); SCN_PROBE(2); SCN_PROBE(3); SCN_PROBE(4); SCN_PROBE(5); SCN_PROBE(6); SCN_PROBE(7); SCN_PROBE(8); SCN_PROBE(9); SCN_PROBE(10); SCN_PROBE(11); SCN_PROBE(12); SCN_PROBE(13); SCN_PROBE(14); SCN_PROBE(15); SCN_PROBE(16); SCN_PROBE(17); SCN_PROBE(18); SCN_PROBE(19); SCN_PROBE(20); SCN_PROBE(21); SCN_PROBE(22); SCN_PROBE(23); SCN_PROBE(24); SCN_PROBE(25); SCN_PROBE(26); SCN_PROBE(27);
+      SCN_PROBE(0); SCN_PROBE(1); SCN_PROBE(2); SCN_PROBE(3); SCN_PROBE(4); SCN_PROBE(5); SCN_PROBE(6); SCN_PROBE(7); SCN_PROBE(8); SCN_PROBE(9); SCN_PROBE(10); SCN_PROBE(11); SCN_PROBE(12); SCN_PROBE(13); SCN_PROBE(14); SCN_PROBE(15); SCN_PROBE(16); SCN_PROBE(17); SCN_PROBE(18); SCN_PROBE(19); SCN_PROBE(20); SCN_PROBE(21); SCN_PROBE(22); SCN_PROBE(23); SCN_PROBE(24); SCN_PROBE(25); SCN_PROBE(26); SCN_PROBE(27); SCN_PROBE(28); SCN_PROBE(29);
       default: return fail(2, "scn_mfma_probe: unknown mode%s", "");
     }
   }

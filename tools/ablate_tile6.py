@@ -11,7 +11,10 @@ from occuseg_amd import SCN, _lib, scenes
 from tools.ab_tile6 import timeit
 
 NAMES = {0: "full", 1: "no tile update", 3: "no tile update, no row loads, no waits", 4: "no weight loads, no waits",
-         15: "MFMAs + skeleton", 16: "pieces before the first MFMA", 31: "MFMAs + skeleton, pieces first"}
+         14: "no loads, no waits", 15: "MFMAs + skeleton", 16: "all loads, no waits", 20: "no weight loads, no waits",
+         32: "weight loads never masked", 64: "tile writes never masked", 96: "neither masked (EXEC never written)",
+         512: "accumulators in AGPRs", 528: "accumulators in AGPRs, no waits",
+         144: "no waits, half of the weight loads", 272: "no waits, weight loads of one dword per lane"}
 
 
 def main():
@@ -28,14 +31,14 @@ def main():
         w = torch.randn(27, ci, co, device=dev) * 0.05
         out = torch.empty(0, device=dev)
         flops = 2.0 * rb.total_pairs * ci * co
-        for xl in (0, 15200):
+        for xl in (0,):
             lib.scn_set_tuning(10, xl)
             lib.scn_set_tuning(11, 0)
             lib.scn_set_tuning(1, 0)
             ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
             print("L0 %d->%d  %s waves/SIMD  %-45s %.3f ms %6.1f TF" % (ci, co, "1" if xl else "2", "k_conv_tile4", ms, flops / ms / 1e9), flush=True)
             lib.scn_set_tuning(11, 128)
-            for dbg in (0, 16, 1, 3, 4, 15, 31, 0):
+            for dbg in (0, 512, 16, 528, 0):
                 lib.scn_set_tuning(1, dbg)
                 ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                 print("L0 %d->%d  %s waves/SIMD  %-45s %.3f ms %6.1f TF" % (ci, co, "1" if xl else "2", "tile6: " + NAMES[dbg], ms, flops / ms / 1e9), flush=True)

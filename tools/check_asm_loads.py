@@ -106,6 +106,80 @@ def check_kernel(name, lines):
     return errors
 
 
+def check_kernel_cfg(name, lines):
+    """Path-exact variant (k_conv_tile6: nested pass loops, forward branches around the MFMAs of an absent group): walks the
+    control-flow graph of the emitted kernel from its entry, EVERY path, with the FIFO of outstanding vector-memory loads as
+    part of the state (vmcnt counts loads and stores in issue order); a state is (instruction, FIFO) and is visited once."""
+    code = []       # (line number, text, inside an asm block)
+    label_at = {}
+    in_asm = False
+    for no, ln in enumerate(lines):
+        if "#ASMSTART" in ln:
+            in_asm = True
+            continue
+        if "#ASMEND" in ln:
+            in_asm = False
+            continue
+        s = ln.split(";")[0].strip()
+        if not s:
+            continue
+        m = re.match(r"^(\.L\w+):", s)
+        if m:
+            label_at[m.group(1)] = len(code)
+            continue
+        if s.startswith(".") or s.endswith(":"):
+            continue
+        code.append((no, s, in_asm))
+    errors = {}
+    seen = set()
+    work = [(0, ())]
+    steps = 0
+    while work:
+        pc, fifo = work.pop()
+        while True:
+            if pc >= len(code) or (pc, fifo) in seen:
+                break
+            seen.add((pc, fifo))
+            steps += 1
+            if steps > 4000000:
+                return ["%s: state space too large" % name]
+            no, s, is_asm = code[pc]
+            op, ops = operands(s)
+            is_load = re.match(r"(buffer|global|flat|scratch)_load", op) is not None
+            is_store = re.match(r"(buffer|global|flat|scratch)_(store|atomic)", op) is not None
+            if not (is_asm and (is_load or op == "s_waitcnt")):
+                touched = set()
+                for t in ops:
+                    touched |= regs(t.split(" ")[0])
+                for dst, lno in fifo:
+                    if touched & dst:
+                        errors.setdefault((no, lno), "%s: line %d `%s` touches v%s, target of the load at line %d still in flight"
+                                          % (name, no + 1, s, sorted(touched & dst), lno + 1))
+            if op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", s)
+                if m and len(fifo) > int(m.group(1)):
+                    fifo = fifo[len(fifo) - int(m.group(1)):]
+            elif is_load:
+                fifo = fifo + ((frozenset(regs(ops[0])), no),)
+            elif is_store:
+                fifo = fifo + ((frozenset(), no),)
+            while len(fifo) > 62 and not fifo[0][0]:
+                fifo = fifo[1:]  # (the hardware counter saturates: issue stalls until the oldest store has completed)
+            if len(fifo) > 62:
+                return ["%s: more than 62 vector-memory operations outstanding at line %d" % (name, no + 1)]
+            if op == "s_endpgm":
+                if any(d for d, _ in fifo):
+                    errors.setdefault(("end", pc), "%s: %d loads never waited for" % (name, sum(1 for d, _ in fifo if d)))
+                break
+            if op == "s_branch":
+                pc = label_at[ops[0]]
+                continue
+            if op.startswith("s_cbranch"):
+                work.append((label_at[ops[0]], fifo))
+            pc += 1
+    return list(errors.values())
+
+
 def main():
     args = [a for a in sys.argv[1:] if a != "--tuning"]
     if args:
@@ -120,13 +194,16 @@ def main():
     lines = text.split("\n")
     # (the timing-only instantiations of k_conv_tile6, DBG != 0, drop loads and waits on purpose: not checked)
     starts = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3scn12k_conv_tile[456]\S*:", ln)
-              and not re.match(r"^_ZN3scn12k_conv_tile6ILi\d+ELi[1-9]", ln)]
+              and not re.match(r"^_ZN3scn12k_conv_tile6ILi\d+ELb[01]ELi[1-9]", ln)]
     errors = []
     n = 0
     for st in starts:
         name = lines[st].split(":")[0]
         end = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i])
-        errors += check_kernel(name, lines[st:end + 1])
+        if "k_conv_tile6" in name:
+            errors += check_kernel_cfg(name, lines[st:end + 1])
+        else:
+            errors += check_kernel(name, lines[st:end + 1])
         n += 1
     for e in errors[:40]:
         print("check_asm_loads:", e)
