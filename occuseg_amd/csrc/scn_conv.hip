@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(256)
 // them in FRONT of the wait), nothing but row registers (fixed variables of a 3-way unrolled loop) is in flight over
 // the back edge, and tools/check_asm_loads.py (run by build.py) proves on the emitted assembly that no instruction
 // touches a register with a load in flight.
-template <int DBG = 0>
+template <int DBG = 0, int INCOL = -1>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
 __global__ void __launch_bounds__(128)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
@@ -643,6 +643,14 @@ __global__ void __launch_bounds__(128)
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
+  const bool icol = INCOL < 0 ? in_col != 0 : INCOL != 0;
+  // a * b + c in ONE full-rate instruction (a, b < 2^24); hipcc turns the C expression into v_sub + v_mul_lo_u32 (quarter rate)
+  auto mad24 = [](unsigned a_, unsigned b_, unsigned c_) __attribute__((always_inline)) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a_), "s"(b_), "v"(c_));
+    return r;
+  };
+  const unsigned row_bytes = (unsigned)(Ci * 4), lq16 = (unsigned)(lq * 16), os_u = (unsigned)OS;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ru_rsrc =
@@ -671,6 +679,8 @@ __global__ void __launch_bounds__(128)
   const int g0 = tile * (M / SCN_TILE_GRANULE);
   const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
   const int nch = Ci / CK;
+  unsigned tile0 = 0u - (unsigned)o0 * (unsigned)OS;  // (kept in a VGPR: a VOP3 instruction takes one scalar operand)
+  asm volatile("" : "+v"(tile0));
 
   // each wave initialises ITS 32 planes of the output tile
   for (int i = lane; i < (M + 1) * 8; i += 64) {
@@ -730,10 +740,12 @@ __global__ void __launch_bounds__(128)
   auto addr = [&](const Ent &e, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const unsigned src = in_col ? pr[i].y : pr[i].x;
-      const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
-      off[i] = (16 * i < rem(e) && !(DBG & 2)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
-      orow[i] = (16 * i + li < rem(e)) ? dst * OS : M * OS;
+      // one v_mad_u32_u24 each (rows and sites are < 2^24, conv_plan): beside f32 MFMAs every vector-ALU instruction costs
+      // 8-12 cycles of matrix-pipe time (tools/mfma_probe.py), the quarter-rate 32-bit multiplies no less
+      const unsigned src = icol ? pr[i].y : pr[i].x;
+      const unsigned dst = icol ? pr[i].x : pr[i].y;
+      off[i] = (16 * i < rem(e) && !(DBG & 2)) ? mad24(src, row_bytes, lq16) : OOB;
+      orow[i] = (16 * i + li < rem(e)) ? (int)mad24(dst, os_u, tile0) : M * OS;
     }
   };
   auto weight_scalars = [&](const Ent &e, int (&so)[NS16], unsigned &voff, bool &fresh) __attribute__((always_inline)) {
@@ -790,12 +802,12 @@ __global__ void __launch_bounds__(128)
     // pass p+2 in pr (arrived); E0..E3 = table entries p..p+3; `ioff` = index-load offsets of pass p+3.
     u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
     unsigned off[2], ioff[2];
-    floatx4 rA[2][NS16], rB[2][NS16], rC[2][NS16], wc[COS][NS16], wn[COS][NS16], prev[2][COS];
+    floatx4 rA[2][NS16], rB[2][NS16], rC[2][NS16], wc[COS][NS16], wn[COS][NS16], prev[2][COS], acc[2][COS];
     int o0r[2], o1r[2], o2r[2], op[2] = {M * OS, M * OS};  // output-tile rows of pass p, p+1, p+2, p-1
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < COS; ++q) prev[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < COS; ++q) prev[i][q] = acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
     Ent E1 = entry(1), E2 = entry(2), E3 = entry(3);
     int pnext = 4;  // table index of the entry read during the current pass
     {  // prologue (not overlapped; once per tile)
@@ -830,15 +842,13 @@ __global__ void __launch_bounds__(128)
 
     auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rm)[2][NS16], floatx4 (&rn)[2][NS16]) __attribute__((always_inline)) {
       const bool two = rem(E0) > 16;
-      floatx4 acc[2][COS], old[2][COS];
+      floatx4 old[2][COS];
       Ent E4 = E3;
       int w_so[NS16], rso = 0;
       unsigned w_off = OOB;
       bool w_new = false;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < COS; ++q) acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      // (the accumulators are not zeroed: the first MFMA of a chain takes C = 0; those of an absent second group keep what
+      //  they held, which goes to the sink row)
       // Everything that is not an MFMA of this pass, cut into pieces of a few instructions; piece m is issued right
       // after MFMA m of the first group (16 pieces).  Measured the same as seven larger slots between groups of four
       // MFMAs (MFMA pipe busy 66 % either way, two waves per SIMD): the granularity of the interleave is not what
@@ -847,10 +857,10 @@ __global__ void __launch_bounds__(128)
       auto piece = [&](int m) __attribute__((always_inline)) {
         if (m == 0 || m == 1) {  // row offset / output row of group m of pass p+2 from its (arrived) pair indices
           const int i = m;
-          const unsigned src = in_col ? pr[i].y : pr[i].x;
-          const int dst = (int)((int64_t)(in_col ? pr[i].x : pr[i].y) - o0);
-          off[i] = (16 * i < rem(E2) && !(DBG & 2) && !((DBG & 2048) && w == 1)) ? src * (unsigned)(Ci * 4) + (unsigned)(lq * 16) : OOB;
-          o2r[i] = (16 * i + li < rem(E2)) ? dst * OS : M * OS;
+          const unsigned src = icol ? pr[i].y : pr[i].x;
+          const unsigned dst = icol ? pr[i].x : pr[i].y;
+          off[i] = (16 * i < rem(E2) && !(DBG & 2) && !((DBG & 2048) && w == 1)) ? mad24(src, row_bytes, lq16) : OOB;
+          o2r[i] = (16 * i + li < rem(E2)) ? (int)mad24(dst, os_u, tile0) : M * OS;
           if (m == 1) {
             rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
             w_new = (E1.meta >> 20) & 1u;
@@ -894,7 +904,7 @@ __global__ void __launch_bounds__(128)
             const int q = h & 1;
             const float a = (h >> 1) == 0 ? wc[q][sp].x : (h >> 1) == 1 ? wc[q][sp].y : (h >> 1) == 2 ? wc[q][sp].z : wc[q][sp].w;
             const float bv = (h >> 1) == 0 ? rc[0][sp].x : (h >> 1) == 1 ? rc[0][sp].y : (h >> 1) == 2 ? rc[0][sp].z : rc[0][sp].w;
-            acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[0][q], 0, 0, 0);
+            acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, (sp == 0 && h < 2) ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[0][q], 0, 0, 0);
             if (sp * 8 + h < 16) {
               __builtin_amdgcn_sched_barrier(0);
               if (DBG & 256) t0 = stamp();
@@ -911,8 +921,8 @@ __global__ void __launch_bounds__(128)
       if (two && !(DBG & 16)) {
 #pragma unroll
         for (int sp = 0; sp < NS16; ++sp) {
-          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].x, rc[1][sp].x, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].x, rc[1][sp].x, acc[1][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].x, rc[1][sp].x, sp == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].x, rc[1][sp].x, sp == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[1][1], 0, 0, 0);
           acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].y, rc[1][sp].y, acc[1][0], 0, 0, 0);
           acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].y, rc[1][sp].y, acc[1][1], 0, 0, 0);
           acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].z, rc[1][sp].z, acc[1][0], 0, 0, 0);
@@ -1211,7 +1221,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
 
     // one pass: weights of the current phase in wc; a phase that starts with the NEXT pass gets its weights into wn
-    auto pass = [&](floatx4 (&wc)[COS][NS16], floatx4 (&wn)[COS][NS16]) __attribute__((always_inline)) {
+    // (WNEW: the NEXT pass starts a phase -- or does not exist --: this pass requests its weights, 18 loads instead of 10)
+    auto pass = [&](auto wnew_tag, floatx4 (&wc)[COS][NS16], floatx4 (&wn)[COS][NS16]) __attribute__((always_inline)) {
+      constexpr bool WNEW = decltype(wnew_tag)::value;
       const bool two = rem(E0) > 16;
       unsigned offn[2], orn[2], ioffn[2];
       floatx4 old[COS];
@@ -1234,7 +1246,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
       const u32x2 e3v = *(const u32x2 *)ptab[pnext];
       const int rson = (int)((E1.meta >> 8) & 15u) * (CK * 4);
       const unsigned mn0 = lane_mask(rem(E1), 0), mn1 = lane_mask(rem(E1), 1);
-      weight_offsets(E1, w_so);
+      if (WNEW) weight_offsets(E1, w_so);
       Ent E3 = E2;
       __builtin_amdgcn_sched_barrier(0);
       // ---- group 0.  Between its MFMAs: memory and LDS instructions only, except one vector-ALU cluster after the first
@@ -1243,10 +1255,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
       for (int sp = 0; sp < NS16; ++sp) {
         if (sp > 0) {
           __builtin_amdgcn_sched_barrier(0);
-          if (NOWAIT) {
-          } else if (sp == 1) asm volatile("s_waitcnt vmcnt(9)" ::"v"(R[0][sp]) : "memory");
-          else if (sp == 2) asm volatile("s_waitcnt vmcnt(15)" ::"v"(R[0][sp]) : "memory");
-          else asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[0][sp]) : "memory");
+          if (NOWAIT || sp == 1) {  // (R0[1] has landed with the top wait)
+          } else if (sp == 2 && WNEW) asm volatile("s_waitcnt vmcnt(15)" ::"v"(R[0][sp]) : "memory");  // (index loads not yet issued)
+          else if (sp == 2) asm volatile("s_waitcnt vmcnt(7)" ::"v"(R[0][sp]) : "memory");
+          else if (WNEW) asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[0][sp]) : "memory");
+          else asm volatile("s_waitcnt vmcnt(9)" ::"v"(R[0][sp]) : "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1257,39 +1270,23 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
           if (sp == 0 && c == 0) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           else acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[0][q], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (sp == 1 && h < 4 && !(DBG & 4)) {  // the 8 weight loads of pass p+1, EXEC = 0 unless it starts a phase
-            if ((DBG & 128) && (h & 1)) {  // timing only: half of the weight loads
-            } else if (DBG & 256)  // timing only: one dword per lane instead of four
-              asm volatile(
-                  "buffer_load_dword %[w0], %[vo], %[rs], %[so] offen\n\t"
-                  "buffer_load_dword %[w1], %[vo], %[rs], %[so] offen offset:1024"
-                  : [w0] "+v"(wn[0][h].x), [w1] "+v"(wn[1][h].x)
-                  : [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[h])
-                  : "memory");
-            else if (DBG & 32)  // timing only: always loaded, EXEC never written
-              asm volatile(
-                  "buffer_load_dwordx4 %[w0], %[vo], %[rs], %[so] offen\n\t"
-                  "buffer_load_dwordx4 %[w1], %[vo], %[rs], %[so] offen offset:1024"
-                  : [w0] "+v"(wn[0][h]), [w1] "+v"(wn[1][h])
-                  : [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[h])
-                  : "memory");
-            else
+          if (WNEW && sp == 1 && h < 4 && !(DBG & 4)) {  // the 8 weight loads of the next phase
             asm volatile(
-                "s_bitcmp1_b32 %[meta], 20\n\t"
-                "s_cselect_b64 exec, -1, 0\n\t"
                 "buffer_load_dwordx4 %[w0], %[vo], %[rs], %[so] offen\n\t"
-                "buffer_load_dwordx4 %[w1], %[vo], %[rs], %[so] offen offset:1024\n\t"
-                "s_mov_b64 exec, -1"
+                "buffer_load_dwordx4 %[w1], %[vo], %[rs], %[so] offen offset:1024"
                 : [w0] "+v"(wn[0][h]), [w1] "+v"(wn[1][h])
-                : [meta] "s"(E1.meta), [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[h])
-                : "memory", "scc");
+                : [vo] "v"(wlane), [rs] "s"(wp_rsrc), [so] "s"(w_so[h])
+                : "memory");
           } else if (sp == 2 && h == 0) {
             load_idx(E2, ioff, pr);  // indices of pass p+2, in place
           }
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_piece(R[0][sp], sp, offn[0], rson);
+        if (DBG & 2048) {  // timing only: the two pieces that share a cache line of every row are requested together
+          if (sp & 1) { load_piece(R[0][sp - 1], sp - 1, offn[0], rson); load_piece(R[0][sp], sp, offn[0], rson); }
+        } else if (!(DBG & 1024)) load_piece(R[0][sp], sp, offn[0], rson);
+        else if (sp > 0) load_piece(R[0][sp - 1], sp - 1, offn[0], rson);  // timing only: each reload one run later
         __builtin_amdgcn_sched_barrier(0);
         if (sp == 0) {  // vector-ALU cluster 2
           if (DBG & 1) asm volatile("" ::"v"(acc[1][0]), "v"(acc[1][1])); else tile_write(op1, mp1, old[0] + acc[1][0], old[1] + acc[1][1]);
@@ -1307,7 +1304,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
       for (int sp = 0; sp < NS16; ++sp) {
         __builtin_amdgcn_sched_barrier(0);
-        if (!NOWAIT) asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[1][sp]) : "memory");
+        if (NOWAIT) {
+        } else if (WNEW) asm volatile("s_waitcnt vmcnt(17)" ::"v"(R[1][sp]) : "memory");
+        else asm volatile("s_waitcnt vmcnt(9)" ::"v"(R[1][sp]) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (two) {
 #pragma unroll
@@ -1320,7 +1319,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_piece(R[1][sp], sp, offn[1], rson);
+        if (DBG & 2048) {
+          if (sp & 1) { load_piece(R[1][sp - 1], sp - 1, offn[1], rson); load_piece(R[1][sp], sp, offn[1], rson); }
+        } else if (!(DBG & 1024)) load_piece(R[1][sp], sp, offn[1], rson);
+        else if (sp == 0) load_piece(R[0][3], 3, offn[0], rson);
+        else load_piece(R[1][sp - 1], sp - 1, offn[1], rson);
+        if ((DBG & 1024) && sp == 3) load_piece(R[1][3], 3, offn[1], rson);
         __builtin_amdgcn_sched_barrier(0);
         if (sp == 0) {  // vector-ALU cluster 3: group 0 -> output tile (its MFMAs ended eight MFMAs ago, if there is a group 1)
           if (DBG & 1) asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1])); else tile_write(orc[0], mc[0], old[0] + acc[0][0], old[1] + acc[0][1]);
@@ -1334,11 +1338,15 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
       E0 = E1; E1 = E2; E2 = E3;
       ++pnext;
     };
-    // The pass loop, once per role of the two weight sets; a copy runs the passes of ONE phase and hands over.  Past the
-    // end of the table the passes are empty ones (no lane writes), so the second copy may run one of those.
+    // The pass loop exists four times, in sequence: {passes inside a phase, last pass of a phase} x {role of the two weight
+    // sets}; every copy is straight-line code with its own constants, none is the other side of a branch.  Past the end
+    // of the table the passes are empty ones (no lane writes), so the second half may run one of those.
+    auto last_of_phase = [&]() __attribute__((always_inline)) { return ((E1.meta >> 20) & 1u) != 0u || rem(E1) == 0; };
     do {
-      do { pass(wA, wB); } while (rem(E0) > 0 && !((E0.meta >> 20) & 1u));
-      do { pass(wB, wA); } while (rem(E0) > 0 && !((E0.meta >> 20) & 1u));
+      while (!last_of_phase()) pass(std::false_type{}, wA, wB);
+      pass(std::true_type{}, wA, wB);
+      while (!last_of_phase()) pass(std::false_type{}, wB, wA);
+      pass(std::true_type{}, wB, wA);
     } while (rem(E0) > 0);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS6(R), "v"(pr[0]), "v"(pr[1]), SCN_W6(wA), SCN_W6(wB) : "memory");
@@ -2347,7 +2355,7 @@ static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, in
   auto blocks = [&](int nw) { return ((n_out + 32 * nw - 1) / (32 * nw)) * (int64_t)(Co / (16 * nw)); };
   const int64_t want = 512;
   if (g_conv_variant == 4 && s16 % 4 == 0 && Ci % 64 == 0 && Ci / 64 <= SCN_TILE4_MAX_CHUNKS && blocks(4) >= want &&
-      n_in < (1 << 24) && (int64_t)K * stride * 8 < (int64_t)0x7fffffff) {
+      n_in < (1 << 24) && n_out < (1 << 24) && (int64_t)K * stride * 8 < (int64_t)0x7fffffff) {
     p.kind = 4;
     p.nw = 2;
     return p;
@@ -2455,6 +2463,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
   float *dst4 = ksplit > 1 ? part : out;
   const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
+#ifdef SCN_TUNING  // k_conv_tile6: experimental (tools/ab_tile6.py), not faster than k_conv_tile4
   if (M != 128 || g_conv_tile6 == 128) {
 #define SCN_LAUNCH_TILE6(MM, IC)                                                                                            \
   k_conv_tile6<MM, IC><<<grid4, 128, tile6_lds_bytes<MM>() + (size_t)g_conv_extra_lds, stream>>>(                            \
@@ -2481,6 +2490,8 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
         case 96: SCN_LAUNCH_TILE6D(96); break;
         case 144: SCN_LAUNCH_TILE6D(144); break;
         case 272: SCN_LAUNCH_TILE6D(272); break;
+        case 1040: SCN_LAUNCH_TILE6D(1040); break;
+        case 2064: SCN_LAUNCH_TILE6D(2064); break;
         default: SCN_LAUNCH_TILE6D(0);
       }
 #undef SCN_LAUNCH_TILE6D
@@ -2492,6 +2503,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     SCN_CHECK_LAUNCH();
     return 0;
   }
+#endif
 #define SCN_LAUNCH_TILE4(D)                                                                                         \
   k_conv_tile4<D><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,                     \
                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
@@ -2514,10 +2526,21 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 4096: SCN_LAUNCH_TILE4(4096 + 3); break;  // timing only: no gathers, no tile update, no index loads
     case 4097: SCN_LAUNCH_TILE4(4096 + 11); break;  // ... and no weight loads
     case 8192: SCN_LAUNCH_TILE4(8192); break;  // A/B: unneeded loads point out of range instead of reading offset 0
-    default: SCN_LAUNCH_TILE4(0);
+    default:
+      if (in_col)
+        k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
+                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+      else
+        k_conv_tile4<0, 0><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
+                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
   }
 #else
-  SCN_LAUNCH_TILE4(0);
+  if (in_col)
+    k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
+                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+  else
+    k_conv_tile4<0, 0><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
+                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
 #endif
   }
 #undef SCN_LAUNCH_TILE4

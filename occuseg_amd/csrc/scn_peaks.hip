@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(256) k_mfma_probe(float *sink, const float *sr
       const int ai = MODE >= 2 ? (m & 31) : 0, bi = MODE >= 2 ? ((m >> 1) & 15) : 0;
       const int ci = MODE == 1 ? (m & 7) : (m & 1);
       // 28 / 29: the MFMA itself from inline asm with the accumulator in VGPRs / in AGPRs
-      if (MODE == 28) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[ci]) : "v"(a[ai]), "v"(b[bi]));
-      else if (MODE == 29) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[ci]) : "v"(a[ai]), "v"(b[bi]));
+      // 30-33: 28 / 29 + one L2-hit buffer_load_dwordx4 per 4 MFMAs (30 / 31) or per 2 MFMAs (32 / 33)
+      if (MODE == 28 || MODE == 30 || MODE == 32) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[ci]) : "v"(a[ai]), "v"(b[bi]));
+      else if (MODE == 29 || MODE == 31 || MODE == 33) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[ci]) : "v"(a[ai]), "v"(b[bi]));
       else acc[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ai], b[bi], acc[ci], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (MODE == 3) f[m & 3] += 1.0f;
@@ -87,7 +88,9 @@ __global__ void __launch_bounds__(256) k_mfma_probe(float *sink, const float *sr
       if (MODE == 7 && (m & 3) == 3) asm volatile("ds_read_b128 %0, %1" : "=v"(junk) : "v"(voff) : "memory");
       if (MODE == 8 && (m & 3) == 3)
         asm volatile("s_mov_b64 exec, 0\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen\n\ts_mov_b64 exec, -1" : "+v"(junk) : "v"(voff), "s"(rs) : "memory");
-      if (MODE == 9 && (m & 3) == 3)
+      if ((MODE == 32 || MODE == 33) && (m & 1) == 1)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(junk) : "v"(voff), "s"(rs) : "memory");
+      if ((MODE == 9 || MODE == 30 || MODE == 31) && (m & 3) == 3)
         asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(junk) : "v"(voff), "s"(rs) : "memory");
       // 10-17: one instruction per MFMA
       if (MODE == 10) asm volatile("v_accvgpr_read_b32 %0, a255" : "=v"(f[m & 3]));
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(256) k_mfma_probe(float *sink, const float *sr
       __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(junk) : "memory");
-    if (MODE == 8 || MODE == 9) asm volatile("s_waitcnt vmcnt(0)" ::"v"(junk) : "memory");
+    if (MODE == 8 || MODE == 9 || MODE >= 30) asm volatile("s_waitcnt vmcnt(0)" ::"v"(junk) : "memory");
   }
   floatx4 s = acc[0];
 #pragma unroll
@@ -179,7 +182,7 @@ int scn_mfma_probe(float *scratch_dev, const float *src_dev, int mode, int waves
     const int n = rep == 0 ? 50 : iters;
     if (rep == 1) SCN_CHECK_HIP(hipEventRecord(e0, stream));
     switch (mode) {
-      SCN_PROBE(0); SCN_PROBE(1); SCN_PROBE(2); SCN_PROBE(3); SCN_PROBE(4); SCN_PROBE(5); SCN_PROBE(6); SCN_PROBE(7); SCN_PROBE(8); SCN_PROBE(9); SCN_PROBE(10); SCN_PROBE(11); SCN_PROBE(12); SCN_PROBE(13); SCN_PROBE(14); SCN_PROBE(15); SCN_PROBE(16); SCN_PROBE(17); SCN_PROBE(18); SCN_PROBE(19); SCN_PROBE(20); SCN_PROBE(21); SCN_PROBE(22); SCN_PROBE(23); SCN_PROBE(24); SCN_PROBE(25); SCN_PROBE(26); SCN_PROBE(27); SCN_PROBE(28); SCN_PROBE(29);
+      SCN_PROBE(0); SCN_PROBE(1); SCN_PROBE(2); SCN_PROBE(3); SCN_PROBE(4); SCN_PROBE(5); SCN_PROBE(6); SCN_PROBE(7); SCN_PROBE(8); SCN_PROBE(9); SCN_PROBE(10); SCN_PROBE(11); SCN_PROBE(12); SCN_PROBE(13); SCN_PROBE(14); SCN_PROBE(15); SCN_PROBE(16); SCN_PROBE(17); SCN_PROBE(18); SCN_PROBE(19); SCN_PROBE(20); SCN_PROBE(21); SCN_PROBE(22); SCN_PROBE(23); SCN_PROBE(24); SCN_PROBE(25); SCN_PROBE(26); SCN_PROBE(27); SCN_PROBE(28); SCN_PROBE(29); SCN_PROBE(30); SCN_PROBE(31); SCN_PROBE(32); SCN_PROBE(33);
       default: return fail(2, "scn_mfma_probe: unknown mode%s", "");
     }
   }

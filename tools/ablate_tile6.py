@@ -14,6 +14,7 @@ NAMES = {0: "full", 1: "no tile update", 3: "no tile update, no row loads, no wa
          14: "no loads, no waits", 15: "MFMAs + skeleton", 16: "all loads, no waits", 20: "no weight loads, no waits",
          32: "weight loads never masked", 64: "tile writes never masked", 96: "neither masked (EXEC never written)",
          512: "accumulators in AGPRs", 528: "accumulators in AGPRs, no waits",
+         1040: "no waits, every reload one run later", 2064: "no waits, reloads in pairs that share cache lines",
          144: "no waits, half of the weight loads", 272: "no waits, weight loads of one dword per lane"}
 
 
@@ -38,7 +39,7 @@ def main():
             ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
             print("L0 %d->%d  %s waves/SIMD  %-45s %.3f ms %6.1f TF" % (ci, co, "1" if xl else "2", "k_conv_tile4", ms, flops / ms / 1e9), flush=True)
             lib.scn_set_tuning(11, 128)
-            for dbg in (0, 512, 16, 528, 0):
+            for dbg in (0, 16, 2064, 16, 2064, 0):
                 lib.scn_set_tuning(1, dbg)
                 ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                 print("L0 %d->%d  %s waves/SIMD  %-45s %.3f ms %6.1f TF" % (ci, co, "1" if xl else "2", "tile6: " + NAMES[dbg], ms, flops / ms / 1e9), flush=True)

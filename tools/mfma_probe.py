@@ -17,7 +17,9 @@ MODES = ["2 accumulators, back to back", "8 accumulators", "2 acc, operands from
          "+ 1 s_nop 0 per MFMA", "+ ds_write_b128 of an accumulator per 4 MFMAs",
          "64 VALU per 64 MFMAs: 2 after every 2nd", "64 per 64: 4 after every 4th", "64 per 64: 16 after every 16th", "64 per 64: 64 after the 64th",
          "32 per 64: 1 after every 2nd", "16 per 64: 1 after every 4th", "16 per 64: 16 after the 64th", "16 v_pk_add_f32 per 64, after the 64th",
-         "asm MFMA, accumulators in VGPRs", "asm MFMA, accumulators in AGPRs"]
+         "asm MFMA, accumulators in VGPRs", "asm MFMA, accumulators in AGPRs",
+         "acc in VGPRs + buffer_load_dwordx4 per 4 MFMAs", "acc in AGPRs + buffer_load_dwordx4 per 4 MFMAs",
+         "acc in VGPRs + buffer_load_dwordx4 per 2 MFMAs", "acc in AGPRs + buffer_load_dwordx4 per 2 MFMAs"]
 ONLY = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else None
 
 if __name__ == "__main__":
