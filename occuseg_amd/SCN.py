@@ -9,6 +9,7 @@ Everything here is host-side plumbing (torch owns device memory and streams);
 all arithmetic and all rulebook construction happens in libscn_hip.so through
 the C ABI of include/scn_hip.h.  CPU tensors are refused: there is no CPU path.
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -559,6 +560,74 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                   (K, n_out, Ci, Co, int(w_transposed), in_col))
 
 
+# ---- dWeight on a second HIP stream.  dInput and dWeight of a layer both consume dOut and nothing in backward consumes
+# dWeight, so inside an autograd backward pass the dWeight kernel is launched on a side stream: it starts when the dInput
+# kernel (whose workgroups hold all the LDS of a CU) drains -- filling the tail in which the last tiles run on a mostly
+# idle chip -- and keeps running beside the batch-norm backward and the elementwise kernels that follow, which are
+# HBM-bound.  The main stream waits for the side stream at the end of the backward pass (autograd final callback) and
+# before a gradient bucket is all-reduced (dw_join, occuseg_amd/dp.py).  Outside autograd (the boundary functions called
+# directly, as the reference's C++ would) everything stays on the caller's stream.
+# Only when the CALLER says nothing reads dWeight before the end of the backward pass (`dw_async`): the convolution
+# modules do when they accumulate straight into a gradient buffer they own (occuseg_amd.dp.FlatGradBucket) and return no
+# gradient to autograd; on the plain autograd path AccumulateGrad reads the returned tensor at once, on the main stream.
+DW_SIDE_STREAM = True   # A/B switch (tools/ab_step.py DW_SIDE_STREAM=0,1)
+_DW_STATE = {}          # device index -> [stream, last event or None, callback queued]
+_DW_ALLOW = [False]
+
+
+@contextlib.contextmanager
+def dw_async(allowed):
+    """inside: the backward boundary functions may leave their dWeight kernel running on the side stream"""
+    before = _DW_ALLOW[0]
+    _DW_ALLOW[0] = bool(allowed)
+    try:
+        yield
+    finally:
+        _DW_ALLOW[0] = before
+
+
+def _dw_side_begin(*tensors):
+    if not (DW_SIDE_STREAM and _DW_ALLOW[0]):
+        return None
+    dev = tensors[0].device
+    st = _DW_STATE.get(dev.index)
+    if st is None:
+        st = _DW_STATE[dev.index] = [torch.cuda.Stream(device=dev), None, False]
+    if not st[2]:
+        try:  # only inside a backward pass: this is what makes the main stream wait for the side stream at its end
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: _dw_finish(dev.index))
+        except RuntimeError:
+            return None
+        st[2] = True
+    side = st[0]
+    side.wait_stream(torch.cuda.current_stream(dev))  # dOut, the zeroed dW, the saved input: produced on the main stream
+    for t in tensors:
+        t.record_stream(side)  # (the caching allocator must not hand their memory out before the side stream is done)
+    return side
+
+
+def _dw_side_end(side):
+    st = _DW_STATE[side.device.index]
+    ev = torch.cuda.Event()
+    ev.record(side)
+    st[1] = ev
+
+
+def dw_join(device=None):
+    """make the current stream wait for every dWeight kernel launched so far (called before gradients are consumed)"""
+    for idx, st in _DW_STATE.items():
+        if st[1] is not None and (device is None or device.index is None or device.index == idx):
+            torch.cuda.current_stream(torch.device("cuda", idx)).wait_event(st[1])
+
+
+def _dw_finish(idx):
+    st = _DW_STATE[idx]
+    st[2] = False
+    if st[1] is not None:
+        torch.cuda.current_stream(torch.device("cuda", idx)).wait_event(st[1])
+        st[1] = None
+
+
 def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse):
     """d_in = gather-mm-scatter of d_out with the transposed weights; dW; d_bias."""
     lib = _lib_()
@@ -572,13 +641,17 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
         else:
             _conv(d_out, d_in, weight, None, rb, out_col, in_col, n_in, True, False)
     if d_weight is not None and d_weight.numel():
-        ev = _prof_begin()
-        check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts),
-                                   ptr(rb.bases.get(out_col)), K, rb.stride, in_col, out_col, inp.size(0),
-                                   d_out.size(0), Ci, Co, stream()))
-        R = rb.total_pairs
-        _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else "dw_narrow", 2.0 * R * Ci * Co,
-                  4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
+        side = _dw_side_begin(inp, d_out, d_weight)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            ev = _prof_begin()
+            check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts),
+                                       ptr(rb.bases.get(out_col)), K, rb.stride, in_col, out_col, inp.size(0),
+                                       d_out.size(0), Ci, Co, stream()))
+            R = rb.total_pairs
+            _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else "dw_narrow", 2.0 * R * Ci * Co,
+                      4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
+        if side is not None:
+            _dw_side_end(side)
     if d_bias is not None and d_bias.numel():
         check(lib.scn_column_sum(ptr(d_out), ptr(d_bias), d_out.size(0), Co, stream()))
 

@@ -29,7 +29,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KMAX = 27;
-constexpr int SCN_TILE4_MAX_CHUNKS = 5;  // k_conv_tile4: C_i <= 320 (pass table in LDS)
+constexpr int SCN_TILE4_MAX_CHUNKS = 6;  // k_conv_tile4: C_i <= 384 (pass table in LDS: 35.1 + 5.2 KB = four workgroups per CU, to the byte)
 
 // diagnostic build only (DBG bit 8 = 256): per-segment cycle sums of the pipelined kernel, added from
 // lane 0 of every wave at kernel end into a buffer nothing else reads (scn_debug_stamps copies it out).

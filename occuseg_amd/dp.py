@@ -24,6 +24,8 @@ import warnings
 import torch
 import torch.distributed as dist
 
+from . import SCN
+
 
 class FlatGradBucket(object):
     def __init__(self, params, n_buckets=4):
@@ -156,6 +158,7 @@ class FlatGradBucket(object):
         if not self._distributed():
             return
         start, end = self.buckets[b][:2]
+        SCN.dw_join()  # dWeight kernels run on a side stream (occuseg_amd/SCN.py): the exchange must see their result
         self._work.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, async_op=True))
 
     def zero(self):

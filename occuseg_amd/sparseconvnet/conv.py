@@ -71,15 +71,18 @@ class _RuleConvFunction(Function):
         grad_weight = weight.grad if direct else torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
         m = ctx.scn_meta
-        if ctx.kind == "submanifold":
-            SCN.SubmanifoldConvolution_backward(in_size, filter_size, m, features, grad_input, grad_output, weight,
-                                                grad_weight, grad_bias, ctx.dilated_rate)
-        elif ctx.kind == "conv":
-            SCN.Convolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
-                                     grad_output, weight, grad_weight, grad_bias)
-        else:
-            SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
-                                       grad_output, weight, grad_weight, grad_bias)
+        # direct accumulation: nothing reads the weight gradient before the end of the backward pass, so the dWeight
+        # kernel may run on a side stream beside what follows (SCN.dw_async)
+        with SCN.dw_async(direct):
+            if ctx.kind == "submanifold":
+                SCN.SubmanifoldConvolution_backward(in_size, filter_size, m, features, grad_input, grad_output, weight,
+                                                    grad_weight, grad_bias, ctx.dilated_rate)
+            elif ctx.kind == "conv":
+                SCN.Convolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
+                                         grad_output, weight, grad_weight, grad_bias)
+            else:
+                SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
+                                           grad_output, weight, grad_weight, grad_bias)
         ctx.scn_meta = None
         if direct:
             owner.grad_written(weight)
