@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(256)
 // the back edge, and tools/check_asm_loads.py (run by build.py) proves on the emitted assembly that no instruction
 // touches a register with a load in flight.
 template <int DBG = 0, int INCOL = -1>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (<= 256 registers: hipcc then keeps the accumulators in VGPRs, no v_accvgpr_read)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
@@ -799,15 +799,17 @@ __global__ void __launch_bounds__(128)
   Ent E0 = entry(0);
   if (rem(E0) > 0) {
     // ---- pipeline state at the top of pass p: rows(p) in rc, rows(p+1) in rm (arrived), weights(p) in wc, indices of
-    // pass p+2 in pr (arrived); E0..E3 = table entries p..p+3; `ioff` = index-load offsets of pass p+3.
+    // pass p+2 in pr (arrived); E0..E3 = table entries p..p+3; `ioff` = index-load offsets of pass p+3; acc[1] / op1 =
+    // result and output-tile rows of the second group of pass p-1, not yet in the tile (the accumulators are never copied:
+    // group 1 goes to the tile beside group 0 of the next pass, group 0 beside group 1 of its own).
     u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
     unsigned off[2], ioff[2];
-    floatx4 rA[2][NS16], rB[2][NS16], rC[2][NS16], wc[COS][NS16], wn[COS][NS16], prev[2][COS], acc[2][COS];
-    int o0r[2], o1r[2], o2r[2], op[2] = {M * OS, M * OS};  // output-tile rows of pass p, p+1, p+2, p-1
+    floatx4 rA[2][NS16], rB[2][NS16], rC[2][NS16], wc[COS][NS16], wn[COS][NS16], acc[2][COS];
+    int o0r[2], o1r[2], o2r[2], op1 = M * OS;  // output-tile rows of pass p, p+1, p+2; of group 1 of pass p-1
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < COS; ++q) prev[i][q] = acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < COS; ++q) acc[i][q] = floatx4{0.f, 0.f, 0.f, 0.f};
     Ent E1 = entry(1), E2 = entry(2), E3 = entry(3);
     int pnext = 4;  // table index of the entry read during the current pass
     {  // prologue (not overlapped; once per tile)
@@ -869,8 +871,10 @@ __global__ void __launch_bounds__(128)
           if (w_new) weight_scalars(E1, w_so, w_off, w_new);  // the row loads, so the vmcnt(8) below is right either way
         } else if (m >= 3 && m <= 6) {
           if (w_new) load_weights(m - 3, w_off, w_so[m - 3], wn);
-        } else if (m == 7) {
-          tile_rows(old, op);
+        } else if (m == 7) {     // group 1 of the previous pass -> output tile: read its rows ...
+#pragma unroll
+          for (int q = 0; q < COS; ++q)
+            if (!(DBG & 1)) old[1][q] = *(const floatx4 *)__builtin_assume_aligned(o_tile + op1 + 32 * w + 16 * q + 4 * lq, 16);
         } else if (m == 8) {     // indices of pass p+3 (pr was consumed by pieces 0-1)
           load_idx(E3, ioff, pr);
         } else if (m >= 9 && m <= 12) {  // rows of pass p+2: the long-latency gathers, in flight until the end of pass p+1
@@ -882,16 +886,19 @@ __global__ void __launch_bounds__(128)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rn[i][0]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rn[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
           }
-        } else if (m == 13 || m == 14) {  // read-add-write of pass p-1, one group per piece
-          const int i = m - 13;
+        } else if (m == 13) {    // ... add, write (its accumulators are free again before this pass's second group starts)
 #pragma unroll
           for (int q = 0; q < COS; ++q) {
             if (DBG & 1) {
-              asm volatile("" ::"v"(prev[i][q]));
+              asm volatile("" ::"v"(acc[1][q]));
             } else {
-              *(floatx4 *)__builtin_assume_aligned(o_tile + op[i] + 32 * w + 16 * q + 4 * lq, 16) = old[i][q] + prev[i][q];
+              *(floatx4 *)__builtin_assume_aligned(o_tile + op1 + 32 * w + 16 * q + 4 * lq, 16) = old[1][q] + acc[1][q];
             }
           }
+        } else if (m == 14) {    // group 0 of THIS pass: read its rows (added and written beside the second group's MFMAs)
+#pragma unroll
+          for (int q = 0; q < COS; ++q)
+            if (!(DBG & 1)) old[0][q] = *(const floatx4 *)__builtin_assume_aligned(o_tile + o0r[0] + 32 * w + 16 * q + 4 * lq, 16);
         } else if (m == 15) {    // table entry p+4
           E4 = entry(pnext);
         }
@@ -918,9 +925,25 @@ __global__ void __launch_bounds__(128)
 #pragma unroll
         for (int m = 0; m < 16; ++m) piece(m);
       }
+      auto write_group0 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < COS; ++q) {
+          if (DBG & 1) {
+            asm volatile("" ::"v"(acc[0][q]));
+          } else {
+            *(floatx4 *)__builtin_assume_aligned(o_tile + o0r[0] + 32 * w + 16 * q + 4 * lq, 16) = old[0][q] + acc[0][q];
+          }
+        }
+      };
+      if (!two || (DBG & 16)) write_group0();
       if (two && !(DBG & 16)) {
 #pragma unroll
         for (int sp = 0; sp < NS16; ++sp) {
+          if (sp == 1) {  // eight MFMAs behind the end of group 0: its result has landed
+            __builtin_amdgcn_sched_barrier(0);
+            write_group0();
+            __builtin_amdgcn_sched_barrier(0);
+          }
           acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].x, rc[1][sp].x, sp == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[1][0], 0, 0, 0);
           acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[1][sp].x, rc[1][sp].x, sp == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[1][1], 0, 0, 0);
           acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[0][sp].y, rc[1][sp].y, acc[1][0], 0, 0, 0);
@@ -937,12 +960,9 @@ __global__ void __launch_bounds__(128)
       asm volatile("s_waitcnt vmcnt(8)" ::SCN_ROWS(rm), SCN_ROWS(wn), "v"(pr[0]), "v"(pr[1]) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (DBG & 256) seg[4] += 1;
+      op1 = o0r[1];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int q = 0; q < COS; ++q) prev[i][q] = acc[i][q];
-        op[i] = o0r[i]; o0r[i] = o1r[i]; o1r[i] = o2r[i];
-      }
+      for (int i = 0; i < 2; ++i) { o0r[i] = o1r[i]; o1r[i] = o2r[i]; }
       if (w_new) {
 #pragma unroll
         for (int q = 0; q < COS; ++q)
@@ -961,10 +981,10 @@ __global__ void __launch_bounds__(128)
     } while (rem(E0) > 0);
     // the (dummy) row prefetches of the passes past the end
     asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS(rA), SCN_ROWS(rB), SCN_ROWS(rC) : "memory");
-    {  // result of the last pass
-      floatx4 old[2][COS];
-      tile_rows(old, op);
-      scatter(prev, old, op);
+    if (!(DBG & 1)) {  // group 1 of the last pass
+#pragma unroll
+      for (int q = 0; q < COS; ++q)
+        *(floatx4 *)__builtin_assume_aligned(o_tile + op1 + 32 * w + 16 * q + 4 * lq, 16) += acc[1][q];
     }
   }
 #undef SCN_ROWS

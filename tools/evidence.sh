@@ -6,6 +6,7 @@
 #   3. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)        -> traffic.json (tools/pmc_traffic.py)
 #   4. rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES (in-step clock and MFMA-pipe occupancy per kernel)
 #   5. PMC groups on the isolated gather-mm layers (tools/pmc_groups.sh)      -> pmc_conv_tile4.txt
+#   6. MFMA issue probe, occupancy probe, kernel A/Bs                          -> mfma_probe.txt, occupancy_probe.txt, ab_*.txt
 # --pmc runs use --kernel-trace only (the pool refuses PMC together with the hip/hsa trace domains).
 set -u
 E=gpurun_out/evidence
@@ -23,6 +24,11 @@ python3 tools/pmc_instep.py $E/clock > $E/instep_clock.txt 2>&1
 bash tools/pmc_groups.sh 1 $E/pmc_tile4
 python3 tools/pmc_summary.py $E/pmc_tile4 k_conv_tile4 > $E/pmc_conv_tile4.txt 2>&1
 python3 tools/pmc_summary.py $E/pmc_tile4 k_dw_tile > $E/pmc_dw_tile.txt 2>&1
+# 6. what an instruction beside an f32 MFMA costs; occupancy probe of k_conv_tile4; k_conv_tile6 against k_conv_tile4
+python3 tools/mfma_probe.py > $E/mfma_probe.txt 2>&1
+python3 tools/bench_conv.py --levels 0,1 --variants 4 --extra-lds 0,2000,15200 > $E/occupancy_probe.txt 2>&1
+python3 tools/ab_tile6.py --rounds 2 > $E/ab_tile6.txt 2>&1
+python3 tools/ab_step.py DW_SIDE_STREAM=0,1 > $E/ab_dw_side_stream.txt 2>&1
 # keep the merge small: raw traces stay on the box
 find $E -name "*.db" -delete
 find $E -name "*kernel_trace.csv" -size +2M -delete
