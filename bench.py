@@ -139,6 +139,9 @@ def main():
                          "the queue between two kernels: ~1200 of them cost a profiled step ~25 ms)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="build each step's rulebooks inside the step instead of one step ahead on a side stream")
+    ap.add_argument("--no-dw-side-stream", action="store_true",
+                    help="keep the dWeight kernels on the main stream in every step (kernel durations in a profile of this "
+                         "command are then exclusive ones, as on the steps whose launches carry events)")
     ap.add_argument("--same-batch", action="store_true", help="replay ONE batch (round-1 behaviour) instead of alternating two")
     ap.add_argument("--dump-launches", default=None, help="write per-launch timings (kernel, shape, ms) to this JSON file")
     args = ap.parse_args()
@@ -212,6 +215,8 @@ def main():
     # therefore timed in ONE extra step after the timed region.  One more event per step (end of step, main stream)
     # gives the per-step durations for the median.
     prof, prof_extra = [], []
+    dw_side = bool(SCN.DW_SIDE_STREAM) and not args.no_dw_side_stream
+    SCN.DW_SIDE_STREAM = dw_side
     SCN.PROFILE_KINDS = ("mm",)
     if rank == 0:  # ~230 events per profiled step (matrix launches) + ~900 for the extra step, created now
         SCN.warm_event_pool(260 * len(range(0, args.steps, args.event_every)) + 1000)
@@ -223,10 +228,15 @@ def main():
     marks[0].record()
     for i in range(args.steps):
         SCN.PROFILE = prof if (i % args.event_every == 0 and rank == 0) else None
+        # dWeight normally runs on a side stream beside the kernels that follow it: two kernels
+        # sharing the chip both take longer, so on the steps whose launches carry events it stays on the main stream and the
+        # per-kernel durations are EXCLUSIVE ones (every rank does the same: the steps stay aligned)
+        SCN.DW_SIDE_STREAM = dw_side and (i % args.event_every != 0)
         step()
         marks[i + 1].record()
         sites_done += n_sites[(first + i) % len(batches)]
     SCN.PROFILE = None
+    SCN.DW_SIDE_STREAM = False  # (the extra step below measures exclusive durations too)
     barrier()
     dt = time.perf_counter() - t0
     # the extra, untimed step (every rank runs it: it holds collectives): events on batch norm, rule build, io launches
@@ -336,7 +346,11 @@ def main():
                     "traffic_source": traffic_note,
                     "launches_per_step": cnt / sampled, "avg_launch_ms": 1e3 * secs / cnt,
                     "algo_flops_per_launch": flops / cnt, "algo_bytes_per_launch": nbytes / cnt,
-                    "algo_GBs": nbytes / secs / 1e9, "hbm_frac_of_8TBs": nbytes / secs / 1e9 / HBM_PEAK_GBS}
+                    "algo_GBs": nbytes / secs / 1e9, "hbm_frac_of_8TBs": nbytes / secs / 1e9 / HBM_PEAK_GBS,
+                    "durations": ("exclusive: on the %d of %d timed steps whose launches carry events the dWeight kernels run on "
+                                  "the main stream; on the others they overlap the kernels that follow them on a side stream "
+                                  "(dw_side_stream=%s), where two kernels sharing the chip both take longer"
+                                  % (sampled, args.steps, dw_side))}
             if peaks:
                 roof["peak_measured"] = peaks["f32_mfma_tflops"]
                 roof["frac_of_measured"] = achieved / peaks["f32_mfma_tflops"]
@@ -360,7 +374,8 @@ def main():
                        "active_voxels_per_batch": n_sites, "parameters": n_params,
                        "parallelism": "dp%d" % world, "allreduce_bytes": 4 * n_params if world > 1 else 0,
                        "backend": backend if world > 1 else None,
-                       "rulebook_prefetch": bool(args.prefetch), "source_hash": source_hash()},
+                       "rulebook_prefetch": bool(args.prefetch), "dweight_side_stream": dw_side,
+                       "source_hash": source_hash()},
             "roofline": roof, "kernels": kernels, "peaks_measured": peaks,
         }
         if args.dump_launches:
