@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a_), "s"(b_), "v"(c_));
     return r;
   };
-  const unsigned row_bytes = (unsigned)(Ci * 4), lq16 = (unsigned)(lq * 16), os_u = (unsigned)OS;
+  const unsigned row_bytes = (unsigned)(Ci * 4), lq16 = (unsigned)(lq * 16), os_u = (unsigned)(OS * 4);
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ru_rsrc =
@@ -679,8 +679,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int g0 = tile * (M / SCN_TILE_GRANULE);
   const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
   const int nch = Ci / CK;
-  unsigned tile0 = 0u - (unsigned)o0 * (unsigned)OS;  // (kept in a VGPR: a VOP3 instruction takes one scalar operand)
+  // output-tile BYTE address of (row dst, this lane's first plane) = dst * (OS * 4) + tile0, modulo 2^32: dst - o0 is what
+  // counts (kept in a VGPR: a VOP3 instruction takes one scalar operand)
+  typedef __attribute__((address_space(3))) floatx4 lds_floatx4;
+  unsigned tile0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)o_tile + (unsigned)(32 * w + 4 * lq) * 4u -
+                   (unsigned)o0 * (unsigned)(OS * 4);
   asm volatile("" : "+v"(tile0));
+  const unsigned li8[2] = {(unsigned)li * 8u, (unsigned)(li + 16) * 8u};  // byte offset of the lane's pair within a pass
 
   // each wave initialises ITS 32 planes of the output tile
   for (int i = lane; i < (M + 1) * 8; i += 64) {
@@ -734,7 +739,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // per-lane byte offsets of a pass's two index loads
   auto index_offsets = [&](const Ent &e, unsigned (&vo)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) vo[i] = (16 * i < rem(e) && !(DBG & 4096)) ? (unsigned)min(16 * i + li, rem(e) - 1) * 8u : OOB;
+    for (int i = 0; i < 2; ++i) {  // the lane's pair, clamped to the last pair of the list: lanes past the end (a whole absent
+      // second group too) repeat it -- rows that are in the cache anyway -- and are masked out of the output-tile write;
+      // rem == 0 (no such pass): no clamp, the first pairs of `rules`
+      if (DBG & 4096) vo[i] = OOB;
+      else vo[i] = min(li8[i], (unsigned)(rem(e) - 1) * 8u);
+    }
   };
   // row byte offsets / output-tile rows of a pass from its pair indices
   auto addr = [&](const Ent &e, const u32x2 (&pr)[2], unsigned (&off)[2], int (&orow)[2]) __attribute__((always_inline)) {
@@ -744,8 +754,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       // 8-12 cycles of matrix-pipe time (tools/mfma_probe.py), the quarter-rate 32-bit multiplies no less
       const unsigned src = icol ? pr[i].y : pr[i].x;
       const unsigned dst = icol ? pr[i].x : pr[i].y;
-      off[i] = (16 * i < rem(e) && !(DBG & 2)) ? mad24(src, row_bytes, lq16) : OOB;
-      orow[i] = (16 * i + li < rem(e)) ? (int)mad24(dst, os_u, tile0) : M * OS;
+      off[i] = (DBG & 2) ? OOB : mad24(src, row_bytes, lq16);
+      orow[i] = (int)mad24(dst, os_u, tile0);
     }
   };
   auto weight_scalars = [&](const Ent &e, int (&so)[NS16], unsigned &voff, bool &fresh) __attribute__((always_inline)) {
@@ -754,7 +764,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int blk = (k * (Ci / 16) + chn * (CK / 16)) * (Co / 16) + co0 / 16 + w * COS;
 #pragma unroll
     for (int sp = 0; sp < NS16; ++sp) so[sp] = (blk + sp * (Co / 16)) * 1024;
-    voff = (fresh && !(DBG & 8)) ? (unsigned)lane * 16u : OOB;
+    voff = (DBG & 8) ? OOB : (unsigned)lane * 16u;  // (the loads themselves are conditional)
   };
   auto load_idx = [&](const Ent &e, const unsigned (&vo)[2], u32x2 (&pr)[2]) __attribute__((always_inline)) {
     const int base = (int)e.base;
@@ -794,6 +804,38 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         //  ds_read2_b32 / ds_write2_b32 per fragment instead of one ds_read_b128 / ds_write_b128)
         if (!(DBG & 1)) old[i][q] = *(const floatx4 *)__builtin_assume_aligned(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq, 16);
   };
+  // EXEC mask of the lanes whose pair exists: group g of a pass with r pairs left holds min(max(r - 16 g, 0), 16) pairs, lanes
+  // li + 16 lq: the same 16 bits in all four quarters.  Scalar instructions only -- the sink-row redirect this replaces was
+  // a v_cmp + v_cndmask per group.
+  auto lane_mask = [](int r, int g) __attribute__((always_inline)) {
+    // (written with compares and selects: hipcc turns max(r - 16, 0) into a saturating v_sub, a vector instruction)
+    const int n = r <= 16 * g ? 0 : (r >= 16 * g + 16 ? 16 : r - 16 * g);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(((1u << n) - 1u) * 0x10001u));
+  };
+  // a + b as two v_pk_add_f32 (hipcc splits about half of these vector adds into four v_add_f32)
+  auto add4 = [](const floatx4 &x, const floatx4 &y) __attribute__((always_inline)) {
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    floatx2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(floatx2{x.x, x.y}), "v"(floatx2{y.x, y.y}));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(floatx2{x.z, x.w}), "v"(floatx2{y.z, y.w}));
+    return floatx4{lo.x, lo.y, hi.x, hi.y};
+  };
+  auto tile_read2 = [&](int addr, floatx4 (&o)[COS]) __attribute__((always_inline)) {
+    const lds_floatx4 *p = (const lds_floatx4 *)(size_t)(unsigned)addr;
+    o[0] = p[0];
+    o[1] = p[4];
+  };
+  auto tile_write2 = [&](int addr, unsigned mask, const floatx4 &d0, const floatx4 &d1) __attribute__((always_inline)) {
+    asm volatile(
+        "s_mov_b32 exec_lo, %[m]\n\t"
+        "s_mov_b32 exec_hi, %[m]\n\t"
+        "ds_write_b128 %[a], %[d0]\n\t"
+        "ds_write_b128 %[a], %[d1] offset:64\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : [a] "v"(addr), [m] "s"(mask), [d0] "v"(d0), [d1] "v"(d1)
+        : "memory");
+  };
   unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 
   Ent E0 = entry(0);
@@ -805,7 +847,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     u32x2 pr[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
     unsigned off[2], ioff[2];
     floatx4 rA[2][NS16], rB[2][NS16], rC[2][NS16], wc[COS][NS16], wn[COS][NS16], acc[2][COS];
-    int o0r[2], o1r[2], o2r[2], op1 = M * OS;  // output-tile rows of pass p, p+1, p+2; of group 1 of pass p-1
+    int oA[2], oB[2], oC[2], op1 = (int)tile0;  // output-tile byte addresses of passes p, p+1, p+2 (rotating with the row sets);
+                                                // of group 1 of pass p-1
+    unsigned mp1 = 0u;                          // its lane mask
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -820,7 +864,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       load_idx(E0, ioff, pr);
       asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]) : "memory");
       __builtin_amdgcn_sched_barrier(0);
-      addr(E0, pr, off, o0r);
+      addr(E0, pr, off, oA);
       weight_scalars(E0, so, voff, fresh);
 #pragma unroll
       for (int sp = 0; sp < NS16; ++sp) load_weights(sp, (DBG & 8) ? OOB : (unsigned)lane * 16u, so[sp], wc);
@@ -831,7 +875,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       load_idx(E1, ioff, pr);
       asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]), SCN_ROWS(rA), SCN_ROWS(wc) : "memory");
       __builtin_amdgcn_sched_barrier(0);
-      addr(E1, pr, off, o1r);
+      addr(E1, pr, off, oB);
       load_rows(0, off[0], (int)((E1.meta >> 8) & 15u) * (CK * 4), rB);
       load_rows(1, off[1], (int)((E1.meta >> 8) & 15u) * (CK * 4), rB);
       __builtin_amdgcn_sched_barrier(0);
@@ -842,8 +886,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       index_offsets(E3, ioff);
     }
 
-    auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rm)[2][NS16], floatx4 (&rn)[2][NS16]) __attribute__((always_inline)) {
+    auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rm)[2][NS16], floatx4 (&rn)[2][NS16], int (&oc)[2], int (&on)[2]) __attribute__((always_inline)) {
       const bool two = rem(E0) > 16;
+      const unsigned m0 = lane_mask(rem(E0), 0), m1 = lane_mask(rem(E0), 1);
       floatx4 old[2][COS];
       Ent E4 = E3;
       int w_so[NS16], rso = 0;
@@ -861,8 +906,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
           const int i = m;
           const unsigned src = icol ? pr[i].y : pr[i].x;
           const unsigned dst = icol ? pr[i].x : pr[i].y;
-          off[i] = (16 * i < rem(E2) && !(DBG & 2) && !((DBG & 2048) && w == 1)) ? mad24(src, row_bytes, lq16) : OOB;
-          o2r[i] = (16 * i + li < rem(E2)) ? (int)mad24(dst, os_u, tile0) : M * OS;
+          off[i] = ((DBG & 2) || ((DBG & 2048) && w == 1)) ? OOB : mad24(src, row_bytes, lq16);
+          on[i] = (int)mad24(dst, os_u, tile0);
           if (m == 1) {
             rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
             w_new = (E1.meta >> 20) & 1u;
@@ -872,9 +917,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         } else if (m >= 3 && m <= 6) {
           if (w_new) load_weights(m - 3, w_off, w_so[m - 3], wn);
         } else if (m == 7) {     // group 1 of the previous pass -> output tile: read its rows ...
-#pragma unroll
-          for (int q = 0; q < COS; ++q)
-            if (!(DBG & 1)) old[1][q] = *(const floatx4 *)__builtin_assume_aligned(o_tile + op1 + 32 * w + 16 * q + 4 * lq, 16);
+          if (!(DBG & 1)) tile_read2(op1, old[1]);
         } else if (m == 8) {     // indices of pass p+3 (pr was consumed by pieces 0-1)
           load_idx(E3, ioff, pr);
         } else if (m >= 9 && m <= 12) {  // rows of pass p+2: the long-latency gathers, in flight until the end of pass p+1
@@ -887,18 +930,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(rn[i][1]) : "v"(off[i]), "s"(in_rsrc), "s"(rso) : "memory");
           }
         } else if (m == 13) {    // ... add, write (its accumulators are free again before this pass's second group starts)
-#pragma unroll
-          for (int q = 0; q < COS; ++q) {
-            if (DBG & 1) {
-              asm volatile("" ::"v"(acc[1][q]));
-            } else {
-              *(floatx4 *)__builtin_assume_aligned(o_tile + op1 + 32 * w + 16 * q + 4 * lq, 16) = old[1][q] + acc[1][q];
-            }
-          }
+          if (DBG & 1) asm volatile("" ::"v"(acc[1][0]), "v"(acc[1][1]));
+          else tile_write2(op1, mp1, add4(old[1][0], acc[1][0]), add4(old[1][1], acc[1][1]));
         } else if (m == 14) {    // group 0 of THIS pass: read its rows (added and written beside the second group's MFMAs)
-#pragma unroll
-          for (int q = 0; q < COS; ++q)
-            if (!(DBG & 1)) old[0][q] = *(const floatx4 *)__builtin_assume_aligned(o_tile + o0r[0] + 32 * w + 16 * q + 4 * lq, 16);
+          if (!(DBG & 1)) tile_read2(oc[0], old[0]);
         } else if (m == 15) {    // table entry p+4
           E4 = entry(pnext);
         }
@@ -926,14 +961,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int m = 0; m < 16; ++m) piece(m);
       }
       auto write_group0 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < COS; ++q) {
-          if (DBG & 1) {
-            asm volatile("" ::"v"(acc[0][q]));
-          } else {
-            *(floatx4 *)__builtin_assume_aligned(o_tile + o0r[0] + 32 * w + 16 * q + 4 * lq, 16) = old[0][q] + acc[0][q];
-          }
-        }
+        if (DBG & 1) asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]));
+        else tile_write2(oc[0], m0, add4(old[0][0], acc[0][0]), add4(old[0][1], acc[0][1]));
       };
       if (!two || (DBG & 16)) write_group0();
       if (two && !(DBG & 16)) {
@@ -960,9 +989,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       asm volatile("s_waitcnt vmcnt(8)" ::SCN_ROWS(rm), SCN_ROWS(wn), "v"(pr[0]), "v"(pr[1]) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (DBG & 256) seg[4] += 1;
-      op1 = o0r[1];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { o0r[i] = o1r[i]; o1r[i] = o2r[i]; }
+      op1 = oc[1];
+      mp1 = m1;
       if (w_new) {
 #pragma unroll
         for (int q = 0; q < COS; ++q)
@@ -975,16 +1003,16 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     };
     do {  // single exit: a mid-loop break makes hipcc read "undefined" scalars out of a row register.  A pass past the
           // end is an empty one (dummy loads, output rows = sink) that only flushes `prev`.
-      body(rA, rB, rC);
-      body(rB, rC, rA);
-      body(rC, rA, rB);
+      body(rA, rB, rC, oA, oC);
+      body(rB, rC, rA, oB, oA);
+      body(rC, rA, rB, oC, oB);
     } while (rem(E0) > 0);
     // the (dummy) row prefetches of the passes past the end
     asm volatile("s_waitcnt vmcnt(0)" ::SCN_ROWS(rA), SCN_ROWS(rB), SCN_ROWS(rC) : "memory");
     if (!(DBG & 1)) {  // group 1 of the last pass
-#pragma unroll
-      for (int q = 0; q < COS; ++q)
-        *(floatx4 *)__builtin_assume_aligned(o_tile + op1 + 32 * w + 16 * q + 4 * lq, 16) += acc[1][q];
+      floatx4 o1[COS];
+      tile_read2(op1, o1);
+      tile_write2(op1, mp1, add4(o1[0], acc[1][0]), add4(o1[1], acc[1][1]));
     }
   }
 #undef SCN_ROWS
