@@ -901,6 +901,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       // MFMAs (MFMA pipe busy 66 % either way, two waves per SIMD): the granularity of the interleave is not what
       // limits the kernel, the vector-memory issue of the 10-18 loads per pass is.  Load order (vmcnt!): 8 weight,
       // 2 index, 8 row.
+      // (the "next pass starts a phase" bit, re-read through an opaque scalar move at every use: a common subexpression
+      //  across the pieces ends up as a 0/1 VGPR, v_cndmask + v_cmp per pass)
+      auto next_is_new = [&]() __attribute__((always_inline)) {
+        unsigned m_;
+        asm volatile("s_mov_b32 %0, %1" : "=s"(m_) : "s"(E1.meta));
+        return ((m_ >> 20) & 1u) != 0u;
+      };
       auto piece = [&](int m) __attribute__((always_inline)) {
         if (m == 0 || m == 1) {  // row offset / output row of group m of pass p+2 from its (arrived) pair indices
           const int i = m;
@@ -908,14 +915,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
           const unsigned dst = icol ? pr[i].x : pr[i].y;
           off[i] = ((DBG & 2) || ((DBG & 2048) && w == 1)) ? OOB : mad24(src, row_bytes, lq16);
           on[i] = (int)mad24(dst, os_u, tile0);
-          if (m == 1) {
-            rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
-            w_new = (E1.meta >> 20) & 1u;
-          }
+          if (m == 1) rso = (int)((E2.meta >> 8) & 15u) * (CK * 4);
         } else if (m == 2) {     // weights of pass p+1 only when it starts a new (offset, chunk) phase: they are OLDER than
-          if (w_new) weight_scalars(E1, w_so, w_off, w_new);  // the row loads, so the vmcnt(8) below is right either way
+          // the row loads, so the vmcnt(8) below is right either way.  (The condition is re-read from the scalar table entry
+          // every time: kept in a bool across the pieces, hipcc parks it in a VGPR -- v_cndmask + v_cmp per pass.)
+          if (next_is_new()) weight_scalars(E1, w_so, w_off, w_new);
         } else if (m >= 3 && m <= 6) {
-          if (w_new) load_weights(m - 3, w_off, w_so[m - 3], wn);
+          if (next_is_new()) load_weights(m - 3, w_off, w_so[m - 3], wn);
         } else if (m == 7) {     // group 1 of the previous pass -> output tile: read its rows ...
           if (!(DBG & 1)) tile_read2(op1, old[1]);
         } else if (m == 8) {     // indices of pass p+3 (pr was consumed by pieces 0-1)
@@ -991,7 +997,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       if (DBG & 256) seg[4] += 1;
       op1 = oc[1];
       mp1 = m1;
-      if (w_new) {
+      if (next_is_new()) {
 #pragma unroll
         for (int q = 0; q < COS; ++q)
 #pragma unroll
