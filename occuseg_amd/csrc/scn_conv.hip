@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256)
 //   * workgroups are renumbered so that each XCD owns a contiguous range of tiles: neighbouring tiles
 //     gather overlapping rows and now share one L2.
 template <int NW, int COS, int CK, int DBG = 0, int NWM = 1, int M_ = 0>
-__global__ void __launch_bounds__(64 * NW * NWM)
+__global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per_eu(2, 8)))  // (<= 256 registers: accumulators stay in VGPRs, no v_accvgpr_read before the output-tile adds)
     k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,

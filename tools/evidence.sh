@@ -14,12 +14,17 @@ mkdir -p $E
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > $E/bench.json 2> $E/bench.err
 python3 bench.py --no-cpu-baseline --steps 20 > $E/bench20.json 2>> $E/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > $E/bench_under_rocprof.json 2> $E/stats.err
+# (kernel durations: --no-dw-side-stream keeps dWeight on the main stream in every step, as bench.py does on the steps whose
+#  launches carry events, so the averages below are exclusive durations like roofline.avg_launch_ms; the second pass is the
+#  default command, in which dWeight overlaps the kernels that follow it and both take longer)
+rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -- python3 bench.py --no-cpu-baseline --no-dw-side-stream --steps 5 --warmup 2 > $E/bench_under_rocprof.json 2> $E/stats.err
 cp $(find $E/stats -name "*kernel_stats.csv" | head -1) $E/kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/fetch -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $E/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/write -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $E/write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats_overlap -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > $E/bench_under_rocprof_overlap.json 2> $E/stats_overlap.err
+cp $(find $E/stats_overlap -name "*kernel_stats.csv" | head -1) $E/kernel_stats_overlap.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/fetch -- python3 bench.py --no-cpu-baseline --no-dw-side-stream --steps 2 --warmup 1 > /dev/null 2> $E/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/write -- python3 bench.py --no-cpu-baseline --no-dw-side-stream --steps 2 --warmup 1 > /dev/null 2> $E/write.err
 python3 tools/pmc_traffic.py $E/fetch $E/write $E/traffic.json > $E/traffic.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $E/clock -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $E/clock.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $E/clock -- python3 bench.py --no-cpu-baseline --no-dw-side-stream --steps 2 --warmup 1 > /dev/null 2> $E/clock.err
 python3 tools/pmc_instep.py $E/clock > $E/instep_clock.txt 2>&1
 bash tools/pmc_groups.sh 1 $E/pmc_tile4
 python3 tools/pmc_summary.py $E/pmc_tile4 k_conv_tile4 > $E/pmc_conv_tile4.txt 2>&1
