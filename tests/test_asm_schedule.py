@@ -47,6 +47,35 @@ def test_checker_detects_a_touched_in_flight_register(tmp_path, capsys):
     assert _run(SNIPPET % "\tv_mov_b32_e32 v10, v41", tmp_path) == 1          # overwrites one
 
 
+BRANCHY = """
+_ZN3scn12k_conv_tile6ILi128ELb0ELi0EEEvPKf:
+	s_load_dwordx2 s[0:1], s[4:5], 0x0
+.LBB0_1:
+	;;#ASMSTART
+	buffer_load_dwordx4 v[8:11], v2, s[12:15], s3 offen
+	;;#ASMEND
+	s_cbranch_scc1 .LBB0_3
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+.LBB0_3:
+%s
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	s_cbranch_vccnz .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_checker_follows_branches(tmp_path, capsys):
+    """the wait is skipped on ONE path only: a linear walk of the listing sees it, the path walk does not let it count"""
+    assert _run(BRANCHY % "\tv_mov_b32_e32 v40, v41", tmp_path) == 0
+    assert _run(BRANCHY % "\tv_mov_b32_e32 v40, v9", tmp_path) == 1
+    assert "still in flight" in capsys.readouterr().out
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 def test_current_kernel_source_is_clean():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py")], capture_output=True,

@@ -199,7 +199,8 @@ def main():
     n = 0
     for st in starts:
         name = lines[st].split(":")[0]
-        end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end")) - 1  # (a kernel can hold several s_endpgm)
+        # (a kernel can hold several s_endpgm: it ends at its .Lfunc_end label; a bare snippet at its last line)
+        end = next((i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end")), len(lines)) - 1
         errors += check_kernel_cfg(name, lines[st:end + 1])  # every path of the control-flow graph
         if "k_conv_tile6" not in name and not re.search(r"k_conv_tile4ILi\d*[13579]ELi", name):
             errors += check_kernel(name, lines[st:end + 1])  # and the older linear walk of the loop (twice), where it applies
