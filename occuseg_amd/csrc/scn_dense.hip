@@ -80,11 +80,29 @@ __device__ __forceinline__ bool bn_sum_partials(const float *partial, int nblk, 
   const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
   c = blockIdx.x * 16 + cl;
   double a = 0, b = 0;
-  if (c < C)
-    for (int blk = bl; blk < nblk; blk += 16) {
-      a += (double)partial[(int64_t)blk * 2 * C + c];
-      b += (double)partial[(int64_t)blk * 2 * C + C + c];
+  if (c < C) {
+    // up to 64 dependent fp64 adds per thread: the LOADS are independent, so eight iterations' worth are requested before
+    // the first add (same summation order; the finalize kernels took 26 us of pure L2 latency per launch before)
+    const float *p0 = partial + c;
+    int blk = bl;
+    for (; blk + 7 * 16 < nblk; blk += 8 * 16) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        va[u] = p0[(int64_t)(blk + 16 * u) * 2 * C];
+        vb[u] = p0[(int64_t)(blk + 16 * u) * 2 * C + C];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a += (double)va[u];
+        b += (double)vb[u];
+      }
     }
+    for (; blk < nblk; blk += 16) {
+      a += (double)p0[(int64_t)blk * 2 * C];
+      b += (double)p0[(int64_t)blk * 2 * C + C];
+    }
+  }
   red[0][bl][cl] = a;
   red[1][bl][cl] = b;
   __syncthreads();
