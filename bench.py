@@ -242,7 +242,10 @@ def main():
     # the extra, untimed step (every rank runs it: it holds collectives): events on batch norm, rule build, io launches
     SCN.PROFILE_KINDS = ("bn", "rules", "io")
     SCN.PROFILE = prof_extra if rank == 0 else None
+    seen_md = []
+    hook = input_layer.register_forward_hook(lambda mod, inp, outp: seen_md.append(outp.metadata))
     step()
+    hook.remove()
     SCN.PROFILE = None
     SCN.PROFILE_KINDS = ("mm", "bn", "rules", "io")
     barrier()
@@ -378,6 +381,27 @@ def main():
                        "source_hash": source_hash()},
             "roofline": roof, "kernels": kernels, "peaks_measured": peaks,
         }
+        # active sites and measured nu (pairs per site of the 3x3x3 rulebook) per UNet level, of the
+        # batch of the extra step; the ten matrix launches (kernel, shape) that take the most time
+        if seen_md:
+            md = seen_md[-1]
+            lv = []
+            for key, rb in md.submanifoldRuleBooks.items():
+                n = md.nActive.get(key[0] if isinstance(key[0], tuple) else key[:3])
+                if n:
+                    lv.append({"spatial_size": int((key[0] if isinstance(key[0], tuple) else key)[0]), "active_sites": int(n),
+                               "nu": float(rb.total_pairs) / float(n)})
+            res["levels"] = sorted(lv, key=lambda d: -d["active_sites"])
+        per_shape = {}
+        for kernel, shape, ms, flops, nbytes, per in launches:
+            if flops > 0:
+                d = per_shape.setdefault((kernel, tuple(shape) if shape else ()), [0.0, 0.0, 0.0])
+                d[0] += per
+                d[1] += ms
+                d[2] += flops
+        res["layers"] = [{"kernel": k[0], "K_rows_Ci_Co_transposed_incol": list(k[1]), "launches_per_step": v[0] / sampled,
+                          "ms_per_launch": v[1] / v[0], "tflops": v[2] / v[1] / 1e9}
+                         for k, v in sorted(per_shape.items(), key=lambda kv: -kv[1][1])[:10]]
         if args.dump_launches:
             per_shape = {}
             for kernel, shape, ms, flops, nbytes, per in launches:
