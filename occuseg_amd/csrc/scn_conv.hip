@@ -257,13 +257,21 @@ __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per
   const int g0 = tile * (M / SCN_TILE_GRANULE);
   const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
 
-  for (int i = tid; i < M * COB; i += NT) {
-    const int r = i / COB, c = i % COB;
-    float v = (bias && blockIdx.y == 0) ? bias[co0 + c] : 0.f;
-    // residual: the tile starts from the rows of another tensor (out = residual + bias + sum ...): the shortcut of a
-    // residual block is added here for the price of reading it, instead of by a separate elementwise kernel
-    if (residual && blockIdx.y == 0 && o0 + r < n_out) v += residual[(o0 + r) * Co + co0 + c];
-    o_tile[r * OS + c] = v;
+  // residual: the tile starts from the rows of another tensor (out = residual + bias + sum ...): the shortcut of a
+  // residual block is added here for the price of reading it, instead of by a separate elementwise kernel.  Eight
+  // elements per thread are requested together (one HBM round trip per eight instead of one per element).
+  for (int i0 = tid; i0 < M * COB; i0 += 8 * NT) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * NT, r = i / COB, c = i % COB;
+      v[u] = (residual && blockIdx.y == 0 && i < M * COB && o0 + r < n_out) ? residual[(o0 + r) * Co + co0 + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * NT, r = i / COB, c = i % COB;
+      if (i < M * COB) o_tile[r * OS + c] = v[u] + ((bias && blockIdx.y == 0) ? bias[co0 + c] : 0.f);
+    }
   }
   if (tid < 64) {
     // one lane per kernel offset: segment of list k inside this tile, then a ballot-compacted list of
@@ -687,13 +695,29 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   asm volatile("" : "+v"(tile0));
   const unsigned li8[2] = {(unsigned)li * 8u, (unsigned)(li + 16) * 8u};  // byte offset of the lane's pair within a pass
 
-  // each wave initialises ITS 32 planes of the output tile
-  for (int i = lane; i < (M + 1) * 8; i += 64) {
-    const int r = i >> 3, c4 = (i & 7) * 4;
-    floatx4 v = {0.f, 0.f, 0.f, 0.f};
-    if (bias && blockIdx.y == 0) v = *(const floatx4 *)(bias + co0 + 32 * w + c4);
-    if (residual && blockIdx.y == 0 && r < M && o0 + r < n_out) v += *(const floatx4 *)(residual + (o0 + r) * Co + co0 + 32 * w + c4);
-    *(floatx4 *)(o_tile + r * OS + 32 * w + c4) = v;
+  // each wave initialises ITS 32 planes of the output tile.  With a residual the 16 row pieces of a lane are requested
+  // TOGETHER (the first version waited for every piece before asking for the next: sixteen HBM round trips per tile, 10-20 %
+  // of the launches that carry a shortcut -- bench.py's `layers` showed forward launches 10 % behind the dInput launches
+  // of the same shape)
+  {
+    constexpr int NIT = M * 8 / 64;  // row pieces per lane; i = lane + 64 j: the plane quad (i & 7) is the lane's own
+    const int c4 = (lane & 7) * 4;
+    floatx4 bv = {0.f, 0.f, 0.f, 0.f}, rv[NIT];
+    if (bias && blockIdx.y == 0) bv = *(const floatx4 *)(bias + co0 + 32 * w + c4);
+    if (residual && blockIdx.y == 0) {
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int r = (lane >> 3) + 8 * j;
+        rv[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (o0 + r < n_out) rv[j] = *(const floatx4 *)(residual + (o0 + r) * Co + co0 + 32 * w + c4);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) rv[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) *(floatx4 *)(o_tile + ((lane >> 3) + 8 * j) * OS + 32 * w + c4) = rv[j] + bv;
+    if (lane < 8) *(floatx4 *)(o_tile + M * OS + 32 * w + c4) = floatx4{0.f, 0.f, 0.f, 0.f};  // (row M: unused sink of older builds)
   }
   if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
     int s = 0, c = 0;
