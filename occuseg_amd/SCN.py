@@ -10,6 +10,7 @@ all arithmetic and all rulebook construction happens in libscn_hip.so through
 the C ABI of include/scn_hip.h.  CPU tensors are refused: there is no CPU path.
 """
 import contextlib
+import os
 import ctypes
 
 import numpy as np
@@ -460,6 +461,9 @@ def _norm_device(device):
     return device
 
 
+PREFETCH_PRIORITY = int(os.environ.get("SCN_PREFETCH_PRIORITY", "-1"))  # HIP stream priority of the rule-build side stream (-1 = high)
+
+
 def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=True, normals=None,
                    normal_guide_scale=None):
     """Build the grids and (replaying the previous forward pass's requests) the rulebooks that the next
@@ -471,9 +475,9 @@ def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=Tr
     serialises the build behind the queued step)."""
     device = _norm_device(device)
     assert coords.dtype in _COORD_DTYPES and coords.dim() == 2
-    side = _SIDE_STREAMS.get(device)
+    side = _SIDE_STREAMS.get((device, PREFETCH_PRIORITY))
     if side is None:
-        side = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device, priority=-1)
+        side = _SIDE_STREAMS[(device, PREFETCH_PRIORITY)] = torch.cuda.Stream(device=device, priority=PREFETCH_PRIORITY)
     if coords.is_cuda and wait_for_current_stream:
         side.wait_stream(torch.cuda.current_stream(device))
     m = Metadata_3()
