@@ -521,7 +521,15 @@ __global__ void __launch_bounds__(256) k_bn_fold(const float *__restrict__ parti
   const int f = blockIdx.y;
   for (int c = blockIdx.x * 256 + threadIdx.x; c < 2 * Cp; c += gridDim.x * 256) {
     double a = 0;
-    for (int b = f; b < nblk; b += BN_FOLD) a += (double)partial[(int64_t)b * 2 * Cp + c];
+    int b = f;
+    for (; b + 7 * BN_FOLD < nblk; b += 8 * BN_FOLD) {  // eight loads in flight, same summation order (see bn_sum_partials)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u * BN_FOLD) * 2 * Cp + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (double)v[u];
+    }
+    for (; b < nblk; b += BN_FOLD) a += (double)partial[(int64_t)b * 2 * Cp + c];
     out[(int64_t)f * 2 * Cp + c] = (float)a;
   }
 }

@@ -103,6 +103,42 @@ def test_rulebook_prefetch_is_equivalent(gpu):
     SCN._PREFETCHED.clear()
 
 
+def test_dweight_side_stream_is_race_free(gpu):
+    """The dWeight kernels of a network whose gradients live in a FlatGradBucket run on a side stream (SCN.dw_async).
+    Twenty double backward passes against the plain autograd path: a residual block's last convolution hands its incoming
+    gradient on to the shortcut, autograd adds into that tensor in place on the main stream, and a side-stream dWeight
+    that still read it came out wrong in 1 of 85 gradients per run before those convolutions were kept on the main
+    stream.  Also with the side stream switched off."""
+    import occuseg_amd
+    from occuseg_amd import SCN, dp, scenes
+    scn = occuseg_amd.install()
+    torch.manual_seed(5)
+    net = _net(scn, 16, 3, 0.0).to(gpu)
+    coords, feats = scenes.batch([1000, 1001], target_sites=6000)
+    batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
+    for p in net.parameters():
+        p.grad = None
+    net(batch).sum().backward()
+    net(batch).sum().backward()
+    plain = [p.grad.clone() for p in net.parameters()]
+    bucket = dp.FlatGradBucket(net.parameters())
+    before = SCN.DW_SIDE_STREAM
+    try:
+        for side in (True, False):
+            SCN.DW_SIDE_STREAM = side
+            for it in range(20 if side else 3):
+                bucket.zero()
+                net(batch).sum().backward()
+                net(batch).sum().backward()
+                bucket.all_reduce_mean()
+                for (name, p), ref in zip(net.named_parameters(), plain):
+                    err = (p.grad - ref).abs().max().item()
+                    assert err <= 1e-4 * ref.abs().max().item() + 1e-30, (side, it, name, err)
+    finally:
+        SCN.DW_SIDE_STREAM = before
+        bucket.close()
+
+
 def test_direct_weight_gradient_accumulation(gpu):
     """FlatGradBucket lets the convolutions accumulate dWeight straight into the flat gradient buffer
     (no zeros_like + autograd add per parameter): same gradients as the plain autograd path, twice in a row
