@@ -575,6 +575,7 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
 # modules do when they accumulate straight into a gradient buffer they own (occuseg_amd.dp.FlatGradBucket) and return no
 # gradient to autograd; on the plain autograd path AccumulateGrad reads the returned tensor at once, on the main stream.
 DW_SIDE_STREAM = True   # A/B switch (tools/ab_step.py DW_SIDE_STREAM=0,1)
+DW_FIRST = False        # A/B switch: dWeight queued (side stream) before the layer's dInput (main stream)
 _DW_STATE = {}          # device index -> [stream, last event or None, callback queued]
 _DW_ALLOW = [False]
 
@@ -637,13 +638,21 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
     lib = _lib_()
     K, Ci, Co = weight.shape
     d_out = d_out.contiguous()
-    if d_in is not None:
+
+    def d_input():
+        if d_in is None:
+            return
         if reverse:
             # submanifold: dIn[i] = sum_k' dOut[nbr(i,k')] . W[26-k']^T over the SAME lists (rules are
             # symmetric: (i,o) in list k <=> (o,i) in list 26-k), so the columns keep their roles
             _conv(d_out, d_in, weight, None, rb, in_col, out_col, n_in, True, True)
         else:
             _conv(d_out, d_in, weight, None, rb, out_col, in_col, n_in, True, False)
+
+    # DW_FIRST: the side stream's wait on the main stream is taken BEFORE the dInput kernel is queued, so the two kernels
+    # of a layer run beside each other from the start (A/B switch; default: dWeight waits for the layer's dInput)
+    if not DW_FIRST:
+        d_input()
     if d_weight is not None and d_weight.numel():
         side = _dw_side_begin(inp, d_out, d_weight)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
@@ -656,6 +665,8 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
                       4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
         if side is not None:
             _dw_side_end(side)
+    if DW_FIRST:
+        d_input()
     if d_bias is not None and d_bias.numel():
         check(lib.scn_column_sum(ptr(d_out), ptr(d_bias), d_out.size(0), Co, stream()))
 
