@@ -1051,24 +1051,30 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // each wave stores its own 32 planes: no barrier needed
   const int rows = (int)min((int64_t)M, n_out - o0);
   float *dst = out + (int64_t)blockIdx.y * n_out * Co;
+  // ... and the column statistics of these 32 planes over the tile's rows come from the SAME 16-byte reads: lane (row
+  // octet lane >> 3, plane quad lane & 7) sums its 16 rows, a butterfly over the eight lanes of a plane quad finishes.  (The
+  // first version walked the tile again, one float per lane and row, 64 dependent LDS reads per lane: 3-6 % of a forward
+  // launch inside the train step.)
+  const bool stats = colstats != nullptr && ksplit == 1;
+  floatx4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
   for (int i = lane; i < rows * 8; i += 64) {
     const int r = i >> 3, c4 = (i & 7) * 4;
-    *(floatx4 *)(dst + (o0 + r) * Co + co0 + 32 * w + c4) = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
+    const floatx4 v = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
+    *(floatx4 *)(dst + (o0 + r) * Co + co0 + 32 * w + c4) = v;
+    cs += v;
+    css += v * v;
   }
-  // column statistics of this wave's 32 planes over the tile's rows (see k_conv_tile2): lane = (plane, half of the rows)
-  if (colstats != nullptr && ksplit == 1) {
-    const int p = lane & 31, half = lane >> 5;
-    float cs = 0.f, css = 0.f;
-    for (int r = half * 64; r < min(rows, half * 64 + 64); ++r) {
-      const float v = o_tile[r * OS + 32 * w + p];
-      cs += v;
-      css += v * v;
-    }
-    cs += __shfl_xor(cs, 32);
-    css += __shfl_xor(css, 32);
-    if (half == 0) {
-      colstats[((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + p] = cs;
-      colstats[((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + p] = css;
+  if (stats) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs[e] += __shfl_xor(cs[e], o);
+        css[e] += __shfl_xor(css[e], o);
+      }
+    if (lane < 8) {
+      *(floatx4 *)(colstats + ((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + lane * 4) = cs;
+      *(floatx4 *)(colstats + ((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + lane * 4) = css;
     }
   }
 }
