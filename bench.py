@@ -146,6 +146,22 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="write per-launch timings (kernel, shape, ms) to this JSON file")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (how the driver calls N = 1): start one rank per GPU as CHILD processes through
+        # torch.distributed.run and hand on its exit status.  Nothing in this process has touched the GPU (importing
+        # torch does not), and nothing is exec'ed: the launcher is a child, rank 0's JSON line goes to the inherited stdout.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus))))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -377,6 +393,7 @@ def main():
                        "active_voxels_per_batch": n_sites, "parameters": n_params,
                        "parallelism": "dp%d" % world, "allreduce_bytes": 4 * n_params if world > 1 else 0,
                        "backend": backend if world > 1 else None,
+                       "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "rulebook_prefetch": bool(args.prefetch), "dweight_side_stream": dw_side,
                        "source_hash": source_hash()},
             "roofline": roof, "kernels": kernels, "peaks_measured": peaks,

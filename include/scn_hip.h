@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 2
+#define SCN_ABI_VERSION 3
 #define SCN_TILE_GRANULE 32 /* output-row granule of the tile-base tables */
 
 int scn_abi_version(void);
@@ -160,6 +160,22 @@ size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_o
 int scn_conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
 int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int Ci, int Co, void *wpack,
                     void *stream);
+/* The re-layout of MANY (weight, orientation) pairs in one launch: what a training loop runs once per optimizer step
+ * instead of one scn_weight_pack per layer and direction (the reference reads the module's weight tensor on every
+ * call, sparseconvnet/SCN/CUDA/Convolution.cpp:105-162; a caller that caches packed weights must re-pack whenever
+ * the weights may have changed -- occuseg_amd/SCN.py does so once per forward pass and after every optimizer step).
+ *   descs: DEVICE array of n scn_wpack_desc, first_block = sum of scn_weight_pack_blocks() of the descriptors before it;
+ *   total_blocks = that sum over all n.  flags = scn_weight_pack_flags(w_transposed, w_reverse, K, Ci, Co).
+ *   Tensors whose planes are not multiples of 16 have 0 blocks (never packed) and must be left out. */
+typedef struct scn_wpack_desc {
+  const float *W;      /* module weight [K][Ci][Co] (or [K][Co][Ci] with the transposed flag) */
+  float *wpack;        /* scn_conv_wpack_bytes(K, Ci, Co) bytes */
+  int32_t K, Ci, Co, flags;
+  int64_t first_block;
+} scn_wpack_desc;
+int64_t scn_weight_pack_blocks(int K, int Ci, int Co);
+int scn_weight_pack_flags(int w_transposed, int w_reverse, int K, int Ci, int Co);
+int scn_weight_pack_batch(const void *descs, int n, int64_t total_blocks, void *stream);
 int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
                      const float *bias, const float *residual, float *colstats, const int32_t *rules,

@@ -235,9 +235,10 @@ class Metadata_3(object):
         # the GPU like the reference's `.type(torch.LongTensor)`, sparseconvnet/ioLayers.py:56)
         assert coords.dtype in _COORD_DTYPES, coords.dtype
         key = _size_key(spatialSize)
+        _WEPOCH[0] += 1  # a new batch: packed weights are re-made from the module's weights at their next use
         pre = _PREFETCHED.pop(id(coords), None)
-        if pre is not None and pre[0] is coords and pre[1] == (key, int(mode), _norm_device(device)) \
-                and pre[4] is normals:
+        if pre is not None and pre[0] is coords and pre[4] is normals \
+                and pre[1] == (key, int(mode), _norm_device(device), self.normal_guide_scale):
             self._adopt(pre[2], pre[3])
             return
         self.clear()
@@ -483,44 +484,133 @@ def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=Tr
     m = Metadata_3()
     if normals is not None and normals.is_cuda and wait_for_current_stream:
         side.wait_stream(torch.cuda.current_stream(device))
+    if normal_guide_scale is not None:  # the threshold getRuleBook tests must be the InputLayer's, not the default
+        m.setNormalGuideScale(normal_guide_scale)
     with torch.cuda.stream(side):
         m.inputLayer(spatialSize, coords, 0, mode, device, normals=normals)
         done = torch.cuda.Event()
         done.record(side)
     _PREFETCHED.clear()  # one batch ahead is all a training loop needs; never keep stale grids alive
-    _PREFETCHED[id(coords)] = (coords, (_size_key(spatialSize), int(mode), device), m, done, normals)
+    _PREFETCHED[id(coords)] = (coords, (_size_key(spatialSize), int(mode), device, m.normal_guide_scale), m, done, normals)
 
 
 # ----------------------------------------------------------------- helpers ---
-# Weights re-laid out in MFMA fragment order (scn_weight_pack), cached per (weight tensor, transposed, reversed) and
-# re-packed only when the tensor's version counter moved: weights change once per optimizer step, not once per call
-# (in evaluation never).  In-place updates through `.data` do not move the counter: call invalidate_weight_cache().
+# Weights re-laid out in MFMA fragment order (scn_weight_pack), one packed copy per (weight tensor, transposed, reversed).
+# The reference reads the module's weight tensor on every call (sparseconvnet/SCN/CUDA/Convolution.cpp:105-162); a packed
+# copy is therefore only ever used within one WEIGHT EPOCH and one value of the tensor's version counter.  The version
+# counter alone is NOT enough: torch's fused optimizers and writes through `.data` do not move it (round-2 verdict: the
+# convolutions kept computing with first-step weights).  The epoch moves
+#   * at every InputLayer call (a new batch: once per forward pass),
+#   * at the first forward-direction call after any backward call (a loop that re-uses one input tensor),
+#   * after every torch optimizer step (global post-step hook) and in FlatGradBucket.zero(),
+#   * when invalidate_weight_cache() is called (writes through `.data` between two calls on the same input).
+# The first lookup in a new epoch re-packs ALL live entries -- both orientations of every layer -- in ONE launch
+# (scn_weight_pack_batch: 0.7 GB of traffic for the m64 UNet instead of 74 launches).  WPACK_CACHE = False: no cache at
+# all, scn_conv_forward packs on every call.
 import weakref  # noqa: E402
 
-_WPACK = {}
+_WPACK = {}          # key -> _PackedWeight
+_WEPOCH = [1]
+_BWD_SEEN = [False]
+_WTABLE = {}         # device index -> (signature, descriptor tensor, total blocks)
 WPACK_CACHE = True
+WPACK_STATS = {"single": 0, "batch": 0, "batch_entries": 0}  # launches since import (tests, bench)
+
+
+class _PackedWeight(object):
+    __slots__ = ("ref", "off", "ptr", "version", "epoch", "wpack", "dims", "flags", "blocks")
+
+
+def weights_changed():
+    """start a new weight epoch: every packed copy is re-made from the module's weights before its next use"""
+    _WEPOCH[0] += 1
 
 
 def invalidate_weight_cache():
     _WPACK.clear()
+    _WTABLE.clear()
+    _WEPOCH[0] += 1
+
+
+def _optimizer_step_hook(_opt, _args, _kwargs):
+    _WEPOCH[0] += 1
+
+
+try:  # global: fires after the step of EVERY torch optimizer (fused ones included)
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
+    _reg_hook(_optimizer_step_hook)
+except ImportError:  # pragma: no cover  (older torch: InputLayer / backward / FlatGradBucket.zero() still move the epoch)
+    pass
+
+
+def _repack_all(device):
+    """one launch re-packs every live entry on `device` and stamps it with the current epoch"""
+    lib = _lib_()
+    live = []
+    for key, ent in list(_WPACK.items()):
+        base = ent.ref()
+        if base is None or base.data_ptr() + ent.off != ent.ptr:
+            _WPACK.pop(key, None)  # freed, or re-seated through `.data = ...`: the next use packs afresh
+            continue
+        if base.device == device and ent.blocks > 0:
+            live.append((ent, base))
+    if not live:
+        return
+    sig = tuple((ent.ptr, ent.wpack.data_ptr()) + ent.dims + (ent.flags,) for ent, _ in live)
+    tab = _WTABLE.get(device.index)
+    if tab is None or tab[0] != sig:
+        desc = np.zeros(len(live), dtype=np.dtype([("W", "<u8"), ("Wp", "<u8"), ("K", "<i4"), ("Ci", "<i4"), ("Co", "<i4"),
+                                                   ("flags", "<i4"), ("first", "<i8")]))
+        first = 0
+        for i, (ent, _) in enumerate(live):
+            desc[i] = (ent.ptr, ent.wpack.data_ptr(), ent.dims[0], ent.dims[1], ent.dims[2], ent.flags, first)
+            first += ent.blocks
+        dev_desc = torch.from_numpy(desc.view(np.uint8).copy()).to(device)
+        tab = _WTABLE[device.index] = (sig, dev_desc, first)
+    check(lib.scn_weight_pack_batch(ptr(tab[1]), len(live), tab[2], stream()))
+    WPACK_STATS["batch"] += 1
+    WPACK_STATS["batch_entries"] += len(live)
+    for ent, base in live:
+        ent.version = base._version
+        ent.epoch = _WEPOCH[0]
 
 
 def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
     """returns (packed tensor, ready flag for scn_conv_forward)"""
+    if not w_transposed and _BWD_SEEN[0]:  # a forward-direction call after a backward call: weights may have been updated
+        _BWD_SEEN[0] = False
+        _WEPOCH[0] += 1
+    if not WPACK_CACHE:
+        return torch.empty(K * Ci * Co, dtype=torch.float32, device=weight.device), 0
     base = weight._base if weight._base is not None else weight
     key = (id(base), weight.data_ptr(), bool(w_transposed), bool(w_reverse))
-    ent = _WPACK.get(key) if WPACK_CACHE else None
-    if ent is not None and ent[0]() is base and ent[1] == weight._version and ent[2].numel() == K * Ci * Co:
-        return ent[2], 1
-    wpack = torch.empty(K * Ci * Co, dtype=torch.float32, device=weight.device)
-    if not WPACK_CACHE:
-        return wpack, 0
-    check(_lib_().scn_weight_pack(ptr(weight), int(w_transposed), int(w_reverse), K, Ci, Co, ptr(wpack), stream()))
+    ent = _WPACK.get(key)
+    if ent is not None and (ent.ref() is not base or ent.dims != (K, Ci, Co) or ent.ptr != weight.data_ptr()):
+        ent = None
+    if ent is not None and ent.epoch != _WEPOCH[0]:
+        _repack_all(weight.device)  # stamps every live entry, this one included (unless it was dropped)
+        ent = _WPACK.get(key)
+    if ent is not None and ent.epoch == _WEPOCH[0] and ent.version == weight._version:
+        return ent.wpack, 1
+    lib = _lib_()
+    if ent is None:
+        ent = _PackedWeight()
+        ent.wpack = torch.empty(K * Ci * Co, dtype=torch.float32, device=weight.device)
 
-    def _drop(_ref, key=key):
-        _WPACK.pop(key, None)
-    _WPACK[key] = (weakref.ref(base, _drop), weight._version, wpack)
-    return wpack, 1
+        def _drop(_ref, key=key):
+            _WPACK.pop(key, None)
+        ent.ref = weakref.ref(base, _drop)
+        ent.ptr = weight.data_ptr()
+        ent.off = ent.ptr - base.data_ptr()
+        ent.dims = (K, Ci, Co)
+        ent.flags = lib.scn_weight_pack_flags(int(w_transposed), int(w_reverse), K, Ci, Co)
+        ent.blocks = lib.scn_weight_pack_blocks(K, Ci, Co)
+        _WPACK[key] = ent
+    check(lib.scn_weight_pack(ptr(weight), int(w_transposed), int(w_reverse), K, Ci, Co, ptr(ent.wpack), stream()))
+    WPACK_STATS["single"] += 1
+    ent.version = weight._version
+    ent.epoch = _WEPOCH[0]
+    return ent.wpack, 1
 
 
 def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False, residual=None,
@@ -576,70 +666,84 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
 # gradient to autograd; on the plain autograd path AccumulateGrad reads the returned tensor at once, on the main stream.
 DW_SIDE_STREAM = True   # A/B switch (tools/ab_step.py DW_SIDE_STREAM=0,1)
 DW_FIRST = False        # A/B switch: dWeight queued (side stream) before the layer's dInput (main stream)
-DW_HOLD_GRAD = False    # A/B switch: see dw_async(hold_grad); False = shortcut convolutions stay on the main stream (measured
-                        # equal: 47.3-47.8 ms per step either way, and nothing is kept alive)
-_DW_STATE = {}          # device index -> [stream, last event or None, callback queued, tensors kept alive]
+_DW_STATE = {}          # device index -> [stream, last event or None, [(event, dOut kept alive), ...]]
 _DW_ALLOW = [0]
 
 
 @contextlib.contextmanager
-def dw_async(allowed, hold_grad=False):
+def dw_async(allowed):
     """inside: the backward boundary functions may leave their dWeight kernel running on the side stream.
-    hold_grad: the caller hands dOut on to autograd as somebody's gradient (the shortcut of a residual block).  Where that
-    gradient meets another one autograd adds IN PLACE into the tensor that arrived first -- but only into a tensor it holds
-    the last reference to (torch/csrc/autograd/input_buffer.cpp: can_accumulate_inplace): a reference kept here until the
-    side stream has been joined makes it add out of place (same traffic), and the side stream reads unchanged memory."""
+    The side-stream kernel reads dOut while the main stream goes on.  dOut is autograd's tensor, and the SAME tensor may
+    be somebody else's gradient too (AddBackward of a residual block hands one tensor to the body and to the shortcut:
+    scn.add_feature_planes / AddTable over ConcatTable, sparseconvnet/networkArchitectures.py:222-229): where it meets
+    another gradient autograd adds IN PLACE into a tensor it holds the last reference to (torch/csrc/autograd/
+    input_buffer.cpp: can_accumulate_inplace), on the main stream, under the side stream's feet.  Every dOut that goes to
+    the side stream is therefore kept referenced until its kernel has finished (then autograd adds out of place: same
+    traffic), whatever the graph around the convolution looks like."""
     before = _DW_ALLOW[0]
-    _DW_ALLOW[0] = (2 if hold_grad else 1) if allowed else 0
+    _DW_ALLOW[0] = 1 if allowed else 0
     try:
         yield
     finally:
         _DW_ALLOW[0] = before
 
 
+def _dw_state(dev):
+    st = _DW_STATE.get(dev.index)
+    if st is None:
+        st = _DW_STATE[dev.index] = [torch.cuda.Stream(device=dev), None, []]
+    return st
+
+
 def _dw_side_begin(*tensors):
     if not (DW_SIDE_STREAM and _DW_ALLOW[0]):
         return None
     dev = tensors[0].device
-    st = _DW_STATE.get(dev.index)
-    if st is None:
-        st = _DW_STATE[dev.index] = [torch.cuda.Stream(device=dev), None, False, []]
-    if not st[2]:
-        try:  # only inside a backward pass: this is what makes the main stream wait for the side stream at its end
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: _dw_finish(dev.index))
-        except RuntimeError:
-            return None
-        st[2] = True
+    st = _dw_state(dev)
+    try:
+        # Only inside a backward pass; this is what makes the main stream wait for the side stream at its end.  Queued
+        # at EVERY launch (the callback is idempotent): a flag that says "already queued" stays set for ever when a
+        # backward pass raises -- final callbacks are then skipped -- and no later pass would join the side stream.
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _dw_finish(dev.index))
+    except RuntimeError:
+        return None
     side = st[0]
     side.wait_stream(torch.cuda.current_stream(dev))  # dOut, the zeroed dW, the saved input: produced on the main stream
     for t in tensors:
         t.record_stream(side)  # (the caching allocator must not hand their memory out before the side stream is done)
-    if _DW_ALLOW[0] == 2:
-        st[3].append(tensors[1])  # dOut: see dw_async(hold_grad)
+    held = st[2]
+    while held and held[0][0].query():  # kernels that have finished no longer pin their dOut
+        held.pop(0)
     return side
 
 
-def _dw_side_end(side):
+def _dw_side_end(side, d_out):
     st = _DW_STATE[side.device.index]
     ev = torch.cuda.Event()
     ev.record(side)
     st[1] = ev
+    st[2].append((ev, d_out))
 
 
 def dw_join(device=None):
-    """make the current stream wait for every dWeight kernel launched so far (called before gradients are consumed)"""
+    """make the current stream wait for every dWeight kernel launched so far (called before gradients are consumed or
+    zeroed: FlatGradBucket.zero / _launch / all_reduce_mean, the end of every backward pass)"""
     for idx, st in _DW_STATE.items():
-        if st[1] is not None and (device is None or device.index is None or device.index == idx):
-            torch.cuda.current_stream(torch.device("cuda", idx)).wait_event(st[1])
+        if device is None or device.index is None or device.index == idx:
+            if st[1] is not None:
+                torch.cuda.current_stream(torch.device("cuda", idx)).wait_event(st[1])
+            while st[2] and st[2][0][0].query():
+                st[2].pop(0)
 
 
 def _dw_finish(idx):
     st = _DW_STATE[idx]
-    st[2] = False
     if st[1] is not None:
         torch.cuda.current_stream(torch.device("cuda", idx)).wait_event(st[1])
         st[1] = None
-    del st[3][:]
+    # the main stream now waits for every side-stream kernel: whatever autograd does with the dOut tensors from here on
+    # is ordered behind them
+    del st[2][:]
 
 
 def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse):
@@ -647,6 +751,7 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
     lib = _lib_()
     K, Ci, Co = weight.shape
     d_out = d_out.contiguous()
+    _BWD_SEEN[0] = True  # (weight epochs: the next forward-direction call may see updated weights)
 
     def d_input():
         if d_in is None:
@@ -673,7 +778,7 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
             _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else "dw_narrow", 2.0 * R * Ci * Co,
                       4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
         if side is not None:
-            _dw_side_end(side)
+            _dw_side_end(side, d_out)
     if DW_FIRST:
         d_input()
     if d_bias is not None and d_bias.numel():
@@ -935,6 +1040,7 @@ def NetworkInNetwork_updateOutput(input_features, output_features, weight, bias)
 def NetworkInNetwork_updateGradInput(d_input_features, d_output_features, weight):
     """sparseconvnet/SCN/CUDA/NetworkInNetwork.cpp:27-37"""
     n = d_output_features.size(0)
+    _BWD_SEEN[0] = True
     if _nin_native(d_output_features, weight):
         rb = _identity_rulebook(n, d_output_features.device)
         _conv(d_output_features.contiguous(), d_input_features, weight.view(1, weight.size(0), weight.size(1)), None,
@@ -948,6 +1054,7 @@ def NetworkInNetwork_updateGradInput(d_input_features, d_output_features, weight
 def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weight, d_bias):
     """sparseconvnet/SCN/CUDA/NetworkInNetwork.cpp:39-50"""
     n = input_features.size(0)
+    _BWD_SEEN[0] = True
     if n and d_bias is not None and d_bias.numel():
         torch.sum(d_output_features, 0, out=d_bias)
     if _nin_native(input_features, d_weight):

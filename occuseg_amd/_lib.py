@@ -33,6 +33,9 @@ SIGNATURES = {
     "scn_conv_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_plan": (c_int, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_weight_pack": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "scn_weight_pack_blocks": (c_int64, [c_int, c_int, c_int]),
+    "scn_weight_pack_flags": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "scn_weight_pack_batch": (c_int, [_P, c_int, c_int64, _P]),
     "scn_conv_stats_blocks": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
                                  c_int64, c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
@@ -66,7 +69,7 @@ TUNING_SIGNATURES = {
     "scn_peak_read": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
 }
 TUNING_LIB_PATH = os.path.join(_HERE, "libscn_hip_tuning.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

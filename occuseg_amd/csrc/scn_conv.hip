@@ -184,6 +184,54 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Every (weight, orientation) pair of a network re-laid out by ONE launch (scn_weight_pack_batch): the reference reads the
+// module's weights on every call (sparseconvnet/SCN/CUDA/Convolution.cpp:105-162); here they are re-read once per
+// optimizer step / forward pass, all of them together.  Descriptor i covers blocks [first_block_i, first_block_{i+1}).
+struct WPackDesc {
+  const float *W;
+  float *Wp;
+  int32_t K, Cr, Cc, flags;  // flags: bit 0 transposed, bit 1 reverse, bit 2 plain (mode 0)
+  int64_t first_block;
+};
+constexpr int WPB_ELEMS = 2048;  // elements per block of k_weight_pack_multi
+__global__ void __launch_bounds__(256)
+    k_weight_pack_multi(const WPackDesc *__restrict__ descs, int n) {
+  // uniform binary search: the last descriptor whose first block is <= this block
+  int lo = 0, hi = n - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const WPackDesc d = descs[lo];
+  const int K = d.K, Cr = d.Cr, Cc = d.Cc;
+  const bool transposed = d.flags & 1, reverse = d.flags & 2, plain = d.flags & 4;
+  const int64_t total = (int64_t)K * Cr * Cc;
+  const int64_t t0 = (b - d.first_block) * WPB_ELEMS + threadIdx.x;
+  const int ncs = Cc / 16, nrs = Cr / 16;
+#pragma unroll
+  for (int j = 0; j < WPB_ELEMS / 256; ++j) {
+    const int64_t t = t0 + j * 256;
+    if (t >= total) break;
+    int k, r, c;
+    if (plain) {
+      k = (int)(t / ((int64_t)Cr * Cc));
+      const int rem = (int)(t % ((int64_t)Cr * Cc));
+      r = rem / Cc; c = rem % Cc;
+    } else {
+      unsigned u = (unsigned)(t >> 8);  // 256 elements per 16 x 16 block
+      const int e = (int)(t & 3), li = (int)((t >> 2) & 15), lq = (int)((t >> 6) & 3);
+      const int cs = (int)(u % (unsigned)ncs); u /= (unsigned)ncs;
+      const int rs = (int)(u % (unsigned)nrs); u /= (unsigned)nrs;
+      k = (int)u;
+      r = rs * 16 + lq * 4 + e;
+      c = cs * 16 + li;
+    }
+    const int ks = reverse ? K - 1 - k : k;
+    d.Wp[t] = transposed ? d.W[((int64_t)ks * Cc + c) * Cr + r] : d.W[((int64_t)ks * Cr + r) * Cc + c];
+  }
+}
+
 // ------------------------------------------------- forward, pipelined (v2) ---
 // Same decomposition as k_conv_tile, restructured so that the matrix pipe does not wait for HBM:
 //   * M = 32 NW output rows per workgroup (128 for 4 waves): fewer padded pair groups, W[k] fetched once
@@ -2717,6 +2765,27 @@ int scn_weight_pack(const float *W, int w_transposed, int w_reverse, int K, int 
   // fragment order for every kernel but the first synchronous one (which only the > 4 GiB fallback still uses)
   const bool plain = g_conv_variant == 1 || total * 4 >= ((int64_t)1 << 32);
   k_weight_pack<<<pg, 256, 0, stream>>>(W, (float *)wpack, K, Ci, Co, w_transposed, w_reverse, plain ? 0 : 1);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int64_t scn_weight_pack_blocks(int K, int Ci, int Co) {
+  if (K < 1 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0) return 0;  // the generic kernel reads W itself
+  return ((int64_t)K * Ci * Co + WPB_ELEMS - 1) / WPB_ELEMS;
+}
+
+int scn_weight_pack_flags(int w_transposed, int w_reverse, int K, int Ci, int Co) {
+  const bool plain = g_conv_variant == 1 || (int64_t)K * Ci * Co * 4 >= ((int64_t)1 << 32);
+  return (w_transposed ? 1 : 0) | (w_reverse ? 2 : 0) | (plain ? 4 : 0);
+}
+
+int scn_weight_pack_batch(const void *descs, int n, int64_t total_blocks, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  static_assert(sizeof(WPackDesc) == 40, "scn_wpack_desc layout");
+  SCN_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "scn_weight_pack_batch: bad arguments");
+  if (n == 0 || total_blocks == 0) return 0;
+  SCN_REQUIRE(descs != nullptr, "scn_weight_pack_batch: descriptor table missing");
+  k_weight_pack_multi<<<(unsigned)total_blocks, 256, 0, stream>>>((const WPackDesc *)descs, n);
   SCN_CHECK_LAUNCH();
   return 0;
 }

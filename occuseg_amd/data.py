@@ -47,6 +47,7 @@ class ScanNetCollate(object):
         self.scale = config["scale"]
         self.full_scale = config["full_scale"]
         self.use_normal = config.get("use_normal", False)
+        self.reference_normal_key = config.get("reference_normal_key", True)  # see _scene
         self.use_elastic = config.get("use_elastic", False)
         self.use_feature = config.get("use_feature", "c")
         self.use_rotation_noise = config.get("use_rotation_noise", False)
@@ -82,7 +83,11 @@ class ScanNetCollate(object):
     # -- one scene ---------------------------------------------------------------
     def _scene(self, s, train):
         a, b, c = np.asarray(s["coords"], np.float64), np.asarray(s["colors"]), np.asarray(s["w"])
-        d = np.asarray(s["normals"], np.float64) if "normals" in s else a  # scannet.py:91-94 (sic: falls back to coords)
+        # scannet.py:90-93 tests the key 'normal' but reads 'normals': on standard *_instance.pth files (key 'normals')
+        # the reference therefore ALWAYS takes the coordinates as d.  reference_normal_key=True (default) reproduces
+        # that; False reads the normals whenever the file has them (the evident intent).
+        has_normals = ("normal" in s and "normals" in s) if self.reference_normal_key else ("normals" in s)
+        d = np.asarray(s["normals"], np.float64) if has_normals else a
         e = np.asarray(s["depth"]) if "depth" in s else np.asarray(s["coords"])
         region_parts = np.asarray(s["region"]) if "region" in s else c[:, 1]
         m = self._transform(train)

@@ -32,6 +32,8 @@ class FlatGradBucket(object):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         p0 = self.params[0]
+        assert all(p.dtype == p0.dtype and p.device == p0.device for p in self.params), \
+            "FlatGradBucket: one dtype and one device for all parameters"
         self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
         off = 0
         self.offsets = []
@@ -90,7 +92,7 @@ class FlatGradBucket(object):
         i = self._index.get(id(param))
         g = param.grad
         return (i is not None and g is not None and g.is_contiguous()
-                and g.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[i])
+                and g.data_ptr() == self.flat.data_ptr() + self.flat.element_size() * self.offsets[i])
 
     def close(self):
         """give the parameters back: no direct accumulation, no hooks (the .grad views stay valid tensors)"""
@@ -163,6 +165,10 @@ class FlatGradBucket(object):
 
     def zero(self):
         """replacement for optimizer.zero_grad()"""
+        # dWeight kernels of the last backward pass may still run on the side stream (always, when that pass raised and
+        # autograd skipped its final callbacks): the buffer they accumulate into is not zeroed under them
+        SCN.dw_join()
+        SCN.weights_changed()  # a new step: packed weights are re-made from the parameters at their next use
         self.flat.zero_()
         if self._attach():
             warnings.warn("FlatGradBucket: some .grad tensors had been detached from the flat buffer "
@@ -178,6 +184,7 @@ class FlatGradBucket(object):
         if self._attach():
             warnings.warn("FlatGradBucket: some .grad tensors were not views of the flat buffer at all_reduce time "
                           "-- their values were copied in; use bucket.zero() instead of zero_grad()")
+        SCN.dw_join()  # single process too: the optimizer reads what the side stream accumulates
         for b in range(len(self.buckets)):
             self._launch(b)
         for w in self._work:

@@ -56,7 +56,9 @@ class ResidualConcatTable(ConcatTable):
         from .conv import SubmanifoldConvolution
         children = list(self._modules.values())
         body = list(children[1]._modules.values()) if len(children) == 2 and isinstance(children[1], Sequential) else []
-        if not body or not isinstance(body[-1], SubmanifoldConvolution):
+        # (the body's children are run by hand below: forward hooks on the body Sequential itself would not fire)
+        hooked = len(children) == 2 and (children[1]._forward_hooks or children[1]._forward_pre_hooks)
+        if not body or not isinstance(body[-1], SubmanifoldConvolution) or hooked:
             return ConcatTable.forward(self, input)
         shortcut = children[0](input)
         x = input

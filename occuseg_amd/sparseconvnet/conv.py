@@ -72,13 +72,10 @@ class _RuleConvFunction(Function):
         grad_bias = torch.zeros_like(bias)
         m = ctx.scn_meta
         # direct accumulation: nothing reads the weight gradient before the end of the backward pass, so the dWeight
-        # kernel may run on a side stream beside what follows (SCN.dw_async).  A convolution that hands its incoming
-        # gradient on as the gradient of the shortcut (below) must keep that tensor referenced until the side stream is
-        # joined (hold_grad): autograd otherwise ADDS INTO it in place where the shortcut's gradient meets the convolution
-        # path's, on the main stream, while the side stream still reads it (tools/stress_dw_side.py found this: 11 of 940
-        # gradients wrong in 20 runs); SCN.DW_HOLD_GRAD = False keeps such convolutions on the main stream instead.
-        residual_grad = ctx.needs_input_grad[10]
-        with SCN.dw_async(direct and (SCN.DW_HOLD_GRAD or not residual_grad), hold_grad=residual_grad):
+        # kernel may run on a side stream beside what follows (SCN.dw_async keeps grad_output referenced until that
+        # kernel has finished, so autograd cannot add another gradient into it in place meanwhile -- the shortcut of a
+        # residual block, add_feature_planes, AddTable: whatever shares this tensor)
+        with SCN.dw_async(direct):
             if ctx.kind == "submanifold":
                 SCN.SubmanifoldConvolution_backward(in_size, filter_size, m, features, grad_input, grad_output, weight,
                                                     grad_weight, grad_bias, ctx.dilated_rate)

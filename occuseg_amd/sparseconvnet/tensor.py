@@ -20,22 +20,33 @@ class SparseConvNetTensor(object):
     """features [N, planes] + the shared Metadata + the spatial size of the grid."""
 
     def __init__(self, features=None, metadata=None, spatial_size=None):
-        self.features = features
+        self._features = features
         self.metadata = metadata
         self.spatial_size = spatial_size
-        self._colstats = None  # (key of the features tensor, [(planes, partial column sums), ...]) -- see set_colstats
+        self._colstats = None  # (version of the features tensor, [(planes, partial column sums), ...]) -- see set_colstats
+
+    @property
+    def features(self):
+        return self._features
+
+    @features.setter
+    def features(self, value):
+        # whatever statistics the producing kernel handed over belong to the tensor that was here before
+        self._features = value
+        self._colstats = None
 
     def set_colstats(self, segments):
-        """column statistics of ``features`` emitted by the kernel(s) that produced it (not in the reference): valid
-        only for exactly this features tensor in exactly this version"""
-        f = self.features
-        self._colstats = ((f.data_ptr(), f._version, tuple(f.shape)), list(segments)) if segments else None
+        """Column statistics of ``features`` emitted by the kernel(s) that produced it (not in the reference).  They
+        travel with THIS assignment of ``features``: assigning ``features`` again drops them, and an in-place
+        operation on the tensor (version counter) invalidates them.  Not visible to either: a write through
+        ``features.data`` -- call ``set_colstats(None)`` after one (the batch norm then reads the tensor itself)."""
+        f = self._features
+        self._colstats = (f._version, list(segments)) if segments and f is not None else None
 
     def get_colstats(self):
-        if self._colstats is None or self.features is None:
+        if self._colstats is None or self._features is None:
             return None
-        f = self.features
-        return self._colstats[1] if self._colstats[0] == (f.data_ptr(), f._version, tuple(f.shape)) else None
+        return self._colstats[1] if self._colstats[0] == self._features._version else None
 
     def get_spatial_locations(self, spatial_size=None):
         """LongTensor [N,4]: coordinates and batch index of the active sites"""

@@ -46,10 +46,12 @@ def pytest_collection_finish(session):
     if "test_bench_two_ranks_code_path" in names:
         log = os.path.join(tmp, "bench2.log")
         e = dict(env, SCN_BENCH_BACKEND="gloo", SCN_BENCH_ONE_DEVICE="1")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--planes", "16",
-               "--sites", "5000", "--scenes-per-gpu", "2", "--no-cpu-baseline"]
+        # exactly how the driver starts it: `python bench.py --gpus N ...`, no launcher -- bench.py starts
+        # torch.distributed.run on itself as a child process (WORLD_SIZE must not leak in from the environment)
+        e.pop("WORLD_SIZE", None)
+        e.pop("RANK", None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--planes", "16", "--sites", "5000", "--scenes-per-gpu", "2", "--no-cpu-baseline"]
         jobs["bench2"] = {"procs": [subprocess.Popen(cmd, env=e, stdout=open(log, "w"), stderr=subprocess.STDOUT,
                                                      cwd=ROOT)], "log": log}
 

@@ -87,7 +87,11 @@ def test_normals_and_feature_selection(tmp_path):
     from occuseg_amd import data
     cfg = {"scale": 50, "full_scale": 4096, "use_normal": True, "use_feature": "lcnh", "regress_sigma": 0.2}
     scenes = [data.load_scene(_scene_file(tmp_path, 5, with_normals=True))]
-    b = data.ScanNetCollate(cfg, rng=np.random.default_rng(0)).trainMerge([0], scenes)
+    # default = the reference's key test ('normal' in the dict, scannet.py:90, while the files say 'normals'): d is the
+    # COORDINATES, rotated and divided by the scale -- not unit vectors
+    ref = data.ScanNetCollate(cfg, rng=np.random.default_rng(0)).trainMerge([0], scenes)
+    assert not torch.allclose(torch.norm(ref["x"][2], dim=1), torch.ones(len(ref["x"][0])), atol=1e-2)
+    b = data.ScanNetCollate(dict(cfg, reference_normal_key=False), rng=np.random.default_rng(0)).trainMerge([0], scenes)
     locs, feats, normals, bs = b["x"]
     assert feats.shape == (len(locs), 3 + 3 + 3 + 1) and normals.shape == (len(locs), 3) and bs == 1
     # normals are rotated / flipped with the scene and keep unit length (d @ m / scale, scannet.py:120)

@@ -6,8 +6,9 @@ for them:
   * two ranks (gloo backend, both on cuda:0) run the mirror's UNet with FlatGradBucket.enable_overlap() on their own
     two scenes: reduced gradient == mean of the two local gradients at 1e-5, every bucket launched exactly once, from
     backward, and only after the last write into its range (SURVEY.md section 8e's parity statement);
-  * `bench.py --gpus 2` through torch.distributed.run with SCN_BENCH_BACKEND=gloo SCN_BENCH_ONE_DEVICE=1: the N > 1
-    branch of the bench (sharding, overlapped all-reduce, max-over-ranks timing, one JSON line from rank 0).
+  * `python bench.py --gpus 2` exactly as the driver calls it (no launcher: bench.py starts torch.distributed.run on
+    itself as a child process) with SCN_BENCH_BACKEND=gloo SCN_BENCH_ONE_DEVICE=1: the N > 1 branch of the bench
+    (sharding, overlapped all-reduce, max-over-ranks timing, one JSON line from rank 0).
 RCCL over xGMI itself needs more than one GPU: only the driver's 8-GPU run exercises it.
 """
 import json
@@ -55,4 +56,4 @@ def test_bench_two_ranks_code_path(request):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["parallelism"] == "dp2" and res["config"]["allreduce_bytes"] > 0
-    assert res["config"]["backend"] == "gloo"
+    assert res["config"]["backend"] == "gloo" and res["config"]["ranks_seen"] == 2
