@@ -552,8 +552,11 @@ def _repack_all(device):
         if base is None or base.data_ptr() + ent.off != ent.ptr:
             _WPACK.pop(key, None)  # freed, or re-seated through `.data = ...`: the next use packs afresh
             continue
-        if base.device == device and ent.blocks > 0:
-            live.append((ent, base))
+        if base.device == device:
+            if ent.blocks > 0:
+                live.append((ent, base))
+            else:  # planes that are not multiples of 16: the generic kernel reads the module's weights itself
+                ent.version, ent.epoch = base._version, _WEPOCH[0]
     if not live:
         return
     sig = tuple((ent.ptr, ent.wpack.data_ptr()) + ent.dims + (ent.flags,) for ent, _ in live)
@@ -606,8 +609,9 @@ def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
         ent.flags = lib.scn_weight_pack_flags(int(w_transposed), int(w_reverse), K, Ci, Co)
         ent.blocks = lib.scn_weight_pack_blocks(K, Ci, Co)
         _WPACK[key] = ent
-    check(lib.scn_weight_pack(ptr(weight), int(w_transposed), int(w_reverse), K, Ci, Co, ptr(ent.wpack), stream()))
-    WPACK_STATS["single"] += 1
+    if ent.blocks > 0:
+        check(lib.scn_weight_pack(ptr(weight), int(w_transposed), int(w_reverse), K, Ci, Co, ptr(ent.wpack), stream()))
+        WPACK_STATS["single"] += 1
     ent.version = weight._version
     ent.epoch = _WEPOCH[0]
     return ent.wpack, 1

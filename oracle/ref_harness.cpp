@@ -12,6 +12,8 @@
 // reference's helpers (it is the loop body of sparseconvnet/SCN/CPU/Convolution.cpp:60-68).
 // No reference source text is copied into this repository; nothing here stands in for CUDA/CUDPP.
 #include <ATen/ATen.h>
+#include <ATen/Parallel.h>
+#include <omp.h>
 
 #include <cmath>
 #include <cstdint>
@@ -34,6 +36,12 @@ static at::Tensor wrap(float *p, int64_t r, int64_t c) {
 }
 
 extern "C" {
+
+// threads of the reference's `#pragma omp parallel for` loops (CPU/Convolution.cpp:15,26, CPU/IOLayers.cpp:16) and of at::mm
+void ref_set_threads(int n) {
+  omp_set_num_threads(n);
+  at::set_num_threads(n);
+}
 
 void ref_bn_forward(float *x, float *y, int32_t nPlanes, int32_t nActive, float *saveMean, float *saveInvStd,
                     float *runningMean, float *runningVar, float *weight, float *bias, float eps, float momentum,

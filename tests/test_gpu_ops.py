@@ -232,16 +232,26 @@ def test_network_in_network(gpu, ci, co, with_bias):
     assert_close(gw.cpu().numpy(), d_w, "NiN dWeight")
 
 
-@pytest.mark.parametrize("ci,co", [(64, 64), (128, 64), (64, 128), (320, 64)])
-def test_submanifold_forward_variants(gpu, ci, co):
-    """The barrier-free two-wave forward kernel (default where it applies: >= 512 tiles, C_i a multiple of 64 up to
-    320, C_o a multiple of 64 -- hence the larger grid) and the LDS-staged kernel (scn_set_tuning(0, 2), which only
-    libscn_hip_tuning.so exports) against the float64 oracle and against each other; then the product library
-    against the tuning build's default (same sources, same kernel: bit-identical)."""
+# (C_i, C_o, points per sample, extent): the last five are the shapes that carry k_conv_tile4's time in the m64 train step
+# (levels 1 and 2 of the UNet, forward and -- with the planes swapped -- dInput), on grids just large enough for
+# >= 512 tiles of 128 rows x 64 planes
+TILE4_SHAPES = [(64, 64, 72000, 60), (128, 64, 72000, 60), (64, 128, 72000, 60), (320, 64, 72000, 60),
+                (128, 128, 20000, 40), (256, 128, 20000, 40), (192, 192, 13000, 35), (384, 192, 13000, 35),
+                (128, 256, 10000, 32)]
+
+
+@pytest.mark.parametrize("ci,co,n,extent", TILE4_SHAPES)
+def test_submanifold_forward_variants(gpu, ci, co, n, extent):
+    """The barrier-free two-wave kernel k_conv_tile4 (default where it applies: >= 512 tiles, C_i a multiple of 64 up to
+    384, C_o a multiple of 64) and the LDS-staged kernel (scn_set_tuning(0, 2), which only libscn_hip_tuning.so
+    exports) against the float64 oracle (arithmetic of sparseconvnet/SCN/CPU/Convolution.cpp:114-189) and against
+    each other; then the product library against the tuning build's default (same sources, same kernel:
+    bit-identical); then dInput and dWeight of the same layer."""
     from occuseg_amd import SCN, _lib
     from oracle import arith as A, rules as R
-    m, size, grid, _, _ = _setup(gpu, seed=11, n=72000, batch=2, extent=60)
-    assert grid.n > 66000
+    m, size, grid, _, _ = _setup(gpu, seed=11, n=n, batch=2, extent=extent)
+    lib0 = _lib.load()
+    assert lib0.scn_conv_plan(27, grid.n, grid.n, grid.n, ci, co, 0) == 401, "forward not on k_conv_tile4"
     rules, _ = R.submanifold_rules(grid)
     rng = np.random.default_rng(ci + co)
     x = rng.normal(size=(grid.n, ci)).astype(np.float32)
@@ -269,14 +279,58 @@ def test_submanifold_forward_variants(gpu, ci, co):
     assert_close(outs[2], want, "variant 2 forward %d->%d" % (ci, co))
     # same per-(offset, chunk) summation order in both kernels: bit-identical
     assert np.array_equal(outs[4], outs[2])
-    # dInput (transposed weights, offsets reversed) through the default kernel
-    if ci <= 128:
-        dy = rng.normal(size=(grid.n, co)).astype(np.float32)
-        d_in, d_w, _ = A.conv_backward(x, dy, w, rules, dtype=np.float64)
-        gi, gw, gb = torch.empty(0, device=gpu), torch.zeros(27, ci, co, device=gpu), torch.zeros(co, device=gpu)
-        SCN.SubmanifoldConvolution_backward(size, F3, m, _t(x, gpu), gi, _t(dy, gpu), _t(w, gpu), gw, gb, 1)
-        assert_close(gi.cpu().numpy(), d_in, "large submanifold dInput")
-        assert_close(gw.cpu().numpy(), d_w, "large submanifold dWeight")
+    # dInput (transposed weights, offsets reversed: planes swapped) and dWeight of the same layer
+    dy = rng.normal(size=(grid.n, co)).astype(np.float32)
+    d_in, d_w, _ = A.conv_backward(x, dy, w, rules, dtype=np.float64)
+    gi, gw, gb = torch.empty(0, device=gpu), torch.zeros(27, ci, co, device=gpu), torch.zeros(co, device=gpu)
+    SCN.SubmanifoldConvolution_backward(size, F3, m, _t(x, gpu), gi, _t(dy, gpu), _t(w, gpu), gw, gb, 1)
+    assert_close(gi.cpu().numpy(), d_in, "large submanifold dInput %d->%d" % (co, ci))
+    assert_close(gw.cpu().numpy(), d_w, "large submanifold dWeight")
+    if (ci, co) in ((128, 128), (256, 128), (192, 192), (384, 192)):  # C_o of the dInput = ci: enough plane blocks
+        assert lib0.scn_conv_plan(27, grid.n, grid.n, grid.n, co, ci, 0) == 401, "dInput not on k_conv_tile4"
+
+
+def test_tile4_residual_and_column_statistics_at_384_192(gpu):
+    """the widest k_conv_tile4 launch of the m64 step (decoder level 2: six 64-plane chunks, LDS to the byte) with the
+    shortcut added inside the kernel and the column statistics for the following batch norm taken from the tile"""
+    from occuseg_amd import SCN, _lib
+    from oracle import arith as A, rules as R
+    ci, co = 384, 192
+    m, size, grid, _, _ = _setup(gpu, seed=12, n=13000, batch=2, extent=35)
+    assert _lib.load().scn_conv_plan(27, grid.n, grid.n, grid.n, ci, co, 0) == 401
+    rules, _ = R.submanifold_rules(grid)
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(grid.n, ci)).astype(np.float32)
+    w = (rng.normal(size=(27, ci, co)) * (2.0 / ci / 27) ** 0.5).astype(np.float32)
+    res = rng.normal(size=(grid.n, co)).astype(np.float32)
+    want, _ = A.conv_forward(x, w, rules, grid.n, None, dtype=np.float64)
+    want = want + res
+    out, sink = torch.empty(0, device=gpu), []
+    SCN.SubmanifoldConvolution_updateOutput(size, F3, m, _t(x, gpu), out, _t(w, gpu), torch.empty(0, device=gpu), 1,
+                                            residual=_t(res, gpu), stats_out=sink)
+    assert_close(out.cpu().numpy(), want, "tile4 384->192 + residual")
+    assert len(sink) == 1 and sink[0].shape[1:] == (2, co)
+    part = sink[0].double().sum(0).cpu().numpy()
+    assert_close(part[0], want.sum(0), "column sums", scale=np.abs(want).sum(0).max())
+    assert_close(part[1], (want * want).sum(0), "column sums of squares")
+
+
+def test_tile4_equals_tile2_bitwise_sweep(gpu):
+    """300 randomised launches (clouds of varying density / extent / batch, C_i 64..384, C_o 64..256, submanifold and
+    strided rulebooks in both directions, plain / transposed / reversed weights, with and without bias) through
+    k_conv_tile4 and through k_conv_tile2: same summation order, so every output must be BIT-identical -- any
+    scheduling hazard in the hand-written load pipeline of k_conv_tile4 shows up as a difference"""
+    import os
+    import sys
+    from occuseg_amd import SCN, _lib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_variants
+    try:
+        ran4, bad = stress_variants.run(300, 0, max_points=150000, verbose=False)
+    finally:
+        _lib.use_product_build()
+        SCN.invalidate_weight_cache()
+    assert bad == 0 and ran4 >= 100, (ran4, bad)
 
 
 @pytest.mark.parametrize("ci,co,n", [(64, 64, 72000), (32, 32, 3000), (128, 64, 3000), (3, 16, 3000)])

@@ -130,16 +130,20 @@ def test_colstats_follow_the_features_assignment(gpu):
     from occuseg_amd import scenes
     scn = occuseg_amd.install()
     torch.manual_seed(13)
-    coords, feats = scenes.batch([1003], target_sites=4000)
+    coords, feats = scenes.batch([1003], target_sites=70000)  # >= 512 tiles: a launch that emits the statistics
     inp = scn.InputLayer(3, 4096, mode=4)
-    conv = scn.SubmanifoldConvolution(3, 3, 32, 3, False).to(gpu)
-    bn = scn.BatchNormReLU(32).to(gpu)
+    stem = scn.SubmanifoldConvolution(3, 3, 64, 3, False).to(gpu)
+    conv_ = scn.SubmanifoldConvolution(3, 64, 64, 3, False).to(gpu)
+    bn = scn.BatchNormReLU(64).to(gpu)
+
+    def conv(t):
+        return conv_(stem(t))
     x = conv(inp([torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 1]))
     assert x.get_colstats() is not None
     bn(x)  # consumes the handed-over statistics
     x.features = x.features * 2.0 + 1.0  # re-assigned: the statistics are gone, the batch norm reads the tensor
     assert x.get_colstats() is None
-    bn2 = scn.BatchNormReLU(32).to(gpu)
+    bn2 = scn.BatchNormReLU(64).to(gpu)
     y1 = bn2(x).features
     f = x.features.detach().double()
     want = torch.relu((f - f.mean(0)) / torch.sqrt(f.var(0, unbiased=False) + bn2.eps))

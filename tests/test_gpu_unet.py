@@ -333,3 +333,130 @@ def test_cfg3_full_size_properties(gpu):
     out2 = net(batch)
     assert not SCN._PREFETCHED
     assert torch.equal(out2, out)
+
+
+def test_headline_unet_levels_0_to_2_on_tile4(gpu):
+    """test_headline_unet_six_levels runs at 2 x 20k sites, where every launch has fewer than 512 tiles and goes through
+    k_conv_tile2 (+ offset split + expand).  Here: the m64 network's levels 0-2 at 2 x 70k sites, so that the autograd
+    path drives k_conv_tile4 -- the kernel that is half of the train step -- forward, dInput, shortcut and column
+    statistics included, against the float64 oracle with the device's activation masks; every gradient at 1e-4."""
+    import occuseg_amd
+    from occuseg_amd import _lib, scenes
+    from oracle import torch_ref
+    scn = occuseg_amd.install()
+    m = 64
+    torch.manual_seed(164)
+    coords, feats = scenes.batch([1000, 1001], target_sites=70000)
+    net = _net(scn, m, 3, 0.0)
+    ref_out, stats0 = torch_ref.ref_forward(net, coords, feats, torch.float64)
+    gsel = torch.from_numpy(np.random.default_rng(1).normal(size=tuple(ref_out.shape)))
+    ctx = stats0["ctx"]
+    sizes = sorted(ctx.grids, reverse=True)
+    n0, n1 = ctx.grids[sizes[0]].n, ctx.grids[sizes[1]].n
+    lib = _lib.load()
+    for n, shapes in ((n0, [(64, 64), (128, 64)]), (n1, [(128, 128), (256, 128)])):
+        for ci, co in shapes:
+            assert lib.scn_conv_plan(27, n, n, n, ci, co, 0) == 401, (n, ci, co)
+    net = net.to(gpu)
+    masks, hooks = {}, []
+    for mod in net.modules():
+        if isinstance(mod, scn.BatchNormalization):
+            hooks.append(mod.register_forward_hook(
+                lambda md, inp, out: masks.__setitem__(id(md), (out.features.detach() > 0).cpu())))
+    out = net([torch.from_numpy(coords), torch.from_numpy(feats).to(gpu), None, 2])
+    for h in hooks:
+        h.remove()
+    (out * gsel.to(gpu, torch.float32)).sum().backward()
+    assert_close(out.detach().cpu().numpy(), ref_out.detach().numpy(), "m64 x 3 levels output (tile4)")
+    flips = sum(int((masks[k] != stats0["own_masks"][k]).sum()) for k in masks)
+    assert flips < 1e-4 * sum(v.numel() for v in masks.values())
+    ref_out2, stats = torch_ref.ref_forward(net, coords, feats, torch.float64, masks=masks)
+    (ref_out2 * gsel).sum().backward()
+    _grads_vs_oracle(net, stats, rel=1e-4)
+    out2 = net([torch.from_numpy(coords), torch.from_numpy(feats).to(gpu), None, 2])
+    assert torch.equal(out2, out)
+
+
+class _RefStyleResidualNet(torch.nn.Module):
+    """residual blocks the way the reference's own model file builds them (examples/ScanNet/model.py:17-33:
+    `scn.add_feature_planes([y1, y2])`) and the plain ConcatTable -> AddTable form (sparseconvnet/networkArchitectures.py:222-229)
+    WITHOUT ResidualConcatTable: in both, AddBackward hands ONE gradient tensor to the body's last convolution and to
+    the shortcut"""
+
+    def __init__(self, scn, m):
+        torch.nn.Module.__init__(self)
+        self.scn = scn
+        self.inp = scn.InputLayer(3, 4096, mode=4)
+        self.stem = scn.SubmanifoldConvolution(3, 3, m, 3, False)
+        self.bn = torch.nn.ModuleList([scn.BatchNormReLU(m) for _ in range(4)])
+        self.sc = torch.nn.ModuleList([scn.SubmanifoldConvolution(3, m, m, 3, False) for _ in range(4)])
+        self.table = scn.Sequential().add(
+            scn.ConcatTable().add(scn.Identity()).add(
+                scn.Sequential().add(scn.BatchNormReLU(m)).add(scn.SubmanifoldConvolution(3, m, m, 3, False))
+                .add(scn.BatchNormReLU(m)).add(scn.SubmanifoldConvolution(3, m, m, 3, False)))).add(scn.AddTable())
+        self.out = scn.OutputLayer(3)
+
+    def forward(self, batch):
+        x = self.stem(self.inp(batch))
+        for i in (0, 2):
+            y = self.sc[i + 1](self.bn[i + 1](self.sc[i](self.bn[i](x))))
+            x = self.scn.add_feature_planes([x, y])
+        return self.out(self.table(x))
+
+
+def test_dweight_side_stream_with_shared_gradient_tensors(gpu):
+    """round-2 advisor finding: with the default DW_SIDE_STREAM a convolution whose grad_output is ALSO the shortcut's
+    gradient (add_feature_planes, ConcatTable + AddTable) had its dOut overwritten in place by autograd's gradient
+    accumulation while the side-stream dWeight kernel still read it.  Every dOut that goes to the side stream is now
+    kept referenced until that kernel has finished.  30 double backward passes against the plain autograd path; then a
+    backward pass that RAISES (autograd skips its final callbacks) must not leave the side stream un-joined."""
+    import occuseg_amd
+    from occuseg_amd import SCN, dp, scenes
+    scn = occuseg_amd.install()
+    torch.manual_seed(6)
+    net = _RefStyleResidualNet(scn, 32).to(gpu)
+    assert not any(isinstance(mod, scn.ResidualConcatTable) for mod in net.modules())
+    coords, feats = scenes.batch([1000, 1001], target_sites=30000)
+    batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
+    for p in net.parameters():
+        p.grad = None
+    net(batch).sum().backward()
+    net(batch).sum().backward()
+    plain = [p.grad.clone() for p in net.parameters()]
+    bucket = dp.FlatGradBucket(net.parameters())
+    assert SCN.DW_SIDE_STREAM
+    try:
+        for it in range(30):
+            bucket.zero()
+            net(batch).sum().backward()
+            net(batch).sum().backward()
+            bucket.all_reduce_mean()
+            for (name, p), ref in zip(net.named_parameters(), plain):
+                err = (p.grad - ref).abs().max().item()
+                assert err <= 1e-4 * ref.abs().max().item() + 1e-30, (it, name, err)
+        # a backward pass that raises half way
+        class _Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                return x.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("boom")
+
+        bucket.zero()
+        x = net.stem(net.inp(batch))
+        y = net.sc[1](net.bn[1](net.sc[0](net.bn[0](x))))
+        x.features = _Boom.apply(x.features)
+        with pytest.raises(RuntimeError, match="boom"):
+            net.out(net.table(scn.add_feature_planes([x, y]))).sum().backward()
+        for it in range(3):  # ... and the next steps are right
+            bucket.zero()
+            net(batch).sum().backward()
+            net(batch).sum().backward()
+            bucket.all_reduce_mean()
+            for (name, p), ref in zip(net.named_parameters(), plain):
+                err = (p.grad - ref).abs().max().item()
+                assert err <= 1e-4 * ref.abs().max().item() + 1e-30, ("after a failed backward", it, name, err)
+    finally:
+        bucket.close()

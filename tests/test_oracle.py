@@ -285,3 +285,34 @@ def test_scatter_oracle_formulas():
     assert np.allclose(O.scatter_std(src, idx, 4)[2], 0)  # a single element: count - 1 clamped to 1
     mx, arg = O.scatter_max(src, idx, 4)
     assert mx.tolist() == [[7, 7], [0, 0], [5, 1], [0, 0]] and arg.tolist() == [[3, 3], [4, 4], [2, 2], [4, 4]]
+
+
+def test_reference_loops_network_matches_the_autograd_oracle():
+    """bench.py's cpu_baseline ("reference"): oracle/ref_net.py walks the network over the reference's compiled CPU loops
+    (oracle/_ref) with an explicit backward pass.  Pinned here against the torch-autograd oracle (float64) on a small
+    UNet: it IS the same computation -- forward at 1e-4; gradients at 1e-2 with ReLU (float32 masks flip), at 1e-4
+    without."""
+    from oracle import ref as REF, ref_net, torch_ref
+    if not REF.available():
+        pytest.skip("oracle/_ref/libscn_ref.so not built (needs /root/reference)")
+    import occuseg_amd
+    from occuseg_amd import scenes
+    scn = occuseg_amd.install()
+    coords, feats = scenes.batch([1000, 1001], 3000)
+    for leak, rel in ((0.0, 1e-2), (1.0, 1e-4)):
+        torch.manual_seed(3)
+        m = 16
+        net = scn.Sequential().add(scn.InputLayer(3, 4096, mode=4)).add(scn.SubmanifoldConvolution(3, 3, m, 3, False)).add(
+            scn.UNet(3, 1, [m, 2 * m, 3 * m], residual_blocks=True, leakiness=leak)).add(
+            scn.BatchNormalization(m, leakiness=leak)).add(scn.OutputLayer(3))
+        want, stats = torch_ref.ref_forward(net, coords, feats, torch.float64)
+        want.sum().backward()
+        got, grads, sec, _ctx = ref_net.forward_backward(net, coords, feats, threads=2)
+        assert_close(got, want.detach().numpy(), "reference-loops forward")
+        assert sec["total"] > 0 and sec["conv"] > 0
+        n = 0
+        for mod in net.modules():
+            for name, leaf in (stats["params"].get(id(mod)) or {}).items():
+                assert_close(grads[(id(mod), name)], leaf.grad.numpy(), "reference-loops grad %s.%s" % (mod, name), rel=rel)
+                n += 1
+        assert n == len(list(net.parameters()))

@@ -27,15 +27,14 @@ net(batch).sum().backward()
 plain = [p.grad.clone() for p in net.parameters()]
 names = [n for n, _ in net.named_parameters()]
 bucket = dp.FlatGradBucket(net.parameters())
-variants = sys.argv[1:] or ["side", "off", "nohold", "hostsync_each", "hostsync_end"]
+variants = sys.argv[1:] or ["side", "off", "hostsync_each", "hostsync_end"]
 orig_end, orig_finish = SCN._dw_side_end, SCN._dw_finish
 for v in variants:
     SCN.DW_SIDE_STREAM = v != "off"
-    SCN.DW_HOLD_GRAD = v != "nohold"
     SCN._dw_side_end, SCN._dw_finish = orig_end, orig_finish
     if v == "hostsync_each":
-        def end(side, _o=orig_end):
-            _o(side)
+        def end(side, d_out, _o=orig_end):
+            _o(side, d_out)
             side.synchronize()
         SCN._dw_side_end = end
     if v == "hostsync_end":
