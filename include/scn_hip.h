@@ -148,6 +148,10 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
  *   wpack_ready = 0: scn_conv_forward packs (W, w_transposed, w_reverse) into it first; 1: the caller already ran
  *   scn_weight_pack for exactly this (W contents, w_transposed, w_reverse) -- weights change once per optimizer
  *   step, not once per call -- and W is not read (planes that are not multiples of 16 always read W itself).
+ *   tile_order (may be NULL): int32 [ceil(n_out / 128)], a permutation of the 128-row output tiles = the order in which
+ *   the big launches (k_conv_tile4) start them.  A caller that knows the pair count of every tile (from `bases`) puts the
+ *   light tiles last, so that the last round of workgroups -- the tail in which the chip runs dry -- is short.  Results do
+ *   not depend on it (every tile is computed by one workgroup in a fixed summation order).
  *   workspace: scn_conv_workspace_bytes(...) bytes (0 for most launches).  Launches with few output tiles (the coarse
  *   UNet levels) split their offsets over several workgroups per tile; the partial tiles go to the workspace and are
  *   added in a fixed order, so every launch is bitwise reproducible run to run (the reference scatters with float
@@ -179,7 +183,7 @@ int scn_weight_pack_batch(const void *descs, int n, int64_t total_blocks, void *
 int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
                      const float *bias, const float *residual, float *colstats, const int32_t *rules,
-                     const int32_t *bases, const int32_t *counts,
+                     const int32_t *bases, const int32_t *tile_order, const int32_t *counts,
                      int K, int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in,
                      int64_t n_out, int Ci, int Co, void *wpack, int wpack_ready, void *workspace,
                      size_t workspace_bytes, void *stream);

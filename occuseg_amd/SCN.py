@@ -88,6 +88,8 @@ def _need_cuda(t, what):
 _PLANS = {}
 _PLANS_USED = {}  # spatial size -> the request list of the most recent forward pass that really ran (tools, bench)
 PREBUILD = True
+TILE_ORDER = 1       # 0: tiles start in index order; 1: the lightest TILE_ORDER_TAIL of them last; 2: longest first
+TILE_ORDER_TAIL = 0.25
 KEEP_NBR = False  # tests only: keep each submanifold rulebook's neighbour table (`d_global_query_result`) alive
 _COORD_DTYPES = {torch.int32: 0, torch.int64: 1, torch.float32: 2}  # scn_grid_build coords_dtype
 
@@ -113,7 +115,7 @@ class _Grid(object):
 class _RuleBook(object):
     """Device rulebook: rules int32 [K, stride, 2], counts int32 [K] (device),
     tile-base tables per output column."""
-    __slots__ = ("K", "stride", "rules", "counts", "bases", "n_rows", "total_pairs", "nbr", "unique_col", "ori",
+    __slots__ = ("K", "stride", "rules", "counts", "bases", "order", "n_rows", "total_pairs", "nbr", "unique_col", "ori",
                  "class_books")
 
     def __init__(self, K, stride, rules, counts):
@@ -122,6 +124,7 @@ class _RuleBook(object):
         self.rules = rules
         self.counts = counts
         self.bases = {}      # out_col -> int32 [K, n_gran+1]
+        self.order = {}      # out_col -> int32 [tiles of 128 rows]: dispatch order of the big launches (may be absent)
         self.n_rows = {}     # out_col -> number of output rows
         self.total_pairs = None
         self.nbr = None
@@ -284,7 +287,7 @@ class Metadata_3(object):
                 if t is not None:
                     yield t
         for rb in list(self.submanifoldRuleBooks.values()) + list(self.ruleBooks.values()):
-            for t in [rb.rules, rb.counts, rb.nbr, rb.ori] + list(rb.bases.values()):
+            for t in [rb.rules, rb.counts, rb.nbr, rb.ori] + list(rb.bases.values()) + list(rb.order.values()):
                 if t is not None:
                     yield t
         for sn, ori in self.normals.values():
@@ -326,6 +329,24 @@ class Metadata_3(object):
                                  ptr(bases), stream()))
         rb.bases[out_col] = bases
         rb.n_rows[out_col] = n_out
+        # Dispatch order of the 128-row tiles of the big launches (scn_conv_forward's tile_order): heavy tiles keep their
+        # place (neighbouring tiles gather overlapping rows and share an L2), the lightest TILE_ORDER_TAIL of them move to
+        # the end, lightest last.
+        n_tiles = (n_out + 127) // 128
+        if TILE_ORDER and rb.K > 1 and n_tiles >= 512 // 4:
+            lo = torch.arange(n_tiles, device=bases.device) * 4
+            hi = torch.clamp(lo + 4, max=n_gran)
+            work = (bases[:, hi] - bases[:, lo]).sum(0)
+            if TILE_ORDER == 2:  # full longest-first order
+                order = torch.argsort(work, descending=True, stable=True)
+            else:
+                by_work = torch.argsort(work, descending=True, stable=True)
+                n_tail = int(n_tiles * TILE_ORDER_TAIL)
+                tail = by_work[n_tiles - n_tail:]
+                keep = torch.ones(n_tiles, dtype=torch.bool, device=bases.device)
+                keep[tail] = False
+                order = torch.cat([torch.nonzero(keep).view(-1), tail])
+            rb.order[out_col] = order.to(torch.int32).contiguous()
 
     def getSubmanifoldRuleBook(self, spatialSize, filterSize, dilated_rate=1, _defer=False):
         """cache key (spatialSize, filterSize) as sparseconvnet/SCN/Metadata/Metadata.cpp:504-529"""
@@ -409,11 +430,18 @@ class Metadata_3(object):
         key = iS + fs + st
         rb = self.ruleBooks.get(key)
         if rb is None and iS in self.normals and iS[0] >= self.normal_guide_scale:
+            # The reference's GPU builder for this case cannot have run: in its rule loop the output index is consumed
+            # TWICE per (input, output) pair -- `out_index[query_index++]` for the orientation and again for the pair
+            # (sparseconvnet/SCN/Metadata/ConvolutionRules.h:224,227) -- while `out_index` holds ONE entry per pair
+            # (:181-182): the orientation is taken from another site's normal and from pair n/2 on the reads run past the
+            # end of the vector (undefined behaviour).  There is no reference behaviour to reproduce; the fork's shipped
+            # configuration never gets here (rotation_guide_level 0: examples/ScanNet/config.py:50, model.py:626).
             raise NotImplementedError(
                 "normal-guided STRIDED rules (input spatial size %d >= normal_guide_scale %d) are not built: the "
-                "reference takes its hash-map path there (sparseconvnet/SCN/Metadata/ConvolutionRules.h:770-828, "
-                ":40-105); with the default rotation_guide_level 0 (examples/ScanNet/config.py:50, model.py:626) the "
-                "normals guide the input scale only, which is what this backend provides" % (iS[0], self.normal_guide_scale))
+                "reference's own GPU path for them (sparseconvnet/SCN/Metadata/ConvolutionRules.h:139-236) indexes "
+                "out of bounds (query_index is incremented twice per pair, :224 and :227) and has no defined result; with "
+                "the default rotation_guide_level 0 (examples/ScanNet/config.py:50, model.py:626) the normals guide the "
+                "input scale only, which is what this backend provides" % (iS[0], self.normal_guide_scale))
         if rb is None:
             lib = _lib_()
             fine = self.grids[iS]
@@ -646,7 +674,8 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None, ptr(residual), ptr(cstats),
-                               ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.counts), K, rb.stride, in_col, out_col, uniq,
+                               ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.order.get(out_col)), ptr(rb.counts), K, rb.stride,
+                               in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
     # algorithmic work of one launch: flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co

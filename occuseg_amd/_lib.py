@@ -37,7 +37,7 @@ SIGNATURES = {
     "scn_weight_pack_flags": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "scn_weight_pack_batch": (c_int, [_P, c_int, c_int64, _P]),
     "scn_conv_stats_blocks": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
-    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
+    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
                                  c_int64, c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),

@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
                  const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
-                 unsigned in_bytes, unsigned wp_bytes, int ksplit) {
+                 unsigned in_bytes, unsigned wp_bytes, int ksplit, const int32_t *__restrict__ tile_order) {
   constexpr int M = 128, COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
   constexpr int TMAX = KMAX * 4 * SCN_TILE4_MAX_CHUNKS + 8;  // passes per tile: <= 4 per (offset, chunk); + sentinels
   __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
@@ -729,7 +729,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       lin = full + (x2 < r ? x2 * (q + 1) : r * (q + 1) + (x2 - r) * q) + j2;
     }
   }
-  const int tile = lin / ncb;
+  // tile_order (may be NULL): position in the dispatch order -> tile.  Workgroups start in blockIdx order; a list that ends
+  // with the LIGHT tiles (few pairs) keeps the last round of the launch short -- the tail in which the chip runs dry
+  // was ~10 % of a launch with tiles of arbitrary weight at the end (4.6 rounds of 1024 resident workgroups).
+  const int tile = tile_order ? __builtin_amdgcn_readfirstlane(tile_order[lin / ncb]) : lin / ncb;
   const int co0 = (lin % ncb) * COB;
   const int64_t o0 = (int64_t)tile * M;
   const int g0 = tile * (M / SCN_TILE_GRANULE);
@@ -2587,7 +2590,7 @@ static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ?
 
 static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, float *colstats, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
-                        int Ci, int Co, int ksplit, float *part, hipStream_t stream) {
+                        int Ci, int Co, int ksplit, float *part, const int32_t *tile_order, hipStream_t stream) {
   const int M = tile4_rows(ksplit);
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
@@ -2639,7 +2642,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 #define SCN_LAUNCH_TILE4(D)                                                                                         \
   k_conv_tile4<D><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,                     \
                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
-                                             in_bytes, wp_bytes, ksplit)
+                                             in_bytes, wp_bytes, ksplit, tile_order)
 #ifdef SCN_TUNING
   if (g_conv_tile5 != 0) {  // one wave per tile, all 64 planes (k_conv_tile5): A/B only, measured slower
     k_conv_tile5<0><<<grid4, 64, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
@@ -2661,18 +2664,18 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     default:
       if (in_col)
         k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
       else
         k_conv_tile4<0, 0><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
   }
 #else
   if (in_col)
     k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
   else
     k_conv_tile4<0, 0><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
+                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
 #endif
   }
 #undef SCN_LAUNCH_TILE4
@@ -2791,7 +2794,8 @@ int scn_weight_pack_batch(const void *descs, int n, int64_t total_blocks, void *
 }
 
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const float *residual, float *colstats, const int32_t *rules, const int32_t *bases, const int32_t *counts, int K,
+                     const float *bias, const float *residual, float *colstats, const int32_t *rules, const int32_t *bases,
+                     const int32_t *tile_order, const int32_t *counts, int K,
                      int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in, int64_t n_out, int Ci,
                      int Co, void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
@@ -2838,7 +2842,8 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     float *part = (float *)workspace;
     if (p.kind == 4)
-      return launch_tile4(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      return launch_tile4(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part,
+                          p.ksplit == 1 ? tile_order : nullptr, stream);
     switch (p.nw) {
       case 4: return launch_tile2_ck<4>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
       case 3: return launch_tile2_ck<3>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);

@@ -38,6 +38,33 @@ def _instance_ids(w1):
     return np.unique(w1, return_inverse=True)[1].astype(np.int64)
 
 
+class LegacyRNG(object):
+    """The reference's random sources -- the GLOBAL numpy RandomState (np.random.randn / randint / rand / uniform) and
+    torch.randn for the colour jitter, seeded with 100 in ScanNet.__init__ (scannet.py:42-45) -- behind the Generator
+    method names ScanNetCollate calls.  With it (and the same seeds) the collate functions consume exactly the random
+    numbers the reference's trainMerge / valMerge consume, in the same order: tests/golden/g7 compares the two."""
+
+    @staticmethod
+    def seed(n=100):
+        torch.manual_seed(n)
+        np.random.seed(n)
+
+    def standard_normal(self, size=None):
+        return np.random.standard_normal(size)
+
+    def integers(self, lo, hi):
+        return np.random.randint(lo, hi)
+
+    def random(self, size=None):
+        return np.random.random_sample(size)
+
+    def uniform(self, lo, hi, size=None):
+        return np.random.uniform(lo, hi, size)
+
+    def colour_noise(self):
+        return torch.randn(3).float()
+
+
 class ScanNetCollate(object):
     """config keys as the reference's (examples/ScanNet/config.py): scale, full_scale, use_normal, use_elastic,
     use_feature ('c' colour, 'l' centred unit vector, 'n' normal, 'd' depth, 'h' height), use_rotation_noise,
@@ -120,8 +147,11 @@ class ScanNetCollate(object):
         feats = []
         if "l" in self.use_feature:
             feats.append(lf / torch.norm(lf, p=2, dim=1, keepdim=True))
+        # (the reference draws the colour jitter whether or not colour is a feature, scannet.py:211)
+        jitter = self.rng.colour_noise() if hasattr(self.rng, "colour_noise") else \
+            torch.from_numpy(self.rng.standard_normal(3)).float()
         if "c" in self.use_feature:
-            feats.append(torch.clamp(torch.from_numpy(b).float() + torch.from_numpy(self.rng.standard_normal(3)).float() * 0.1, -1, 1))
+            feats.append(torch.clamp(torch.from_numpy(b).float() + jitter * 0.1, -1, 1))
         if "n" in self.use_feature:
             feats.append(torch.from_numpy(d).float())
         if "d" in self.use_feature:

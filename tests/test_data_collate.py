@@ -98,3 +98,41 @@ def test_normals_and_feature_selection(tmp_path):
     assert torch.allclose(torch.norm(normals, dim=1), torch.ones(len(locs)), atol=1e-4)
     assert torch.allclose(torch.norm(feats[:, :3], dim=1), torch.ones(len(locs)), atol=1e-4)   # 'l'
     assert torch.equal(feats[:, 6:9], normals) and torch.equal(feats[:, 9], locs[:, 2])       # 'n', 'h'
+
+
+def test_collate_against_the_reference_trainmerge_fixture():
+    """tests/golden/g7_trainmerge.npz = what the reference's OWN ScanNet.trainMerge / valMerge
+    (examples/ScanNet/datasets/scannet.py:69-424, imported unchanged by tests/golden/make_g7.py in the build container)
+    return for three stored scenes with elastic distortion, rotation noise, normals and 'lcnh' features.  Same scenes,
+    same seeds, the reference's random sources (data.LegacyRNG): every key must agree -- integers exactly, floats to
+    float32 rounding (the per-instance loops are index_add_ reductions here)."""
+    import os
+    from occuseg_amd import data
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_trainmerge.npz"))
+    scenes = [{k: g["scene%d_%s" % (i, k)] for k in ("coords", "colors", "w", "normals", "region")} for i in range(3)]
+    cfg = {"scale": 50, "full_scale": 4096, "use_normal": True, "use_elastic": True, "use_feature": "lcnh",
+           "use_rotation_noise": True, "regress_sigma": 0.2}
+    data.LegacyRNG.seed(100)  # ScanNet.__init__, scannet.py:42-45
+    col = data.ScanNetCollate(cfg, rng=data.LegacyRNG())
+    train = col.trainMerge([2, 0], scenes)
+    val = col.valMerge([1, 2], scenes, list(g["arg_valOffsets"]))
+    for prefix, b in (("train_", train), ("val_", val)):
+        locs, feats, normals, bs = b["x"]
+        assert bs == int(g[prefix + "batch"])
+        want_locs = g[prefix + "locs"]
+        assert locs.shape == want_locs.shape, (locs.shape, want_locs.shape)
+        # voxel coordinates: the elastic field is interpolated in float64 on both sides; float32 rounding only
+        assert np.abs(locs.numpy() - want_locs).max() < 2e-3, np.abs(locs.numpy() - want_locs).max()
+        assert np.array_equal(locs.numpy()[:, 3], want_locs[:, 3])
+        assert np.abs(feats.numpy() - g[prefix + "feats"]).max() < 1e-4
+        assert np.abs(normals.numpy() - g[prefix + "normals"]).max() < 1e-5
+        for k in ("y", "sizes", "regions", "region_masks", "region_indexs"):
+            assert np.array_equal(b[k].numpy(), g[prefix + k]), k
+        assert np.array_equal(b["instance_masks"].numpy(), g[prefix + "instance_masks"])
+        assert np.abs(b["instance_sizes"].numpy() - g[prefix + "instance_sizes"]).max() < 1e-6
+        assert np.abs(b["offsets"].numpy() - g[prefix + "offsets"]).max() < 1e-4
+        assert np.abs(b["displacements"].numpy() - g[prefix + "displacements"]).max() < 1e-4
+        assert np.array_equal(np.concatenate([m.argmax(1).numpy() for m in b["masks"]]), g[prefix + "mask_argmax"])
+        assert np.array_equal(np.concatenate([m.sum(1).numpy() for m in b["masks"]]), g[prefix + "mask_rowsum"])
+        assert np.array_equal(np.concatenate([i.numpy() for i in b["idxs"]]), g[prefix + "idxs"])
+    assert np.array_equal(val["point_ids"].numpy(), g["val_point_ids"])

@@ -37,7 +37,8 @@ def apply(name, val):
         m = importlib.import_module("occuseg_amd.sparseconvnet." + mod)
         setattr(m, attr, type(getattr(m, attr))(int(val)))
     else:
-        setattr(SCN, name, type(getattr(SCN, name))(int(val)))
+        cur = getattr(SCN, name)
+        setattr(SCN, name, float(val) if isinstance(cur, float) else type(cur)(int(val)))
 
 
 name, vals = sys.argv[1].split("=")
