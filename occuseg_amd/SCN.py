@@ -432,14 +432,14 @@ class Metadata_3(object):
         if rb is None and iS in self.normals and iS[0] >= self.normal_guide_scale:
             # The reference's GPU builder for this case cannot have run: in its rule loop the output index is consumed
             # TWICE per (input, output) pair -- `out_index[query_index++]` for the orientation and again for the pair
-            # (sparseconvnet/SCN/Metadata/ConvolutionRules.h:224,227) -- while `out_index` holds ONE entry per pair
-            # (:181-182): the orientation is taken from another site's normal and from pair n/2 on the reads run past the
+            # (sparseconvnet/SCN/Metadata/ConvolutionRules.h:225,228) -- while `out_index` holds ONE entry per pair
+            # (:164-178): the orientation is taken from another site's normal and from pair n/2 on the reads run past the
             # end of the vector (undefined behaviour).  There is no reference behaviour to reproduce; the fork's shipped
             # configuration never gets here (rotation_guide_level 0: examples/ScanNet/config.py:50, model.py:626).
             raise NotImplementedError(
                 "normal-guided STRIDED rules (input spatial size %d >= normal_guide_scale %d) are not built: the "
                 "reference's own GPU path for them (sparseconvnet/SCN/Metadata/ConvolutionRules.h:139-236) indexes "
-                "out of bounds (query_index is incremented twice per pair, :224 and :227) and has no defined result; with "
+                "out of bounds (query_index is incremented twice per pair, :225 and :228) and has no defined result; with "
                 "the default rotation_guide_level 0 (examples/ScanNet/config.py:50, model.py:626) the normals guide the "
                 "input scale only, which is what this backend provides" % (iS[0], self.normal_guide_scale))
         if rb is None:
