@@ -2299,6 +2299,159 @@ __global__ void __launch_bounds__(256)
       }
 }
 
+// ---- dWeight without LDS staging (k_dw_direct).  dW[k][ci][co] = sum over the pairs of list k of in[pair.in][ci] *
+// dout[pair.out][co] is a GEMM whose reduction index is the PAIR, so the accumulators are stationary and the operands can
+// be fetched straight into MFMA fragment registers with full-row, fully coalesced 16-byte loads:
+//   one k-step = 4 pairs.  Lane (li, lq) loads in[pair 4s+lq][ci0 + 4 li .. +4] and dout[pair 4s+lq][co0 + 4 li .. +4]
+//   (two buffer_load_dwordx4: the 16 lanes of a quarter read one whole 256-byte row each way); component ja of the
+//   first is the A operand of the MFMAs for the ci with ci % 4 == ja, component jb of the second the B operand for the
+//   co with co % 4 == jb: 16 independent v_mfma_f32_16x16x4_f32 per k-step on 16 accumulators cover the 64 x 64 block.
+// No LDS, no ds_read per MFMA (the staged kernel: 40 LDS instructions per 64 MFMAs), no barrier in the loop, two
+// vector-ALU instructions (row offsets) per 16 MFMAs.  Rows are requested one iteration (4 k-steps) ahead into four
+// register sets that are reloaded in place, pair indices two iterations ahead.  The four waves of a workgroup take the
+// 16-pair chunks of the workgroup's slice round robin (they walk the same neighbourhood together) and add their
+// accumulators through 16 KB of LDS at the end, so the number of float atomics per launch is that of k_dw_tile.
+template <int INCOL, bool ATOMIC = true>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+    k_dw_direct(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+                const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
+                int Ci, int Co, int gx, unsigned in_bytes, unsigned do_bytes, int K) {
+  __shared__ __attribute__((aligned(16))) floatx4 red[16 * 64];
+  int lin;
+  {  // as k_dw_tile: (plane block t, offset k, slice c), c slowest, each XCD a contiguous range
+    const int total = gridDim.x;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int nci = Ci / 64, nt = nci * (Co / 64);
+  const int t = lin % nt, k = (lin / nt) % K, c = lin / (nt * K);
+  const int count = counts[k];
+  const int per = ((count + gx - 1) / gx + 63) / 64 * 64;  // pairs per slice of THIS list
+  const int p0 = c * per;
+  if (p0 >= count) return;
+  const int p1 = min(count, p0 + per);
+  const int ci0 = (t % nci) * 64, co0 = (t / nci) * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t do_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dout, 0, (int)do_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ru_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(rules + (int64_t)k * stride), 0, (int)(stride * 8), 0x00020000);
+  const unsigned ci4 = (unsigned)Ci * 4u, co4 = (unsigned)Co * 4u, li16 = (unsigned)li * 16u, lq8 = (unsigned)lq * 8u;
+  auto mad24 = [](unsigned a_, unsigned b_, unsigned c_) __attribute__((always_inline)) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a_), "s"(b_), "v"(c_));
+    return r;
+  };
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // this wave's iterations: chunks w, w + 4, w + 8, ... of 16 pairs
+  const int nchunks = (p1 - p0 + 15) >> 4;
+  const int J = (nchunks - w + 3) >> 2;  // may be 0
+  u32x2 ix[2][4];  // pair indices of iterations j + 1 (set (j + 1) & 1) and j + 2
+  floatx4 ra[4], rb[4];
+  auto chunk_base = [&](int j) __attribute__((always_inline)) { return p0 + ((j << 2) + w) * 16; };
+  auto load_idx = [&](int j, u32x2 (&dst)[4]) __attribute__((always_inline)) {
+    const int so = chunk_base(j) * 8;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      dst[u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(ru_rsrc, lq8 + (unsigned)u * 32u, so, 0));
+  };
+  // rows of k-step u of iteration j; masked: pairs at or behind p1 come from an out-of-range offset (zeros)
+  auto load_rows = [&](int j, int u, const u32x2 &pr, bool masked) __attribute__((always_inline)) {
+    const unsigned src = INCOL ? pr.y : pr.x, dst = INCOL ? pr.x : pr.y;
+    unsigned oa = mad24(src, ci4, li16), ob = mad24(dst, co4, li16);
+    if (masked) {
+      const bool ok = chunk_base(j) + 4 * u + lq < p1;
+      oa = ok ? oa : 0xffffff00u;
+      ob = ok ? ob : 0xffffff00u;
+    }
+    ra[u] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, oa, ci0 * 4, 0));
+    rb[u] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(do_rsrc, ob, co0 * 4, 0));
+  };
+  auto mfma16 = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+        acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u][ja], rb[u][jb], acc[ja][jb], 0, 0, 0);
+  };
+  if (J > 0) {
+    // prologue: indices of iterations 0 and 1, rows of iteration 0
+    load_idx(0, ix[0]);
+    load_idx(1, ix[1]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_rows(0, u, ix[0][u], true);
+    load_idx(2, ix[0]);  // (ix[0] has been consumed by the row loads above: the compiler orders the waits)
+    int j = 0;
+    // Trips of two iterations whose prefetches (iterations j + 1 and j + 2) are not the wave's last iteration: only the
+    // LAST chunk of a slice can be partial, so these need no mask.
+    for (; j + 3 < J; j += 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // two iterations per trip: the index sets alternate without copies
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          mfma16(u);
+          // (pinned: left alone, hipcc sinks these loads to the end of the trip, right in front of their use)
+          __builtin_amdgcn_sched_barrier(0);
+          load_rows(j + h + 1, u, ix[(h + 1) & 1][u], false);
+          if (u == 3) load_idx(j + h + 3, ix[(h + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // the last one to three iterations: masked prefetch
+    for (; j < J; ++j) {
+      const int par = j & 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        mfma16(u);
+        if (j + 1 < J) load_rows(j + 1, u, par ? ix[0][u] : ix[1][u], true);
+      }
+      if (j + 1 < J) { if (par) load_idx(j + 3, ix[0]); else load_idx(j + 3, ix[1]); }
+    }
+  }
+  // add the four waves' accumulators through LDS (wave 3 -> 2 -> 1 -> 0), then one set of atomics per workgroup
+#pragma unroll 1
+  for (int src = 3; src >= 1; --src) {
+    if (w == src) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) red[(a * 4 + b) * 64 + lane] = acc[a][b];
+    }
+    __syncthreads();
+    if (w == src - 1) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += red[(a * 4 + b) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (w == 0) {
+    // D of (ja, jb): lane holds rows 4 lq + r, column li, i.e. ci = ci0 + 4 (4 lq + r) + ja, co = co0 + 4 li + jb
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float *dst = dW + ((int64_t)k * Ci + ci0 + 4 * (4 * lq + r) + ja) * Co + co0 + 4 * li;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          if (ATOMIC) unsafeAtomicAdd(dst + jb, acc[ja][jb][r]);
+          else dst[jb] = acc[ja][jb][r];
+        }
+      }
+  }
+}
+
 // dW for narrow inputs (the 3 -> m stem, Ci <= 4): thread = one output plane, wave = every fourth pair of the chunk;
 // the pair and the Ci input values are wave-uniform, only the dOut row is a vector load
 template <int CI>
@@ -2457,6 +2610,9 @@ SCN_KNOB g_conv_tile5 = 0;      // tuning key 9: 1 = k_conv_tile5 (one wave per 
 SCN_KNOB g_conv_expand = 1;     // tuning key 8: 0 = launches with one contribution per output row use the tile kernels (A/B)
 SCN_KNOB g_conv_tile6 = 0;      // tuning key 11: 96 / 128 = k_conv_tile6 with that many rows per tile where k_conv_tile4 would run unsplit
 SCN_KNOB g_conv_extra_lds = 0;  // tuning key 10: bytes of unused dynamic LDS added to k_conv_tile4 launches (occupancy probe)
+SCN_KNOB g_dw_direct = 0;       // tuning key 12: 1 = k_dw_direct (no LDS staging) for 64-plane blocks.  Round 3: correct (all dW parity
+                                // tests), 107-130 against 105-126 TFLOP/s on the six big layer shapes in isolation, but the train
+                                // step is 1.8 ms SLOWER with it (50.3 against 48.4 ms, tools/ab_step.py tune12=0,1): off
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 // Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.
@@ -2727,6 +2883,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 8) { g_conv_expand = value; return 0; }
   if (key == 9) { g_conv_tile5 = value; return 0; }
   if (key == 11 && (value == 0 || value == 96 || value == 128)) { g_conv_tile6 = value; return 0; }
+  if (key == 12) { g_dw_direct = value; return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
@@ -2885,6 +3042,14 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     const int gx = (int)((stride + per - 1) / per);
     if (Ci % 64 == 0 && Co % 64 == 0) {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 64) * (Co / 64));
+      if (g_dw_direct && g_dw_dbg == 0) {
+        if (in_col)
+          k_dw_direct<1><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, Ci, Co, gx, in_bytes, do_bytes, K);
+        else
+          k_dw_direct<0><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, Ci, Co, gx, in_bytes, do_bytes, K);
+        SCN_CHECK_LAUNCH();
+        return 0;
+      }
 #ifdef SCN_TUNING
       if (g_dw_dbg == 100)  // A/B: 32 pairs per step
         k_dw_tile<2, 2, 32><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--m", type=int, default=64)
     ap.add_argument("--dw", action="store_true")
     ap.add_argument("--extra-lds", default="0", help="comma list: unused dynamic LDS bytes per k_conv_tile4 workgroup (occupancy probe)")
-    ap.add_argument("--dw-variants", default="101,0,101,0")
+    ap.add_argument("--dw-variants", default="s0,0,s0,0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.use_tuning_build()
@@ -64,15 +64,19 @@ def main():
                     lib.scn_set_tuning(4, int(v) // 100000)
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                     line += "  v%s%s %.3f ms %.1f TF" % (v, "" if xl == "0" else "+%sB" % xl, ms, flops / ms / 1e9)
-                for dv in ([int(v) for v in args.dw_variants.split(',')] if args.dw else []):
-                    lib.scn_set_tuning(1, dv % 1000)
+                for dv in (args.dw_variants.split(',') if args.dw else []):
+                    # "s<n>": the LDS-staged k_dw_tile (tuning key 12 = 0) with ablation n; plain numbers: default kernel choice
+                    lib.scn_set_tuning(12, 0 if dv.startswith("s") else 1)
+                    dv = int(dv.lstrip("s"))
+                    lib.scn_set_tuning(6, dv % 1000)
                     lib.scn_set_tuning(5, dv // 1000 if dv >= 1000 else 256)
                     dy = torch.randn(n, co, device=dev)
                     dw = torch.zeros_like(w)
                     ms = timeit(lambda: _lib.check(lib.scn_conv_dweight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
                                 rb.rules.data_ptr(), rb.counts.data_ptr(), None, 27, rb.stride, 0, 1, n, n, ci, co, _lib.stream())))
                     line += "  dW[%d] %.3f ms %.1f TF" % (dv, ms, flops / ms / 1e9)
-                lib.scn_set_tuning(1, 0)
+                lib.scn_set_tuning(6, 0)
+                lib.scn_set_tuning(12, 1)
                 print(line, flush=True)
         out_size = size // 2
         md.getRuleBook(size, out_size, f2, f2)
