@@ -181,8 +181,20 @@ int64_t scn_weight_pack_blocks(int K, int Ci, int Co);
 int scn_weight_pack_flags(int w_transposed, int w_reverse, int K, int Ci, int Co);
 int scn_weight_pack_batch(const void *descs, int n, int64_t total_blocks, void *stream);
 int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
+/* bn_bwd (may be NULL; needs colstats): this launch is the dInput of a convolution whose INPUT was the output
+ * y = leaky(fma(x, w, b)) of a batch norm over x (w = invstd*gamma, b = fma(-mean, w, beta): scn_bn_forward's own
+ * arithmetic), i.e. its result d is that batch norm's d_output_features.  colstats then receives, per block of output
+ * rows, sum d' and sum (x - mean) d' with d' = d * (y > 0 ? 1 : leakiness) -- the two reductions of
+ * BatchNormalization_BackwardPass (sparseconvnet/SCN/CPU/BatchNormalization.cpp:75-87) -- taken while the tile is in LDS /
+ * registers; scn_bn_backward_ext finishes the batch norm's backward pass from them without reading x and d once more.
+ * x: [n_out, Co] (the rows of the launch's output); weight / bias may be NULL. */
+typedef struct scn_bn_bwd_stats {
+  const float *x, *save_mean, *save_invstd, *weight, *bias;
+  double leakiness;
+} scn_bn_bwd_stats;
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const float *residual, float *colstats, const int32_t *rules,
+                     const float *bias, const float *residual, float *colstats, const scn_bn_bwd_stats *bn_bwd,
+                     const int32_t *rules,
                      const int32_t *bases, const int32_t *tile_order, const int32_t *counts,
                      int K, int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in,
                      int64_t n_out, int Ci, int Co, void *wpack, int wpack_ready, void *workspace,
@@ -236,6 +248,16 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
                     const float *save_mean, const float *save_invstd, const float *weight,
                     const float *bias, float *d_weight, float *d_bias, double leakiness, int64_t N,
                     int C, int flags, void *temp, void *stream);
+/* The SCN_BN_MASK_FROM_X backward pass with two things handed in (both may be NULL / 0):
+ *   partial [nblk][2][C]: the two reductions, emitted by the kernel that produced d_out (scn_conv_forward's bn_bwd):
+ *   the statistics pass is skipped, d_out and x are read once (12 instead of 20 bytes per element);
+ *   d_x_add [N, C]: added to the result, d_x = (batch norm's d_input) + d_x_add -- the gradient arriving at x along
+ *   another path (the shortcut of a residual block), which autograd would otherwise add with a kernel of its own.
+ * flags: SCN_BN_ACCUMULATE_DPARAMS only. */
+int scn_bn_backward_ext(const float *x, float *d_x, const float *d_out, const float *save_mean,
+                        const float *save_invstd, const float *weight, const float *bias, float *d_weight,
+                        float *d_bias, double leakiness, int64_t N, int C, int flags, void *temp,
+                        const float *partial, int nblk, const float *d_x_add, void *stream);
 
 /* ------------------------------------------------------ input / output ---
  * Replaces InputLayer_fp/bp (sparseconvnet/SCN/CUDA/IOLayers.cu:17-76) and the four wrappers of

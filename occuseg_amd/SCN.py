@@ -645,8 +645,42 @@ def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
     return ent.wpack, 1
 
 
+class BnLink(object):
+    """What a batch norm leaves for the convolution that consumes its output (not in the reference).  In the backward pass
+    that convolution's dInput launch IS the batch norm's d_output_features: it takes the two reductions of the batch norm's
+    backward pass from its output tile (scn_conv_forward's bn_bwd) and leaves them here, keyed on the gradient tensor it
+    returned; BatchNormalization_backward then skips its statistics pass over x and d_out."""
+    __slots__ = ("x", "save_mean", "save_invstd", "weight", "bias", "leakiness", "partials", "grad_key")
+
+    def __init__(self, x, save_mean, save_invstd, weight, bias, leakiness):
+        self.x, self.save_mean, self.save_invstd = x, save_mean, save_invstd
+        self.weight = weight if weight is not None and weight.numel() else None
+        self.bias = bias if bias is not None and bias.numel() else None
+        self.leakiness = float(leakiness)
+        self.partials, self.grad_key = None, None
+
+    def struct(self):
+        return _lib.BnBwdStats(ptr(self.x), ptr(self.save_mean), ptr(self.save_invstd), ptr(self.weight), ptr(self.bias),
+                               self.leakiness)
+
+    def offer(self, grad, partials):
+        self.partials = partials
+        self.grad_key = (grad.data_ptr(), grad._version, tuple(grad.shape)) if partials is not None else None
+
+    def take(self, grad):
+        """the partial sums, if `grad` is exactly the tensor they were taken from (nothing was added into it since)"""
+        p, key = self.partials, self.grad_key
+        self.partials, self.grad_key = None, None
+        if p is not None and grad.is_contiguous() and key == (grad.data_ptr(), grad._version, tuple(grad.shape)):
+            return p
+        return None
+
+
+BN_BWD_STATS_FROM_CONV = True  # A/B switch
+
+
 def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False, residual=None,
-          stats_out=None):
+          stats_out=None, bn_link=None):
     """out = gather-mm-scatter over rb; weight is the module's [K, a, b] tensor, used as [K, Ci, Co]
     (forward) or, with w_transposed, as its per-offset transpose (dInput).  When every output row appears in exactly
     one pair of the rulebook (rb.unique_col == out_col: the fine column of a strided rulebook, the identity list)
@@ -666,17 +700,26 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=inp.device) if ws_bytes else None
     # column statistics of the result for the batch norm that consumes it (stats_out: a list that receives the tensor)
     cstats = None
-    if stats_out is not None:
+    bnb = None
+    if bn_link is not None and not (BN_BWD_STATS_FROM_CONV and tuple(bn_link.x.shape) == (n_out, Co)
+                                    and bn_link.x.is_contiguous()):
+        bn_link = None
+    if stats_out is not None or bn_link is not None:
         nblk = lib.scn_conv_stats_blocks(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
         if nblk > 0:
             cstats = torch.empty((nblk, 2, Co), dtype=torch.float32, device=inp.device)
-            stats_out.append(cstats)
+            if bn_link is not None:
+                bnb = bn_link.struct()
+            else:
+                stats_out.append(cstats)
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None, ptr(residual), ptr(cstats),
-                               ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.order.get(out_col)), ptr(rb.counts), K, rb.stride,
+                               ctypes.byref(bnb) if bnb is not None else None, ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.order.get(out_col)), ptr(rb.counts), K, rb.stride,
                                in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
+    if bn_link is not None:
+        bn_link.offer(out, cstats if bnb is not None else None)
     # algorithmic work of one launch: flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
     if ev is not None:
@@ -779,8 +822,10 @@ def _dw_finish(idx):
     del st[2][:]
 
 
-def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse):
-    """d_in = gather-mm-scatter of d_out with the transposed weights; dW; d_bias."""
+def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse, bn_link=None,
+                   d_in_add=None):
+    """d_in = gather-mm-scatter of d_out with the transposed weights; dW; d_bias.
+    bn_link: see BnLink; d_in_add: a tensor added to d_in inside the dInput kernel (its `residual`)."""
     lib = _lib_()
     K, Ci, Co = weight.shape
     d_out = d_out.contiguous()
@@ -792,9 +837,9 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
         if reverse:
             # submanifold: dIn[i] = sum_k' dOut[nbr(i,k')] . W[26-k']^T over the SAME lists (rules are
             # symmetric: (i,o) in list k <=> (o,i) in list 26-k), so the columns keep their roles
-            _conv(d_out, d_in, weight, None, rb, in_col, out_col, n_in, True, True)
+            _conv(d_out, d_in, weight, None, rb, in_col, out_col, n_in, True, True, residual=d_in_add, bn_link=bn_link)
         else:
-            _conv(d_out, d_in, weight, None, rb, out_col, in_col, n_in, True, False)
+            _conv(d_out, d_in, weight, None, rb, out_col, in_col, n_in, True, False, residual=d_in_add, bn_link=bn_link)
 
     # DW_FIRST: the side stream's wait on the main stream is taken BEFORE the dInput kernel is queued, so the two kernels
     # of a layer run beside each other from the start (A/B switch; default: dWeight waits for the layer's dInput)
@@ -894,7 +939,7 @@ def SubmanifoldConvolution_updateOutput(spatialSize, filterSize, m, input_featur
 
 
 def SubmanifoldConvolution_backward(spatialSize, filterSize, m, input_features, d_input_features,
-                                    d_output_features, weight, d_weight, d_bias, dilated_rate=1):
+                                    d_output_features, weight, d_weight, d_bias, dilated_rate=1, _bn_link=None):
     """sparseconvnet/SCN/pybind.cpp:143-147 -> sparseconvnet/SCN/CUDA/Convolution.cpp:165-210.
     d_input_features may be None to skip the dInput half."""
     _need_cuda(d_output_features, "SubmanifoldConvolution_backward")
@@ -902,7 +947,7 @@ def SubmanifoldConvolution_backward(spatialSize, filterSize, m, input_features, 
     n = m.getNActive(spatialSize)
     if rb.ori is None:
         _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight, d_weight, d_bias,
-                       rb, 0, 1, n, reverse=True)
+                       rb, 0, 1, n, reverse=True, bn_link=_bn_link)
         return
     # Normal-guided rulebook: list n holds the pairs found at offset i = inv(class of the OUTPUT site)[n], so the
     # (i,o) <-> (o,i) symmetry the plain dInput relies on is gone and an input site can appear several times in one
@@ -932,13 +977,13 @@ def Convolution_updateOutput(inputSize, outputSize, filterSize, filterStride, m,
 
 
 def Convolution_backward(inputSize, outputSize, filterSize, filterStride, m, input_features, d_input_features,
-                         d_output_features, weight, d_weight, d_bias):
+                         d_output_features, weight, d_weight, d_bias, _bn_link=None):
     """sparseconvnet/SCN/pybind.cpp:64-69 -> sparseconvnet/SCN/CUDA/Convolution.cpp:69-102"""
     _need_cuda(d_output_features, "Convolution_backward")
     rb = m.getRuleBook(inputSize, outputSize, filterSize, filterStride)
     n_in = m.getNActive(inputSize)
     _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight, d_weight, d_bias,
-                   rb, 0, 1, n_in, reverse=False)
+                   rb, 0, 1, n_in, reverse=False, bn_link=_bn_link)
 
 
 def Deconvolution_updateOutput(inputSize, outputSize, filterSize, filterStride, m, input_features,
@@ -953,13 +998,13 @@ def Deconvolution_updateOutput(inputSize, outputSize, filterSize, filterStride, 
 
 
 def Deconvolution_backward(inputSize, outputSize, filterSize, filterStride, m, input_features,
-                           d_input_features, d_output_features, weight, d_weight, d_bias):
+                           d_input_features, d_output_features, weight, d_weight, d_bias, _bn_link=None):
     """sparseconvnet/SCN/pybind.cpp:88-93 -> sparseconvnet/SCN/CUDA/Deconvolution.cpp:52-84"""
     _need_cuda(d_output_features, "Deconvolution_backward")
     rb = m.getRuleBook(outputSize, inputSize, filterSize, filterStride)
     n_in = m.getNActive(inputSize)
     _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight, d_weight, d_bias,
-                   rb, 1, 0, n_in, reverse=False)
+                   rb, 1, 0, n_in, reverse=False, bn_link=_bn_link)
 
 
 def _bn_temp(C, device):
@@ -999,7 +1044,7 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
 
 def BatchNormalization_backward(input_features, d_input_features, output_features, d_output_features, saveMean,
                                 saveInvStd, runningMean, runningVar, weight, bias, d_weight, d_bias, leakiness,
-                                _rewrite_d_output=True, _accumulate=False, _mask_from_x=False):
+                                _rewrite_d_output=True, _accumulate=False, _mask_from_x=False, _partials=None, _d_x_add=None):
     """sparseconvnet/SCN/sparseconvnet.h:27-32 -> sparseconvnet/SCN/CUDA/BatchNormalization.cpp:45-76.
     d_output_features must be contiguous: it is rewritten in place
     (sparseconvnet/SCN/CUDA/BatchNormalization.cu:151-153).  ``_rewrite_d_output=False`` (not in the reference;
@@ -1013,6 +1058,19 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     d_input_features.resize_(N, C)
     temp = _bn_temp(C, x.device)
     ev = _prof_begin("bn")
+    if _partials is not None or _d_x_add is not None:
+        # (not in the reference) statistics handed over by the kernel that produced d_output_features, and / or another
+        # gradient of input_features added to the result inside the apply pass
+        assert _mask_from_x
+        assert _partials is None or (_partials.is_contiguous() and tuple(_partials.shape[1:]) == (2, C))
+        assert _d_x_add is None or (_d_x_add.is_contiguous() and tuple(_d_x_add.shape) == (N, C))
+        check(_lib_().scn_bn_backward_ext(ptr(x), ptr(d_input_features), ptr(d_output_features), ptr(saveMean),
+                                          ptr(saveInvStd), ptr(weight), ptr(bias), ptr(d_weight), ptr(d_bias),
+                                          float(leakiness), N, C, 2 if _accumulate else 0, ptr(temp), ptr(_partials),
+                                          _partials.size(0) if _partials is not None else 0, ptr(_d_x_add), stream()))
+        _prof_end(ev, "bn_bwd", 0.0, (12.0 if _partials is not None else 20.0) * N * C + (4.0 * N * C if _d_x_add is not None else 0.0),
+                  (N, C, "ext"))
+        return
     flags = (4 if _mask_from_x else int(bool(_rewrite_d_output))) | (2 if _accumulate else 0)
     check(_lib_().scn_bn_backward(ptr(x), ptr(d_input_features), ptr(output_features), ptr(d_output_features),
                                   ptr(saveMean), ptr(saveInvStd), ptr(weight), ptr(bias), ptr(d_weight), ptr(d_bias),
@@ -1082,6 +1140,32 @@ def NetworkInNetwork_updateGradInput(d_input_features, d_output_features, weight
     d_input_features.resize_(n, weight.size(0))
     if n:
         torch.mm(d_output_features, weight.t(), out=d_input_features)
+
+
+def NetworkInNetwork_backward(input_features, d_input_features, d_output_features, weight, d_weight, d_bias,
+                              _d_in_add=None):
+    """(not in the reference: its three functions below, fused for the autograd module)  dInput (+ ``_d_in_add`` inside
+    the kernel), dWeight ACCUMULATED into d_weight (zeroed by the caller, or the owner's flat gradient view: the dWeight
+    kernel may then run on the side stream like a convolution's), dBias assigned."""
+    n = input_features.size(0)
+    if _nin_native(input_features, weight):
+        rb = _identity_rulebook(n, input_features.device)
+        Ci, Co = weight.shape
+        _conv_backward(input_features.contiguous(), d_input_features, d_output_features, weight.view(1, Ci, Co),
+                       d_weight.view(1, Ci, Co), d_bias, rb, 0, 1, n, reverse=False, d_in_add=_d_in_add)
+        return
+    _BWD_SEEN[0] = True
+    d_out = d_output_features.contiguous()
+    if d_input_features is not None:
+        d_input_features.resize_(n, weight.size(0))
+        if n:
+            torch.mm(d_out, weight.t(), out=d_input_features)
+            if _d_in_add is not None:
+                d_input_features.add_(_d_in_add)
+    if n:
+        d_weight.addmm_(input_features.t(), d_out)
+        if d_bias is not None and d_bias.numel():
+            torch.sum(d_out, 0, out=d_bias)
 
 
 def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weight, d_bias):

@@ -37,7 +37,7 @@ SIGNATURES = {
     "scn_weight_pack_flags": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "scn_weight_pack_batch": (c_int, [_P, c_int, c_int64, _P]),
     "scn_conv_stats_blocks": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
-    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
+    "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
                                  c_int64, c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
@@ -47,6 +47,7 @@ SIGNATURES = {
     "scn_bn_forward_ext": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_double, c_int64, c_int, _P,
                                    c_int, ctypes.POINTER(c_int32), ctypes.POINTER(_P), ctypes.POINTER(c_int32), _P]),
     "scn_bn_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P]),
+    "scn_bn_backward_ext": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P, c_int, _P, _P]),
     "scn_input_forward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_input_backward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_output_forward": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
@@ -72,6 +73,12 @@ TUNING_LIB_PATH = os.path.join(_HERE, "libscn_hip_tuning.so")
 ABI_VERSION = 3
 
 _lib = None
+
+
+class BnBwdStats(ctypes.Structure):
+    """scn_bn_bwd_stats of include/scn_hip.h"""
+    _fields_ = [("x", c_void_p), ("save_mean", c_void_p), ("save_invstd", c_void_p), ("weight", c_void_p),
+                ("bias", c_void_p), ("leakiness", c_double)]
 
 
 def _open(path, signatures):

@@ -28,6 +28,54 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// Where a gather-mm launch leaves per-block column sums for the batch norm next to it (scn_conv_forward's `colstats`):
+//   x == nullptr: sum v and sum v^2 of the RESULT v (the batch norm that CONSUMES this tensor: forward statistics);
+//   x != nullptr: the launch computes the gradient d w.r.t. the OUTPUT y = leaky(fma(x, w, b)) of a batch norm over x
+//                 (it is the dInput of the convolution that consumed y): sum d' and sum (x - mean) d' with
+//                 d' = d * (y > 0 ? 1 : leak) -- the two reductions of the batch norm's backward pass
+//                 (sparseconvnet/SCN/CPU/BatchNormalization.cpp:75-87), so that pass need not read x and d once more.
+struct StatsArg {
+  float *out;
+  const float *x, *mean, *invstd, *gamma, *beta;
+  float leak;
+};
+// per-lane constants of four consecutive planes c .. c+3 and the two sums for one float4 of the result
+struct StatsCols {
+  floatx4 m, w, b;
+  float leak;
+  bool bn;
+  __device__ __forceinline__ void init(const StatsArg &a, int c) {
+    bn = a.x != nullptr;
+    leak = a.leak;
+    if (bn) {
+      m = *(const floatx4 *)(a.mean + c);
+      const floatx4 is = *(const floatx4 *)(a.invstd + c);
+      const floatx4 g = a.gamma ? *(const floatx4 *)(a.gamma + c) : floatx4{1.f, 1.f, 1.f, 1.f};
+      const floatx4 be = a.beta ? *(const floatx4 *)(a.beta + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // the forward pass's own arithmetic (k_bn_finalize): bit-identical sign of y
+        w[e] = is[e] * g[e];
+        b[e] = fmaf(-m[e], w[e], be[e]);
+      }
+    }
+  }
+  // v = four results of row `row_x` (pointer to the row's planes c .. c+3 of x when bn)
+  __device__ __forceinline__ void add(const floatx4 &v, const float *xrow, floatx4 &s0, floatx4 &s1) const {
+    if (!bn) {
+      s0 += v;
+      s1 += v * v;
+    } else {
+      const floatx4 xv = *(const floatx4 *)xrow;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = (leak == 1.f || fmaf(xv[e], w[e], b[e]) > 0.f) ? v[e] : v[e] * leak;
+        s0[e] += d;
+        s1[e] += (xv[e] - m[e]) * d;
+      }
+    }
+  }
+};
+
 constexpr int KMAX = 27;
 constexpr int SCN_TILE4_MAX_CHUNKS = 6;  // k_conv_tile4: C_i <= 384 (pass table in LDS: 35.1 + 5.2 KB = four workgroups per CU, to the byte)
 
@@ -56,7 +104,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <int NW, int COS, int M, int CK>
 __global__ void __launch_bounds__(64 * NW)
     k_conv_tile(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
-                const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
+                const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                 int64_t n_out, int n_gran, int Ci, int Co) {
   constexpr int COB = NW * COS * 16;
@@ -247,7 +295,7 @@ __global__ void __launch_bounds__(256)
 template <int NW, int COS, int CK, int DBG = 0, int NWM = 1, int M_ = 0>
 __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per_eu(2, 8)))  // (<= 256 registers: accumulators stay in VGPRs, no v_accvgpr_read before the output-tile adds)
     k_conv_tile2(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb, int ksplit,
                  unsigned in_bytes, unsigned wp_bytes) {
@@ -621,14 +669,28 @@ __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per
   // Column statistics of the finished tile (sum, sum of squares per output plane over the tile's rows) while it is still
   // in LDS: the batch norm that consumes this tensor takes them instead of reading the tensor once more
   // (colstats [ntiles][2][Co], one deterministic partial per tile; the fp64 finalize of scn_bn_forward adds them up).
-  if (colstats != nullptr && ksplit == 1) {
+  if (colstats.out != nullptr && ksplit == 1) {
     constexpr int G = NT / COB;  // threads per column
     const int c = tid % COB, g = tid / COB;
     float cs = 0.f, css = 0.f;
-    for (int r = g; r < rows; r += G) {
-      const float v = o_tile[r * OS + c];
-      cs += v;
-      css += v * v;
+    if (colstats.x == nullptr) {
+      for (int r = g; r < rows; r += G) {
+        const float v = o_tile[r * OS + c];
+        cs += v;
+        css += v * v;
+      }
+    } else {  // the two reductions of the backward pass of the batch norm over x whose output this launch differentiates
+      const float m = colstats.mean[co0 + c];
+      const float wv = colstats.invstd[co0 + c] * (colstats.gamma ? colstats.gamma[co0 + c] : 1.f);
+      const float bv = fmaf(-m, wv, colstats.beta ? colstats.beta[co0 + c] : 0.f);
+      const float leak = colstats.leak;
+      for (int r = g; r < rows; r += G) {
+        const float xv = colstats.x[(o0 + r) * Co + co0 + c];
+        float d = o_tile[r * OS + c];
+        d = (leak == 1.f || fmaf(xv, wv, bv) > 0.f) ? d : d * leak;
+        cs += d;
+        css += (xv - m) * d;
+      }
     }
     float *red = a_tile;  // free: every wave is past the last phase's closing barrier (or no phase ran)
     red[(g * COB + c) * 2 + 0] = cs;
@@ -641,8 +703,8 @@ __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per
         cs += red[(j * COB + tid) * 2 + 0];
         css += red[(j * COB + tid) * 2 + 1];
       }
-      colstats[((int64_t)tile * 2 + 0) * Co + co0 + tid] = cs;
-      colstats[((int64_t)tile * 2 + 1) * Co + co0 + tid] = css;
+      colstats.out[((int64_t)tile * 2 + 0) * Co + co0 + tid] = cs;
+      colstats.out[((int64_t)tile * 2 + 1) * Co + co0 + tid] = css;
     }
   }
 }
@@ -686,7 +748,7 @@ __global__ void __launch_bounds__(256)
 template <int DBG = 0, int INCOL = -1>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (<= 256 registers: hipcc then keeps the accumulators in VGPRs, no v_accvgpr_read)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes, int ksplit, const int32_t *__restrict__ tile_order) {
@@ -1106,14 +1168,16 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // octet lane >> 3, plane quad lane & 7) sums its 16 rows, a butterfly over the eight lanes of a plane quad finishes.  (The
   // first version walked the tile again, one float per lane and row, 64 dependent LDS reads per lane: 3-6 % of a forward
   // launch inside the train step.)
-  const bool stats = colstats != nullptr && ksplit == 1;
+  const bool stats = colstats.out != nullptr && ksplit == 1;
   floatx4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
+  StatsCols sc;
+  sc.bn = false;
+  if (stats) sc.init(colstats, co0 + 32 * w + (lane & 7) * 4);  // (i & 7 == lane & 7: a lane keeps its plane quad)
   for (int i = lane; i < rows * 8; i += 64) {
     const int r = i >> 3, c4 = (i & 7) * 4;
     const floatx4 v = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
     *(floatx4 *)(dst + (o0 + r) * Co + co0 + 32 * w + c4) = v;
-    cs += v;
-    css += v * v;
+    sc.add(v, colstats.x + (o0 + r) * Co + co0 + 32 * w + c4, cs, css);
   }
   if (stats) {
 #pragma unroll
@@ -1124,8 +1188,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         css[e] += __shfl_xor(css[e], o);
       }
     if (lane < 8) {
-      *(floatx4 *)(colstats + ((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + lane * 4) = cs;
-      *(floatx4 *)(colstats + ((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + lane * 4) = css;
+      *(floatx4 *)(colstats.out + ((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + lane * 4) = cs;
+      *(floatx4 *)(colstats.out + ((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + lane * 4) = css;
     }
   }
 }
@@ -1155,7 +1219,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int M, bool INCOL, int DBG = 0>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))
     k_conv_tile6(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes, int ksplit) {
@@ -1501,7 +1565,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int r = i >> 3, c4 = (i & 7) * 4;
     *(floatx4 *)(dst + (o0 + r) * Co + co0 + 32 * w + c4) = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
   }
-  if (colstats != nullptr && ksplit == 1) {  // column statistics of this wave's 32 planes: lane = (plane, half of the rows)
+  if (colstats.out != nullptr && ksplit == 1) {  // column statistics of this wave's 32 planes: lane = (plane, half of the rows)
     const int p = lane & 31, half = lane >> 5;
     float cs = 0.f, css = 0.f;
     for (int r = half * (M / 2); r < min(rows, half * (M / 2) + M / 2); ++r) {
@@ -1512,8 +1576,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
     cs += __shfl_xor(cs, 32);
     css += __shfl_xor(css, 32);
     if (half == 0) {
-      colstats[((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + p] = cs;
-      colstats[((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + p] = css;
+      colstats.out[((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + p] = cs;
+      colstats.out[((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + p] = css;
     }
   }
 }
@@ -1532,7 +1596,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
 template <int DBG = 0>
 __global__ void __launch_bounds__(64)
     k_conv_tile5(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
+                 const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
                  unsigned in_bytes, unsigned wp_bytes, int ksplit) {
@@ -1915,7 +1979,7 @@ __device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], con
 // walked in chunks of 32 planes, the loads of chunk c+1 requested before the MFMAs of chunk c.
 __global__ void __launch_bounds__(64)
     k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                  const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
+                  const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
                   int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes, unsigned wp_bytes) {
   // chunks of 32 reduction planes: 2 x (8 row + 32 weight) registers in flight + 32 accumulators keep the wave at
   // ~150 VGPRs = three waves per SIMD (with 64-plane chunks it needed 272: one wave per SIMD, and a launch of
@@ -1934,10 +1998,10 @@ __global__ void __launch_bounds__(64)
     blk -= nb;
   }
   if (k >= K) {  // past the end of the lists: nothing to compute, but this block's statistics slot must read zero
-    if (colstats != nullptr) {
+    if (colstats.out != nullptr) {
       const int64_t pb = blockIdx.x / ncb;
-      colstats[(pb * 2 + 0) * Co + co0 + lane] = 0.f;
-      colstats[(pb * 2 + 1) * Co + co0 + lane] = 0.f;
+      colstats.out[(pb * 2 + 0) * Co + co0 + lane] = 0.f;
+      colstats.out[(pb * 2 + 1) * Co + co0 + lane] = 0.f;
     }
     return;
   }
@@ -2015,12 +2079,16 @@ __global__ void __launch_bounds__(64)
     }
   // column statistics of the wave's 32 output rows (colstats [pair blocks][2][Co]; blocks past the end of the lists
   // wrote zeros above): sum over the 16 pairs of a group = butterfly over the 16 lanes that share lq
-  if (colstats != nullptr) {
+  if (colstats.out != nullptr) {
     const int64_t pb = blockIdx.x / ncb;
 #pragma unroll
     for (int q = 0; q < COS; ++q) {
-      floatx4 cs = acc[0][q] + acc[1][q];
-      floatx4 css = acc[0][q] * acc[0][q] + acc[1][q] * acc[1][q];
+      floatx4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
+      StatsCols sc;
+      sc.init(colstats, co0 + 16 * q + 4 * lq);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        if (!sc.bn || live[g]) sc.add(acc[g][q], colstats.x + (int64_t)orow[g] * Co + co0 + 16 * q + 4 * lq, cs, css);
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1)
 #pragma unroll
@@ -2029,8 +2097,8 @@ __global__ void __launch_bounds__(64)
           css[e] += __shfl_xor(css[e], o);
         }
       if (li == 0) {
-        *(floatx4 *)(colstats + (pb * 2 + 0) * Co + co0 + 16 * q + 4 * lq) = cs;
-        *(floatx4 *)(colstats + (pb * 2 + 1) * Co + co0 + 16 * q + 4 * lq) = css;
+        *(floatx4 *)(colstats.out + (pb * 2 + 0) * Co + co0 + 16 * q + 4 * lq) = cs;
+        *(floatx4 *)(colstats.out + (pb * 2 + 1) * Co + co0 + 16 * q + 4 * lq) = css;
       }
     }
   }
@@ -2043,7 +2111,7 @@ __global__ void __launch_bounds__(64)
 template <bool W_IN_LDS>
 __global__ void __launch_bounds__(256)
     k_conv_generic(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W,
-                   const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ colstats, const int2 *__restrict__ rules,
+                   const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
                    const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                    int64_t n_out, int n_gran, int Ci, int Co, int w_transposed, int w_reverse) {
   constexpr int M = SCN_TILE_GRANULE;
@@ -2682,7 +2750,7 @@ static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, in
 }
 
 template <int NW, int COS, int M, int CK>
-static int launch_tile(const float *in, float *out, const float *W, const float *bias, const float *residual, float *colstats,
+static int launch_tile(const float *in, float *out, const float *W, const float *bias, const float *residual, StatsArg colstats,
                        const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                        int in_col, int64_t n_out, int Ci, int Co, hipStream_t stream) {
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
@@ -2694,7 +2762,7 @@ static int launch_tile(const float *in, float *out, const float *W, const float 
 }
 
 template <int NW, int COS, int CK, int NWM = 1, int M_ = 0>
-static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias, const float *residual, float *colstats,
+static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias, const float *residual, StatsArg colstats,
                         const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                         int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
                         hipStream_t stream) {
@@ -2744,7 +2812,7 @@ constexpr size_t tile6_lds_bytes() { return (size_t)(M * 68 + (KMAX * (M / 32) *
 // rows per tile of a kind-4 launch
 static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ? 96 : 128; }
 
-static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, float *colstats, const int32_t *rules,
+static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, StatsArg colstats, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
                         int Ci, int Co, int ksplit, float *part, const int32_t *tile_order, hipStream_t stream) {
   const int M = tile4_rows(ksplit);
@@ -2847,7 +2915,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 }
 
 template <int NW>
-static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias, const float *residual, float *colstats,
+static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias, const float *residual, StatsArg colstats,
                            const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                            int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
                            hipStream_t stream) {
@@ -2951,11 +3019,19 @@ int scn_weight_pack_batch(const void *descs, int n, int64_t total_blocks, void *
 }
 
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
-                     const float *bias, const float *residual, float *colstats, const int32_t *rules, const int32_t *bases,
+                     const float *bias, const float *residual, float *colstats_out, const scn_bn_bwd_stats *bn_bwd,
+                     const int32_t *rules, const int32_t *bases,
                      const int32_t *tile_order, const int32_t *counts, int K,
                      int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in, int64_t n_out, int Ci,
                      int Co, void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
+  StatsArg colstats{colstats_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f};
+  if (bn_bwd != nullptr && colstats_out != nullptr) {
+    SCN_REQUIRE(bn_bwd->x != nullptr && bn_bwd->save_mean != nullptr && bn_bwd->save_invstd != nullptr,
+                "scn_conv_forward: bn_bwd needs x, save_mean and save_invstd");
+    colstats = StatsArg{colstats_out, bn_bwd->x, bn_bwd->save_mean, bn_bwd->save_invstd, bn_bwd->weight, bn_bwd->bias,
+                        (float)bn_bwd->leakiness};
+  }
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_forward: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_forward: in_col/out_col must be 0/1 or 1/0");
   SCN_REQUIRE(Ci > 0 && Co > 0, "scn_conv_forward: bad plane counts");

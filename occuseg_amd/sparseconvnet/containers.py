@@ -10,7 +10,7 @@ from torch.nn import Module, Parameter
 
 from .. import SCN
 from . import counters
-from .tensor import SparseConvNetTensor, like_empty, optionalTensor
+from .tensor import GradJoin, SparseConvNetTensor, like_empty, optionalTensor
 
 
 class Sequential(torch.nn.Sequential):
@@ -30,6 +30,9 @@ class Identity(Module):
 
     def input_spatial_size(self, out_size):
         return out_size
+
+
+GRAD_JOIN = True  # A/B switch: residual blocks add the two gradients of their input inside a kernel (tensor.GradJoin)
 
 
 def _like(first, features):
@@ -60,13 +63,25 @@ class ResidualConcatTable(ConcatTable):
         hooked = len(children) == 2 and (children[1]._forward_hooks or children[1]._forward_pre_hooks)
         if not body or not isinstance(body[-1], SubmanifoldConvolution) or hooked:
             return ConcatTable.forward(self, input)
-        shortcut = children[0](input)
-        x = input
-        for mod in body[:-1]:
+        # GradJoin (tensor.py): the two gradients of the block's input -- out of the body's first batch norm, and through
+        # the shortcut (identity: the last convolution's incoming gradient itself; NiN: its dInput) -- are added inside
+        # one of the two kernels instead of by an autograd add kernel
+        from .norm import BatchNormalization
+        fits = (input.features.size(0) > 0 and
+                (children[0].nOut if isinstance(children[0], NetworkInNetwork) else input.features.size(1)) == body[-1].nOut)
+        join = None
+        if GRAD_JOIN and fits and isinstance(body[0], BatchNormalization) and self.training and \
+                isinstance(children[0], (Identity, NetworkInNetwork)) and not children[0]._forward_hooks:
+            join = GradJoin()
+        nin_join = join if isinstance(children[0], NetworkInNetwork) else None
+        shortcut = children[0](input, join=nin_join) if nin_join is not None else children[0](input)
+        x = body[0](input, join=join) if join is not None else body[0](input)
+        for mod in body[1:-1]:
             x = mod(x)
         if shortcut.features.size(1) != body[-1].nOut or shortcut.features.size(0) != x.features.size(0):
+            assert join is None
             return [shortcut, body[-1](x)]
-        return [body[-1](x, residual=shortcut.features)]
+        return [body[-1](x, residual=shortcut.features, join=join if nin_join is None else None)]
 
 
 class JoinTable(torch.nn.Sequential):
@@ -98,23 +113,39 @@ class AddTable(torch.nn.Sequential):
 
 class _NiNFunction(Function):
     @staticmethod
-    def forward(ctx, features, weight, bias):
+    def forward(ctx, features, weight, bias, join=None):
         out = like_empty(features)
         macs = SCN.NetworkInNetwork_updateOutput(features, out, weight, bias)
         counters.add(macs, out.nelement())
         ctx.save_for_backward(features, weight, bias)
+        ctx.join = join
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
+        from .conv import grad_owner
         features, weight, bias = ctx.saved_tensors
         grad_output = grad_output.contiguous()
-        grad_input = like_empty(grad_output)
-        grad_weight = torch.zeros_like(weight)
+        grad_input = like_empty(grad_output) if ctx.needs_input_grad[0] else None
+        # the weight gradient goes straight into the owner's flat buffer when there is one (as the convolutions' does)
+        owner = grad_owner(weight)
+        direct = owner is not None
+        grad_weight = weight.grad if direct else torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
-        SCN.NetworkInNetwork_updateGradInput(grad_input, grad_output, weight)
-        SCN.NetworkInNetwork_accGradParameters(features, grad_output, grad_weight, grad_bias)
-        return grad_input, grad_weight, (grad_bias if grad_bias.numel() else None)
+        # GradJoin: the other gradient of `features` (out of the body's first batch norm), if that finished first, is added
+        # inside the dInput kernel; otherwise this one is left for the batch norm's apply pass to add
+        join, ctx.join = ctx.join, None
+        extra = join.take() if (join is not None and grad_input is not None) else None
+        with SCN.dw_async(direct):
+            SCN.NetworkInNetwork_backward(features, grad_input, grad_output, weight, grad_weight, grad_bias,
+                                          _d_in_add=extra.contiguous() if extra is not None else None)
+        if join is not None and grad_input is not None and extra is None:
+            join.put(grad_input)
+            grad_input = None
+        if direct:
+            owner.grad_written(weight)
+            grad_weight = None
+        return grad_input, grad_weight, (grad_bias if grad_bias.numel() else None), None
 
 
 class NetworkInNetwork(Module):
@@ -127,9 +158,9 @@ class NetworkInNetwork(Module):
         if bias:
             self.bias = Parameter(torch.zeros(nOut))
 
-    def forward(self, input):
+    def forward(self, input, join=None):
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, input.features.shape)
-        return _like(input, _NiNFunction.apply(input.features, self.weight, optionalTensor(self, "bias")))
+        return _like(input, _NiNFunction.apply(input.features, self.weight, optionalTensor(self, "bias"), join))
 
     def input_spatial_size(self, out_size):
         return out_size

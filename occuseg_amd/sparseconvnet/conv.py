@@ -38,8 +38,9 @@ class _RuleConvFunction(Function):
 
     @staticmethod
     def forward(ctx, features, weight, bias, kind, metadata, in_size, out_size, filter_size, filter_stride,
-                dilated_rate, residual=None, stats_out=None):
+                dilated_rate, residual=None, stats_out=None, bn_link=None, join=None):
         ctx.kind, ctx.scn_meta, ctx.dilated_rate = kind, metadata, dilated_rate
+        ctx.bn_link, ctx.join = bn_link, join
         ctx.sizes = (in_size, out_size, filter_size, filter_stride)
         out = like_empty(features)
         if kind == "submanifold":
@@ -75,23 +76,36 @@ class _RuleConvFunction(Function):
         # kernel may run on a side stream beside what follows (SCN.dw_async keeps grad_output referenced until that
         # kernel has finished, so autograd cannot add another gradient into it in place meanwhile -- the shortcut of a
         # residual block, add_feature_planes, AddTable: whatever shares this tensor)
+        # bn_link: `features` is the output of a batch norm; the dInput launch below leaves that batch norm's two backward
+        # reductions with it (SCN.BnLink)
+        link = ctx.bn_link if grad_input is not None else None
         with SCN.dw_async(direct):
             if ctx.kind == "submanifold":
                 SCN.SubmanifoldConvolution_backward(in_size, filter_size, m, features, grad_input, grad_output, weight,
-                                                    grad_weight, grad_bias, ctx.dilated_rate)
+                                                    grad_weight, grad_bias, ctx.dilated_rate, _bn_link=link)
             elif ctx.kind == "conv":
                 SCN.Convolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
-                                         grad_output, weight, grad_weight, grad_bias)
+                                         grad_output, weight, grad_weight, grad_bias, _bn_link=link)
             else:
                 SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, m, features, grad_input,
-                                           grad_output, weight, grad_weight, grad_bias)
-        ctx.scn_meta = None
+                                           grad_output, weight, grad_weight, grad_bias, _bn_link=link)
+        ctx.scn_meta = ctx.bn_link = None
         if direct:
             owner.grad_written(weight)
             grad_weight = None
-        # d(out)/d(residual) = identity: the incoming gradient itself
+        # d(out)/d(residual) = identity: the incoming gradient itself.  With a GradJoin (the residual IS the block's
+        # input x, whose other gradient comes out of the body's first batch norm) it is left for that batch norm's
+        # apply pass to add; if that one finished first, the sum is formed here.
         grad_residual = grad_output if ctx.needs_input_grad[10] else None
-        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7 + (grad_residual, None)
+        join, ctx.join = ctx.join, None
+        if join is not None and grad_residual is not None:
+            other = join.take()
+            if other is None:
+                join.put(grad_residual)
+                grad_residual = None
+            else:
+                grad_residual = grad_residual + other
+        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7 + (grad_residual, None, None, None)
 
 
 class _RuleConv(Module):
@@ -114,9 +128,9 @@ class _RuleConv(Module):
     def output_spatial_size(self, in_size):
         raise NotImplementedError
 
-    def forward(self, input, residual=None):
+    def forward(self, input, residual=None, join=None):
         """``residual`` (submanifold only; used by the residual blocks of scn.UNet): features added to the output
-        inside the convolution kernel"""
+        inside the convolution kernel; ``join``: see tensor.GradJoin (the residual is the block's input)"""
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, self.nOut, input)
         assert residual is None or self.kind == "submanifold"
         out_size = self.output_spatial_size(input.spatial_size)
@@ -126,7 +140,8 @@ class _RuleConv(Module):
         sink = [] if (self.training and EMIT_COLSTATS) else None
         output.features = _RuleConvFunction.apply(
             input.features, self.weight, optionalTensor(self, "bias"), self.kind, input.metadata,
-            input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate, residual, sink)
+            input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate, residual, sink,
+            input.get_bn_link() if hasattr(input, "get_bn_link") else None, join if residual is not None else None)
         if sink:
             output.set_colstats([(self.nOut, sink[0])])
         return output

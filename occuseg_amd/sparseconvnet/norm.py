@@ -16,14 +16,20 @@ from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTen
 
 class _BatchNormFunction(Function):
     @staticmethod
-    def forward(ctx, features, weight, bias, running_mean, running_var, eps, momentum, train, leakiness, colstats=None):
+    def forward(ctx, features, weight, bias, running_mean, running_var, eps, momentum, train, leakiness, colstats=None,
+                link_out=None, join=None):
         ctx.train, ctx.leakiness = train, leakiness
+        ctx.join = join
         out = like_empty(features)
         save_mean = like_empty(features)
         save_invstd = like_empty(features)
         SCN.BatchNormalization_updateOutput(features, out, save_mean, save_invstd, running_mean, running_var,
                                             weight, bias, eps, momentum, train, leakiness, _colstats=colstats)
         ctx.save_for_backward(features, out, weight, bias, running_mean, running_var, save_mean, save_invstd)
+        ctx.link = None
+        if link_out is not None and train:  # for the convolution that consumes `out` (SCN.BnLink)
+            ctx.link = SCN.BnLink(features, save_mean, save_invstd, weight, bias, leakiness)
+            link_out.append(ctx.link)
         return out
 
     @staticmethod
@@ -40,14 +46,28 @@ class _BatchNormFunction(Function):
         direct = owner is not None
         grad_weight = weight.grad if direct else torch.zeros_like(weight)
         grad_bias = bias.grad if direct else torch.zeros_like(bias)
+        # (not in the reference) the two reductions of this pass, if the convolution that consumed `out` took them from
+        # its dInput tile (SCN.BnLink), and the gradient arriving at `features` along the other path of a residual block
+        # (GradJoin): added inside the apply pass instead of by an autograd add kernel
+        partials = ctx.link.take(grad_output) if ctx.link is not None else None
+        join, extra = ctx.join, None
+        if join is not None and join.pending is not None:
+            extra = join.take()
+            if not (extra.is_contiguous() and extra.shape == features.shape):
+                extra = extra.contiguous()
         SCN.BatchNormalization_backward(features, grad_input, out, grad_output, save_mean, save_invstd,
                                         running_mean, running_var, weight, bias, grad_weight, grad_bias,
-                                        ctx.leakiness, _rewrite_d_output=False, _accumulate=direct, _mask_from_x=True)
+                                        ctx.leakiness, _rewrite_d_output=False, _accumulate=direct, _mask_from_x=True,
+                                        _partials=partials, _d_x_add=extra)
+        ctx.link = ctx.join = None
+        if join is not None and extra is None:  # first of the two paths to finish: the other one adds this
+            join.put(grad_input)
+            grad_input = None
         if direct:
             owner.grad_written(weight)
             owner.grad_written(bias)
-            return (grad_input, None, None) + (None,) * 7
-        return (grad_input, optionalTensorReturn(grad_weight), optionalTensorReturn(grad_bias)) + (None,) * 7
+            return (grad_input, None, None) + (None,) * 9
+        return (grad_input, optionalTensorReturn(grad_weight), optionalTensorReturn(grad_bias)) + (None,) * 9
 
 
 class BatchNormalization(Module):
@@ -61,7 +81,8 @@ class BatchNormalization(Module):
             self.weight = Parameter(torch.ones(nPlanes))
             self.bias = Parameter(torch.zeros(nPlanes))
 
-    def forward(self, input):
+    def forward(self, input, join=None):
+        """``join`` (not in the reference; used by the residual blocks of scn.UNet): see tensor.GradJoin"""
         assert input.features.nelement() == 0 or input.features.size(1) == self.nPlanes, \
             (self.nPlanes, input.features.shape)
         output = SparseConvNetTensor(metadata=input.metadata, spatial_size=input.spatial_size)
@@ -69,9 +90,12 @@ class BatchNormalization(Module):
         ext = input.get_colstats() if self.training and hasattr(input, "get_colstats") else None
         if ext and sum(n for n, _ in ext) != self.nPlanes:
             ext = None
+        link_out = [] if (self.training and torch.is_grad_enabled() and input.features.requires_grad) else None
         output.features = _BatchNormFunction.apply(
             input.features, optionalTensor(self, "weight"), optionalTensor(self, "bias"), self.running_mean,
-            self.running_var, self.eps, self.momentum, self.training, self.leakiness, ext)
+            self.running_var, self.eps, self.momentum, self.training, self.leakiness, ext, link_out, join)
+        if link_out:
+            output.set_bn_link(link_out[0])
         return output
 
     def input_spatial_size(self, out_size):

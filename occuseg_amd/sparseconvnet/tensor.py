@@ -16,6 +16,26 @@ def Metadata(dim):
     return SCN.Metadata_3()
 
 
+class GradJoin(object):
+    """Two autograd Functions whose input gradients meet at ONE tensor x (the shortcut and the body of a residual block)
+    share one of these, created in forward.  In backward the first to finish leaves its gradient here and returns None
+    to autograd; the second adds it INSIDE its own kernel (batch norm backward's apply pass, the NiN dInput's output
+    tile) and returns the sum: the elementwise add kernel autograd would launch at x disappears.  Whichever order the
+    engine runs the two in, the sum is the same.  One object per forward pass: nothing survives a failed backward."""
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = None
+
+    def put(self, grad):
+        assert self.pending is None
+        self.pending = grad
+
+    def take(self):
+        g, self.pending = self.pending, None
+        return g
+
+
 class SparseConvNetTensor(object):
     """features [N, planes] + the shared Metadata + the spatial size of the grid."""
 
@@ -24,6 +44,7 @@ class SparseConvNetTensor(object):
         self.metadata = metadata
         self.spatial_size = spatial_size
         self._colstats = None  # (version of the features tensor, [(planes, partial column sums), ...]) -- see set_colstats
+        self._bn_link = None   # (version, SCN.BnLink) left by the batch norm that produced `features` -- see set_bn_link
 
     @property
     def features(self):
@@ -34,6 +55,7 @@ class SparseConvNetTensor(object):
         # whatever statistics the producing kernel handed over belong to the tensor that was here before
         self._features = value
         self._colstats = None
+        self._bn_link = None
 
     def set_colstats(self, segments):
         """Column statistics of ``features`` emitted by the kernel(s) that produced it (not in the reference).  They
@@ -47,6 +69,16 @@ class SparseConvNetTensor(object):
         if self._colstats is None or self._features is None:
             return None
         return self._colstats[1] if self._colstats[0] == self._features._version else None
+
+    def set_bn_link(self, link):
+        """``features`` is the output of a batch norm: the convolution that consumes it hands that batch norm's backward
+        pass its two reductions (SCN.BnLink).  Same validity rules as set_colstats."""
+        self._bn_link = (self._features._version, link) if link is not None and self._features is not None else None
+
+    def get_bn_link(self):
+        if self._bn_link is None or self._features is None:
+            return None
+        return self._bn_link[1] if self._bn_link[0] == self._features._version else None
 
     def get_spatial_locations(self, spatial_size=None):
         """LongTensor [N,4]: coordinates and batch index of the active sites"""

@@ -490,3 +490,62 @@ def test_network_with_and_without_statistics_handover(gpu):
     assert_close(o1.cpu().numpy(), o2.cpu().numpy(), "statistics hand-over: output", rel=2e-5)
     for a, b in zip(g1, g2):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), "statistics hand-over: grads", rel=2e-4)
+
+
+# dInput launches: 64->64 and 128->64 on k_conv_tile4, 96->64 on the unsplit k_conv_tile2; the last one (a small grid) is
+# an offset-split launch, which emits no sums: the batch norm then runs its own statistics pass
+@pytest.mark.parametrize("ci,co,n,extent,leak", [(64, 64, 72000, 60, 0.0), (64, 96, 72000, 60, 0.2), (128, 64, 20000, 40, 1.0),
+                                                 (64, 64, 3000, 20, 0.0)])
+def test_bn_backward_reductions_from_the_dinput_launch(gpu, ci, co, n, extent, leak):
+    """scn_conv_forward(bn_bwd): the dInput launch of a convolution whose input was y = BN(x) leaves sum d' and
+    sum (x - mean) d' per block of rows; scn_bn_backward_ext finishes the batch norm's backward pass from them, with another
+    gradient added inside the apply pass -- against the oracle's batch-norm backward (arithmetic of
+    sparseconvnet/SCN/CPU/BatchNormalization.cpp:64-107) over the oracle's dInput, and against the plain two-pass path."""
+    from occuseg_amd import SCN
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu, seed=3, n=n, batch=2, extent=extent)
+    rules, _ = R.submanifold_rules(grid)
+    rng = np.random.default_rng(ci + co)
+    N = grid.n
+    x = (rng.normal(size=(N, ci)) * 2 + rng.normal(size=ci)).astype(np.float32)
+    gamma, beta = rng.normal(size=ci).astype(np.float32), rng.normal(size=ci).astype(np.float32)
+    w = (rng.normal(size=(27, ci, co)) * (2.0 / ci / 27) ** 0.5).astype(np.float32)
+    dy = rng.normal(size=(N, co)).astype(np.float32)
+    extra = rng.normal(size=(N, ci)).astype(np.float32)
+    e = torch.empty(0, device=gpu)
+    xt, gt, bt = _t(x, gpu), _t(gamma, gpu), _t(beta, gpu)
+    y, sm, si = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+    rm, rv = torch.zeros(ci, device=gpu), torch.ones(ci, device=gpu)
+    SCN.BatchNormalization_updateOutput(xt, y, sm, si, rm, rv, gt, bt, 1e-4, 0.9, True, leak)
+    # the convolution's backward pass with the link: d_in = d(loss)/dy, partial sums for the batch norm
+    link = SCN.BnLink(xt, sm, si, gt, bt, leak)
+    d_in, gw = torch.empty(0, device=gpu), torch.zeros(27, ci, co, device=gpu)
+    SCN.SubmanifoldConvolution_backward(size, F3, m, y, d_in, _t(dy, gpu), _t(w, gpu), gw, e, 1, _bn_link=link)
+    partials = link.take(d_in)
+    assert (partials is None) == (n == 3000)
+    assert partials is None or partials.shape[1:] == (2, ci)
+    dgam, dbet = torch.zeros(ci, device=gpu), torch.zeros(ci, device=gpu)
+    dx = torch.empty(0, device=gpu)
+    SCN.BatchNormalization_backward(xt, dx, y, d_in, sm, si, rm, rv, gt, bt, dgam, dbet, leak, _rewrite_d_output=False,
+                                    _mask_from_x=True, _partials=partials, _d_x_add=_t(extra, gpu))
+    # plain path on the same d_in
+    dgam2, dbet2, dx2 = torch.zeros(ci, device=gpu), torch.zeros(ci, device=gpu), torch.empty(0, device=gpu)
+    SCN.BatchNormalization_backward(xt, dx2, y, d_in, sm, si, rm, rv, gt, bt, dgam2, dbet2, leak, _rewrite_d_output=False,
+                                    _mask_from_x=True)
+    assert_close(dx.cpu().numpy(), dx2.cpu().numpy() + extra, "fused dX against the two-pass path", rel=1e-5)
+    assert_close(dgam.cpu().numpy(), dgam2.cpu().numpy(), "dGamma", rel=1e-5)
+    assert_close(dbet.cpu().numpy(), dbet2.cpu().numpy(), "dBeta", rel=1e-5)
+    # oracle: batch-norm backward of the oracle's own dInput, with the device's y for the mask
+    yo, smo, sio, _, _ = A.batchnorm_forward(x, gamma, beta, np.zeros(ci), np.ones(ci), train=True, leakiness=leak, dtype=np.float64)
+    d_in_o, _, _ = A.conv_backward(y.cpu().numpy(), dy, w, rules, dtype=np.float64)
+    want_dx, _, want_dg, want_db = A.batchnorm_backward(x, y.cpu().numpy(), d_in_o, smo, sio, gamma, leakiness=leak, dtype=np.float64)
+    assert_close(dx.cpu().numpy(), want_dx + extra, "fused dX against the oracle")
+    assert_close(dgam.cpu().numpy(), want_dg, "dGamma against the oracle")
+    assert_close(dbet.cpu().numpy(), want_db, "dBeta against the oracle")
+    # a gradient that was modified after the launch does not get the stale sums
+    link2 = SCN.BnLink(xt, sm, si, gt, bt, leak)
+    d2 = torch.empty(0, device=gpu)
+    SCN.SubmanifoldConvolution_backward(size, F3, m, y, d2, _t(dy, gpu), _t(w, gpu), torch.zeros(27, ci, co, device=gpu), e, 1,
+                                        _bn_link=link2)
+    d2.add_(1.0)
+    assert link2.take(d2) is None

@@ -460,3 +460,42 @@ def test_dweight_side_stream_with_shared_gradient_tensors(gpu):
                 assert err <= 1e-4 * ref.abs().max().item() + 1e-30, ("after a failed backward", it, name, err)
     finally:
         bucket.close()
+
+
+@pytest.mark.parametrize("m,levels,sites", [(16, 3, 6000), (64, 3, 70000)], ids=["m16-tile2", "m64-tile4"])
+def test_fused_backward_paths_equal_the_plain_ones(gpu, m, levels, sites):
+    """Round 3 moved two pieces of the backward pass into neighbouring kernels: the two reductions of a batch norm's
+    backward pass are taken by the dInput launch of the convolution that consumed its output (SCN.BnLink: tile4 / tile2 /
+    expand epilogues), and the two gradients of a residual block's input are added inside a kernel (tensor.GradJoin: the
+    batch norm's apply pass, the NiN dInput tile).  Every combination of the two switches against the plain autograd
+    path: same outputs bitwise (the forward pass is untouched), every gradient at 1e-5."""
+    import occuseg_amd
+    from occuseg_amd import SCN, scenes
+    from occuseg_amd.sparseconvnet import containers
+    scn = occuseg_amd.install()
+    torch.manual_seed(21)
+    net = _net(scn, m, levels, 0.0).to(gpu)
+    coords, feats = scenes.batch([1000, 1001], target_sites=sites)
+    batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
+    gsel = torch.randn(len(coords), m, device=gpu)
+    buffers = [b.clone() for b in net.buffers()]
+
+    def run(stats_from_conv, grad_join):
+        SCN.BN_BWD_STATS_FROM_CONV, containers.GRAD_JOIN = stats_from_conv, grad_join
+        for b, r in zip(net.buffers(), buffers):
+            b.copy_(r)
+        for p in net.parameters():
+            p.grad = None
+        out = net(batch)
+        (out * gsel).sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()]
+
+    try:
+        ref_out, ref = run(False, False)
+        for combo in ((True, False), (False, True), (True, True)):
+            out, grads = run(*combo)
+            assert torch.equal(out, ref_out)
+            for (name, _), g, r in zip(net.named_parameters(), grads, ref):
+                assert_close(g.cpu().numpy(), r.cpu().numpy(), "%s with %s" % (name, combo), rel=1e-5)
+    finally:
+        SCN.BN_BWD_STATS_FROM_CONV, containers.GRAD_JOIN = True, True

@@ -41,6 +41,12 @@ def apply(name, val):
         setattr(SCN, name, float(val) if isinstance(cur, float) else type(cur)(int(val)))
 
 
+# AB_MAIN_PRIORITY=-1: run the steps on a high-priority stream (the dWeight side stream stays at normal priority)
+_main = None
+if os.environ.get("AB_MAIN_PRIORITY"):
+    print("stream priority range", torch.cuda.Stream.priority_range())
+    _main = torch.cuda.Stream(device=dev, priority=int(os.environ["AB_MAIN_PRIORITY"]))
+    torch.cuda.set_stream(_main)
 name, vals = sys.argv[1].split("=")
 vals = vals.split(",")
 for _ in range(3):
