@@ -120,6 +120,11 @@ int scn_strided_rules(const int32_t *fine_coords, int64_t N, const int32_t *coar
 int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
                    int out_col, int64_t n_out, int32_t *bases, void *stream);
 
+/* order [ceil(n_out / 128)]: a dispatch order for scn_conv_forward's tile_order from the tile-base table of the output
+ * column: the tiles with fewer pairs than light_permille / 1000 of the mean go last, the others keep their place
+ * (a stable partition).  At most 16384 tiles. */
+int scn_tile_order(const int32_t *bases, int K, int64_t n_out, int light_permille, int32_t *order, void *stream);
+
 /* ------------------------------------------------------- gather-mm-scatter ---
  * out[o,:] = (bias) + sum_k sum_{pairs of list k} in[pair.in_col,:] . Wk
  * Replaces cuda_SubmanifoldConvolution_updateOutput / cuda_Convolution_updateOutput /

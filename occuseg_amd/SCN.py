@@ -88,8 +88,10 @@ def _need_cuda(t, what):
 _PLANS = {}
 _PLANS_USED = {}  # spatial size -> the request list of the most recent forward pass that really ran (tools, bench)
 PREBUILD = True
-TILE_ORDER = 1       # 0: tiles start in index order; 1: the lightest TILE_ORDER_TAIL of them last; 2: longest first
-TILE_ORDER_TAIL = 0.25
+# dispatch order of the 128-row tiles of the big launches: 0 = index order; 1 = the tiles lighter than TILE_ORDER_LIGHT x the
+# mean pair count last, in index order (scn_tile_order); 2 = longest first (see Metadata_3._tile_bases)
+TILE_ORDER = int(os.environ.get("SCN_TILE_ORDER", "0"))
+TILE_ORDER_LIGHT = float(os.environ.get("SCN_TILE_ORDER_LIGHT", "0.95"))
 KEEP_NBR = False  # tests only: keep each submanifold rulebook's neighbour table (`d_global_query_result`) alive
 _COORD_DTYPES = {torch.int32: 0, torch.int64: 1, torch.float32: 2}  # scn_grid_build coords_dtype
 
@@ -333,20 +335,15 @@ class Metadata_3(object):
         # place (neighbouring tiles gather overlapping rows and share an L2), the lightest TILE_ORDER_TAIL of them move to
         # the end, lightest last.
         n_tiles = (n_out + 127) // 128
-        if TILE_ORDER and rb.K > 1 and n_tiles >= 512 // 4:
-            lo = torch.arange(n_tiles, device=bases.device) * 4
-            hi = torch.clamp(lo + 4, max=n_gran)
-            work = (bases[:, hi] - bases[:, lo]).sum(0)
-            if TILE_ORDER == 2:  # full longest-first order
-                order = torch.argsort(work, descending=True, stable=True)
-            else:
-                by_work = torch.argsort(work, descending=True, stable=True)
-                n_tail = int(n_tiles * TILE_ORDER_TAIL)
-                tail = by_work[n_tiles - n_tail:]
-                keep = torch.ones(n_tiles, dtype=torch.bool, device=bases.device)
-                keep[tail] = False
-                order = torch.cat([torch.nonzero(keep).view(-1), tail])
-            rb.order[out_col] = order.to(torch.int32).contiguous()
+        if TILE_ORDER and rb.K > 1 and 128 <= n_tiles <= 16384:
+            if TILE_ORDER == 1:  # one small kernel: stable partition, tiles lighter than TILE_ORDER_LIGHT x the mean last
+                order = torch.empty(n_tiles, dtype=torch.int32, device=bases.device)
+                check(lib.scn_tile_order(ptr(bases), rb.K, n_out, int(1000 * TILE_ORDER_LIGHT), ptr(order), stream()))
+            else:  # 2: longest first (A/B)
+                lo = torch.arange(n_tiles, device=bases.device) * 4
+                work = (bases[:, torch.clamp(lo + 4, max=n_gran)] - bases[:, lo]).sum(0)
+                order = torch.argsort(work, descending=True, stable=True).to(torch.int32).contiguous()
+            rb.order[out_col] = order
 
     def getSubmanifoldRuleBook(self, spatialSize, filterSize, dilated_rate=1, _defer=False):
         """cache key (spatialSize, filterSize) as sparseconvnet/SCN/Metadata/Metadata.cpp:504-529"""

@@ -29,6 +29,7 @@ SIGNATURES = {
     "scn_submanifold_rules": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_size_t, _P, c_int, c_int, _P, _P]),
     "scn_strided_rules": (c_int, [_P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "scn_tile_bases": (c_int, [_P, _P, c_int, c_int64, c_int, c_int64, _P, _P]),
+    "scn_tile_order": (c_int, [_P, c_int, c_int64, c_int, _P, _P]),
     "scn_conv_wpack_bytes": (c_size_t, [c_int, c_int, c_int]),
     "scn_conv_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_plan": (c_int, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),

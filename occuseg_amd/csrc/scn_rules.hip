@@ -311,6 +311,70 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Dispatch order of the 128-row tiles of one output column (scn_conv_forward's tile_order): the tiles whose pair count is
+// below light_permille / 1000 of the mean move to the end, everything else keeps its place -- a stable partition, so
+// neighbouring tiles (which gather overlapping rows) stay neighbours in both parts.  One workgroup: <= 16 tiles per thread.
+constexpr int TILE_ORDER_MAX = 16384;
+__global__ void __launch_bounds__(1024)
+    k_tile_order(const int32_t *__restrict__ bases, int K, int n_gran, int n_tiles, int light_permille, int32_t *__restrict__ order) {
+  constexpr int PER = TILE_ORDER_MAX / 1024;
+  __shared__ unsigned long long total_s;
+  __shared__ int wsum[16], heavy_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int work[PER];
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {  // thread t owns the CONSECUTIVE tiles t * PER + j (keeps the partition stable)
+    const int t = tid * PER + j;
+    int wk = 0;
+    if (t < n_tiles) {
+      const int g0 = t * 4, g1 = min(g0 + 4, n_gran);
+      for (int k = 0; k < K; ++k) wk += bases[(int64_t)k * (n_gran + 1) + g1] - bases[(int64_t)k * (n_gran + 1) + g0];
+    }
+    work[j] = wk;
+    mine += (unsigned long long)wk;
+  }
+  if (tid == 0) total_s = 0;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if (lane == 0) atomicAdd(&total_s, mine);
+  __syncthreads();
+  // light: work * 1000 * n_tiles < light_permille * total
+  const unsigned long long rhs = (unsigned long long)light_permille * total_s;
+  int nh = 0;
+  bool heavy[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int t = tid * PER + j;
+    heavy[j] = t < n_tiles && (unsigned long long)work[j] * 1000ull * (unsigned long long)n_tiles >= rhs;
+    nh += heavy[j];
+  }
+  // exclusive scan of the per-thread heavy counts over the workgroup
+  int incl = nh;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 16; ++i) { const int v = wsum[i]; wsum[i] = run; run += v; }
+    heavy_s = run;
+  }
+  __syncthreads();
+  int hpos = wsum[wv] + incl - nh;                                   // heavy tiles before this thread's first tile
+  int lpos = heavy_s + min(tid * PER, n_tiles) - hpos;               // light tiles before it, behind all heavy ones
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int t = tid * PER + j;
+    if (t < n_tiles) {
+      if (heavy[j]) order[hpos++] = t;
+      else order[lpos++] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------ tile bases ---
 __global__ void k_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
                              int out_col, int n_gran, int32_t *bases) {
@@ -556,6 +620,17 @@ int scn_strided_rules(const int32_t *fine_coords, int64_t N, const int32_t *coar
   SCN_CHECK_LAUNCH();
   k_str_fill<<<nblk, 256, 0, stream>>>((const int4 *)fine_coords, N, coarse_of_fine, blk_cnt, nblk,
                                       (int2 *)rules);
+  SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int scn_tile_order(const int32_t *bases, int K, int64_t n_out, int light_permille, int32_t *order, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+  const int n_tiles = (int)((n_out + 127) / 128);
+  SCN_REQUIRE(K >= 1 && n_tiles >= 1 && n_tiles <= TILE_ORDER_MAX && light_permille >= 0 && light_permille <= 1000,
+              "scn_tile_order: bad arguments (at most 16384 tiles)");
+  k_tile_order<<<1, 1024, 0, stream>>>(bases, K, n_gran, n_tiles, light_permille, order);
   SCN_CHECK_LAUNCH();
   return 0;
 }
