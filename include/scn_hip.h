@@ -213,10 +213,16 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
  * as the reference's callers do: sparseconvnet/submanifoldConvolution.py:114-115).
  * Replaces dConvolution_KMxKN_backward_dW_* (sparseconvnet/SCN/CUDA/Convolution.cu:265-442,:695-753).
  * bases: scn_tile_bases(.., out_col, n_dout) or NULL; with it, narrow inputs (Ci <= 4: the 3 -> m stem) are processed
- * output-row major (every dOut row read once instead of once per pair). */
+ * output-row major (every dOut row read once instead of once per pair).
+ * workspace (may be NULL): scn_conv_dweight_workspace_bytes(...) bytes.  Without it the workgroups add their partial sums to
+ * dW with float atomics (as the reference, Convolution.cu:749): the result is reproducible to rounding only.  With it every
+ * workgroup stores its partial sums to a slot of its own and a second kernel adds the slots to dW in a fixed order: dW is
+ * bitwise reproducible run to run (costs a memset and a pass over slots x |dW| floats). */
+size_t scn_conv_dweight_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_dout, int Ci, int Co, int has_bases);
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, const int32_t *bases, int K, int64_t stride, int in_col,
-                     int out_col, int64_t n_in, int64_t n_dout, int Ci, int Co, void *stream);
+                     int out_col, int64_t n_in, int64_t n_dout, int Ci, int Co, void *workspace,
+                     size_t workspace_bytes, void *stream);
 
 /* column sums: d_bias[c] = sum_rows dOut[r][c] (sparseconvnet/SCN/CUDA/Convolution.cu:52-75) */
 int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream);

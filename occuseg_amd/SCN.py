@@ -819,6 +819,17 @@ def _dw_finish(idx):
     del st[2][:]
 
 
+DETERMINISTIC_DW = False  # True: parameter gradients bitwise reproducible run to run (scn_conv_dweight's workspace: partial
+                          # sums added in a fixed order instead of float atomics); costs a memset + a reduction per launch
+
+
+def _dw_workspace(rb, out_col, K, n_in, n_dout, Ci, Co, device):
+    if not DETERMINISTIC_DW:
+        return None, 0
+    nbytes = _lib_().scn_conv_dweight_workspace_bytes(K, rb.stride, n_in, n_dout, Ci, Co, int(rb.bases.get(out_col) is not None))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
 def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_col, n_in, reverse, bn_link=None,
                    d_in_add=None):
     """d_in = gather-mm-scatter of d_out with the transposed weights; dW; d_bias.
@@ -846,9 +857,10 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
         side = _dw_side_begin(inp, d_out, d_weight)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             ev = _prof_begin()
+            ws, wsb = _dw_workspace(rb, out_col, K, inp.size(0), d_out.size(0), Ci, Co, inp.device)
             check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts),
                                        ptr(rb.bases.get(out_col)), K, rb.stride, in_col, out_col, inp.size(0),
-                                       d_out.size(0), Ci, Co, stream()))
+                                       d_out.size(0), Ci, Co, ptr(ws), wsb, stream()))
             R = rb.total_pairs
             _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else "dw_narrow", 2.0 * R * Ci * Co,
                       4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
@@ -1176,9 +1188,10 @@ def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weig
         Ci, Co = d_weight.shape
         d_weight.zero_()
         ev = _prof_begin()
+        ws, wsb = _dw_workspace(rb, 1, 1, n, n, Ci, Co, input_features.device)
         check(_lib_().scn_conv_dweight(ptr(input_features.contiguous()), ptr(d_output_features.contiguous()),
                                        ptr(d_weight), ptr(rb.rules), ptr(rb.counts), ptr(rb.bases.get(1)), 1, rb.stride,
-                                       0, 1, n, n, Ci, Co, stream()))
+                                       0, 1, n, n, Ci, Co, ptr(ws), wsb, stream()))
         _prof_end(ev, "dw_tile", 2.0 * n * Ci * Co, 4.0 * n * (Ci + Co) + 8.0 * n + 4.0 * Ci * Co, (1, n, Ci, Co, 0, 0))
         return
     if n:

@@ -40,7 +40,9 @@ SIGNATURES = {
     "scn_conv_stats_blocks": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
                                  c_int64, c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
-    "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P]),
+    "scn_conv_dweight_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
+    "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P,
+                                 c_size_t, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
     "scn_bn_temp_bytes": (c_size_t, [c_int]),
     "scn_bn_forward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_int, c_double,

@@ -2202,10 +2202,45 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------- dWeight ---
+// Where a dWeight workgroup leaves its partial sums.  Default: float atomics into dW (as the reference,
+// sparseconvnet/SCN/CUDA/Convolution.cu:749): fastest, reproducible to rounding only.  With a workspace (`part`: [slots][K Ci Co],
+// zeroed by the launcher): plain stores into the workgroup's own slot, and k_dw_reduce adds the slots to dW in a FIXED
+// order afterwards: parameter gradients are then bitwise reproducible run to run.
+struct DwOut {
+  float *dW, *part;
+  int64_t elems;  // K * Ci * Co
+  __device__ __forceinline__ void add(int64_t slot, int64_t idx, float v) const {
+    if (part) part[slot * elems + idx] = v;
+    else unsafeAtomicAdd(dW + idx, v);
+  }
+};
+__global__ void __launch_bounds__(256)
+    k_dw_reduce(const float *__restrict__ part, float *__restrict__ dW, int64_t elems4, int nslots) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < elems4; i += (int64_t)gridDim.x * 256) {
+    float4 a = ((const float4 *)part)[i];
+    for (int s = 1; s < nslots; ++s) {
+      const float4 b = ((const float4 *)part)[(int64_t)s * elems4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float4 d = ((float4 *)dW)[i];
+    d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+    ((float4 *)dW)[i] = d;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_dw_reduce1(const float *__restrict__ part, float *__restrict__ dW, int64_t elems, int nslots) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= elems) return;
+  float a = part[i];
+  for (int s = 1; s < nslots; ++s) a += part[(int64_t)s * elems + i];
+  dW[i] += a;
+}
+
 // block: 4 waves as 2x2; wave owns TI x TJ 16x16 tiles; block tile CIB x COB.
 template <int TI, int TJ, int PS = 32, int ABL = 0>
 __global__ void __launch_bounds__(256)
-    k_dw_tile(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+    k_dw_tile(const float *__restrict__ in, const float *__restrict__ dout, DwOut dwo,
               const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
               int in_col, int Ci, int Co, int chunk, unsigned in_bytes, unsigned do_bytes, int K) {
   constexpr int CIB = 32 * TI, COB = 32 * TJ;
@@ -2363,7 +2398,7 @@ __global__ void __launch_bounds__(256)
       for (int r = 0; r < 4; ++r) {
         const int ci = ci0 + (wi * TI + ta) * 16 + 4 * lq + r;
         const int co = co0 + (wj * TJ + tb) * 16 + li;
-        unsafeAtomicAdd(dW + ((int64_t)k * Ci + ci) * Co + co, acc[ta][tb][r]);
+        dwo.add(c, ((int64_t)k * Ci + ci) * Co + co, acc[ta][tb][r]);
       }
 }
 
@@ -2381,7 +2416,7 @@ __global__ void __launch_bounds__(256)
 // accumulators through 16 KB of LDS at the end, so the number of float atomics per launch is that of k_dw_tile.
 template <int INCOL, bool ATOMIC = true>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
-    k_dw_direct(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+    k_dw_direct(const float *__restrict__ in, const float *__restrict__ dout, DwOut dwo,
                 const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
                 int Ci, int Co, int gx, unsigned in_bytes, unsigned do_bytes, int K) {
   __shared__ __attribute__((aligned(16))) floatx4 red[16 * 64];
@@ -2510,12 +2545,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
     for (int ja = 0; ja < 4; ++ja)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float *dst = dW + ((int64_t)k * Ci + ci0 + 4 * (4 * lq + r) + ja) * Co + co0 + 4 * li;
+        const int64_t idx = ((int64_t)k * Ci + ci0 + 4 * (4 * lq + r) + ja) * Co + co0 + 4 * li;
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-          if (ATOMIC) unsafeAtomicAdd(dst + jb, acc[ja][jb][r]);
-          else dst[jb] = acc[ja][jb][r];
-        }
+        for (int jb = 0; jb < 4; ++jb) dwo.add(c, idx + jb, acc[ja][jb][r]);
       }
   }
 }
@@ -2524,7 +2556,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 // the pair and the Ci input values are wave-uniform, only the dOut row is a vector load
 template <int CI>
 __global__ void __launch_bounds__(256)
-    k_dw_narrow(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+    k_dw_narrow(const float *__restrict__ in, const float *__restrict__ dout, DwOut dwo,
                 const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
                 int in_col, int Co, int chunk) {
   const int k = blockIdx.y;
@@ -2556,7 +2588,8 @@ __global__ void __launch_bounds__(256)
         for (int c = 0; c < CI; ++c) acc[c] += x[u][c] * d[u];
     }
 #pragma unroll
-    for (int c = 0; c < CI; ++c) unsafeAtomicAdd(dW + ((int64_t)k * CI + c) * Co + co, acc[c]);
+    // (with a workspace: the four waves of this workgroup would store to the same slot -- wave w takes slot 4 x + w)
+    for (int c = 0; c < CI; ++c) dwo.add((int64_t)blockIdx.x * 4 + w, ((int64_t)k * CI + c) * Co + co, acc[c]);
   }
 }
 
@@ -2569,7 +2602,7 @@ __global__ void __launch_bounds__(256)
 // per (k, c, plane) and workgroup at the end.
 template <int CI>
 __global__ void __launch_bounds__(256)
-    k_dw_rows(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+    k_dw_rows(const float *__restrict__ in, const float *__restrict__ dout, DwOut dwo,
               const int2 *__restrict__ rules, const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
               int n_gran, int64_t n_dout, int Co) {
   constexpr int M = SCN_TILE_GRANULE;
@@ -2617,13 +2650,13 @@ __global__ void __launch_bounds__(256)
       red[w][lane] = acc[k][c];
       __syncthreads();
       if (w == 0 && co < Co)
-        unsafeAtomicAdd(dW + ((int64_t)k * CI + c) * Co + co, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        dwo.add(blockIdx.x, ((int64_t)k * CI + c) * Co + co, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
     }
 }
 
 // generic dW (any Ci, Co): block = (pair chunk, k); threads stride over (ci, co)
 __global__ void __launch_bounds__(256)
-    k_dw_generic(const float *__restrict__ in, const float *__restrict__ dout, float *__restrict__ dW,
+    k_dw_generic(const float *__restrict__ in, const float *__restrict__ dout, DwOut dwo,
                  const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
                  int in_col, int Ci, int Co, int chunk) {
   const int k = blockIdx.y;
@@ -2648,7 +2681,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += (p + u < p1) ? x[u] * d[u] : 0.f;
     }
-    unsafeAtomicAdd(dW + ((int64_t)k * Ci + ci) * Co + co, acc);
+    dwo.add(blockIdx.x, ((int64_t)k * Ci + ci) * Co + co, acc);
   }
 }
 
@@ -3097,13 +3130,57 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
   return 0;
 }
 
+// slots of the deterministic workspace = workgroups along the pair dimension of the kernel scn_conv_dweight picks
+static int64_t dw_slots(int K, int64_t stride, int64_t n_dout, int Ci, int Co, bool has_bases, int64_t n_in) {
+  const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 32) || n_dout * Co * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
+                    n_dout >= (1 << 24) || stride >= (1 << 28);
+  if (Ci % 32 == 0 && Co % 32 == 0 && !huge) {
+    int per = (int)(((stride + g_dw_slices - 1) / g_dw_slices + 63) / 64 * 64);
+    if (per < 2048) per = 2048;
+    if (per > 16384) per = 16384;
+    return (stride + per - 1) / per;
+  }
+  if (Ci >= 1 && Ci <= 4 && has_bases && n_dout > 0) {
+    const int64_t n_gran = (n_dout + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE;
+    return n_gran < 1024 ? n_gran : 1024;
+  }
+  if (Ci >= 1 && Ci <= 4) return 4 * ((stride + 2047) / 2048);
+  return (stride + 255) / 256;
+}
+
+size_t scn_conv_dweight_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_dout, int Ci, int Co, int has_bases) {
+  if (K < 1 || stride <= 0 || Ci <= 0 || Co <= 0) return 0;
+  return (size_t)dw_slots(K, stride, n_dout, Ci, Co, has_bases != 0, n_in) * (size_t)K * Ci * Co * 4;
+}
+
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, const int32_t *bases, int K, int64_t stride, int in_col, int out_col,
-                     int64_t n_in, int64_t n_dout, int Ci, int Co, void *stream_) {
+                     int64_t n_in, int64_t n_dout, int Ci, int Co, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_dweight: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_dweight: in_col/out_col must be 0/1 or 1/0");
   if (stride <= 0) return 0;
+  // deterministic mode: per-workgroup partial sums in the (zeroed) workspace, added to dW in a fixed order afterwards
+  const int64_t elems = (int64_t)K * Ci * Co;
+  const int64_t nslots = workspace ? dw_slots(K, stride, n_dout, Ci, Co, bases != nullptr, n_in) : 0;
+  if (workspace) {
+    SCN_REQUIRE(workspace_bytes >= (size_t)nslots * (size_t)elems * 4, "scn_conv_dweight: workspace smaller than scn_conv_dweight_workspace_bytes()");
+    SCN_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)nslots * (size_t)elems * 4, stream));
+  }
+  const DwOut dwo{dW, (float *)workspace, elems};
+  auto finish = [&]() -> int {
+    if (workspace) {
+      if (elems % 4 == 0) {
+        int64_t g = (elems / 4 + 255) / 256;
+        if (g > 4096) g = 4096;
+        k_dw_reduce<<<(unsigned)g, 256, 0, stream>>>((const float *)workspace, dW, elems / 4, (int)nslots);
+      } else {
+        k_dw_reduce1<<<(unsigned)((elems + 255) / 256), 256, 0, stream>>>((const float *)workspace, dW, elems, (int)nslots);
+      }
+      SCN_CHECK_LAUNCH();
+    }
+    return 0;
+  };
   // (k_dw_tile: 32-bit byte offsets, row numbers through v_mad_u32_u24, 31-bit byte offsets into one rule list)
   const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 32) || n_dout * Co * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
                     n_dout >= (1 << 24) || stride >= (1 << 28);
@@ -3120,58 +3197,58 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
       const unsigned nblk = (unsigned)(gx * K * (Ci / 64) * (Co / 64));
       if (g_dw_direct && g_dw_dbg == 0) {
         if (in_col)
-          k_dw_direct<1><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, Ci, Co, gx, in_bytes, do_bytes, K);
+          k_dw_direct<1><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, Ci, Co, gx, in_bytes, do_bytes, K);
         else
-          k_dw_direct<0><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, Ci, Co, gx, in_bytes, do_bytes, K);
+          k_dw_direct<0><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, Ci, Co, gx, in_bytes, do_bytes, K);
         SCN_CHECK_LAUNCH();
-        return 0;
+        return finish();
       }
 #ifdef SCN_TUNING
       if (g_dw_dbg == 100)  // A/B: 32 pairs per step
-        k_dw_tile<2, 2, 32><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+        k_dw_tile<2, 2, 32><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
       else if (g_dw_dbg == 103)  // timing only: every row load reads row 0 (no gather traffic)
-        k_dw_tile<2, 2, 64, 1><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+        k_dw_tile<2, 2, 64, 1><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
       else if (g_dw_dbg == 101)
-        k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col + 2, Ci, Co, gx, in_bytes, do_bytes, -K);
+        k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col + 2, Ci, Co, gx, in_bytes, do_bytes, -K);
       else
 #endif
-        k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+        k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
     } else {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 32) * (Co / 32));
-      k_dw_tile<1, 1, 64><<<nblk, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+      k_dw_tile<1, 1, 64><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
     }
     SCN_CHECK_LAUNCH();
-    return 0;
+    return finish();
   }
   if (Ci >= 1 && Ci <= 4 && bases != nullptr && n_dout > 0) {
     const int n_gran = (int)((n_dout + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
     dim3 grid((unsigned)(n_gran < 1024 ? n_gran : 1024), (unsigned)((Co + 63) / 64));
     switch (Ci) {
-      case 1: k_dw_rows<1><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
-      case 2: k_dw_rows<2><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
-      case 3: k_dw_rows<3><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
-      default: k_dw_rows<4><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co);
+      case 1: k_dw_rows<1><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+      case 2: k_dw_rows<2><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+      case 3: k_dw_rows<3><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+      default: k_dw_rows<4><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co);
     }
     SCN_CHECK_LAUNCH();
-    return 0;
+    return finish();
   }
   if (Ci >= 1 && Ci <= 4) {
     const int chunk = 2048;
     dim3 grid((unsigned)((stride + chunk - 1) / chunk), K);
     switch (Ci) {
-      case 1: k_dw_narrow<1><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
-      case 2: k_dw_narrow<2><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
-      case 3: k_dw_narrow<3><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
-      default: k_dw_narrow<4><<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Co, chunk);
+      case 1: k_dw_narrow<1><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
+      case 2: k_dw_narrow<2><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
+      case 3: k_dw_narrow<3><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Co, chunk); break;
+      default: k_dw_narrow<4><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Co, chunk);
     }
     SCN_CHECK_LAUNCH();
-    return 0;
+    return finish();
   }
   const int chunk = 256;
   dim3 grid((unsigned)((stride + chunk - 1) / chunk), K);
-  k_dw_generic<<<grid, 256, 0, stream>>>(in, dout, dW, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
+  k_dw_generic<<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, chunk);
   SCN_CHECK_LAUNCH();
-  return 0;
+  return finish();
 }
 
 }  // extern "C"

@@ -152,3 +152,47 @@ def test_colstats_follow_the_features_assignment(gpu):
     with torch.no_grad():
         x2.features.mul_(3.0)  # in place: version counter
     assert x2.get_colstats() is None
+
+
+def test_deterministic_mode_train_steps_are_bitwise_equal(gpu):
+    """SCN.DETERMINISTIC_DW: every dWeight launch adds its workgroups' partial sums in a fixed order (workspace + reduce)
+    instead of with float atomics.  Forward, dInput and batch norm are deterministic anyway, so two runs of three whole
+    train steps (fused Adam included) from the same seed end in bitwise-equal parameters -- which the reference's own
+    backward pass cannot do (float atomics, sparseconvnet/SCN/CUDA/Convolution.cu:749) -- and the gradients equal the default
+    mode's at 1e-5.  m64 levels 0-1 at 2 x 40k sites (k_dw_tile over 64-plane blocks, the stem's k_dw_rows, NiN) and
+    m16 (the 32-plane and generic fallbacks)."""
+    import occuseg_amd
+    from occuseg_amd import SCN, dp, scenes
+    scn = occuseg_amd.install()
+
+    def run(m, levels, sites, deterministic, steps=3):
+        SCN.DETERMINISTIC_DW = deterministic
+        torch.manual_seed(77)
+        net = _net(scn, m, levels).to(gpu)
+        coords, feats = scenes.batch([1000, 1001], target_sites=sites)
+        batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
+        bucket = dp.FlatGradBucket(net.parameters())
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+        first = None
+        try:
+            for _ in range(steps):
+                bucket.zero()
+                net(batch).sum().backward()
+                bucket.all_reduce_mean()
+                if first is None:
+                    first = bucket.flat.clone()
+                opt.step()
+        finally:
+            bucket.close()
+        return first, [p.detach().clone() for p in net.parameters()]
+
+    try:
+        for m, levels, sites in ((64, 2, 40000), (16, 3, 6000)):
+            g1, p1 = run(m, levels, sites, True)
+            g2, p2 = run(m, levels, sites, True)
+            assert torch.equal(g1, g2), "first-step gradients differ between two deterministic runs (m%d)" % m
+            assert all(torch.equal(a, b) for a, b in zip(p1, p2)), "parameters after 3 steps differ (m%d)" % m
+            g0, _ = run(m, levels, sites, False, steps=1)
+            assert_close(g1.cpu().numpy(), g0.cpu().numpy(), "deterministic against atomic gradients", rel=1e-5)
+    finally:
+        SCN.DETERMINISTIC_DW = False
