@@ -33,7 +33,7 @@ import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def build_net(scn, m):
@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--no-dw-side-stream", action="store_true",
                     help="keep the dWeight kernels on the main stream in every step (kernel durations in a profile of this "
                          "command are then exclusive ones, as on the steps whose launches carry events)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="SCN.DETERMINISTIC_DW: dWeight partial sums added in a fixed order (bitwise reproducible gradients)")
     ap.add_argument("--same-batch", action="store_true", help="replay ONE batch (round-1 behaviour) instead of alternating two")
     ap.add_argument("--dump-launches", default=None, help="write per-launch timings (kernel, shape, ms) to this JSON file")
     args = ap.parse_args()
@@ -213,6 +215,7 @@ def main():
     import occuseg_amd
     from occuseg_amd import SCN, dp, scenes
     scn = occuseg_amd.install()
+    SCN.DETERMINISTIC_DW = bool(args.deterministic)
 
     torch.manual_seed(0)  # identical replicas
     net = build_net(scn, args.m).to(dev)
@@ -277,6 +280,7 @@ def main():
     sites_done = 0
     first = counter[0]
     barrier()
+    wpack_before = dict(SCN.WPACK_STATS)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -292,6 +296,7 @@ def main():
     SCN.DW_SIDE_STREAM = False  # (the extra step below measures exclusive durations too)
     barrier()
     dt = time.perf_counter() - t0
+    wpack_after = dict(SCN.WPACK_STATS)
     # the extra, untimed step (every rank runs it: it holds collectives): events on batch norm, rule build, io launches
     SCN.PROFILE_KINDS = ("bn", "rules", "io")
     SCN.PROFILE = prof_extra if rank == 0 else None
@@ -387,10 +392,10 @@ def main():
                 tj = json.load(open(TRAFFIC_FILE))
                 if tj.get("source_hash") == source_hash():
                     traffic = tj.get(dom or "", {}).get("hbm_bytes_per_launch")
-                    traffic_note = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
+                    traffic_note = ("profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
                                     "separate passes; FETCH_SIZE x2 per the gfx950 note), same kernel sources")
                 else:
-                    traffic_note = "profiles/r02_traffic.json was measured on other kernel sources: refused"
+                    traffic_note = "profiles/r03_traffic.json was measured on other kernel sources: refused"
             except (OSError, ValueError):
                 traffic = None
         roof = None
@@ -420,6 +425,9 @@ def main():
             "value": total_sites / dt, "unit": "active-voxels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_min": step_ms[0],
+            # (SURVEY.md section 8d asks for the median of the per-step times; `value` is the driver's contract: all units
+            #  over the whole timed region, max over ranks)
+            "value_from_median": (total_sites / args.steps) / (step_ms[len(step_ms) // 2] * 1e-3) if world == 1 else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: ScanNet m%d UNet train step (fwd+bwd+Adam), "
@@ -432,6 +440,10 @@ def main():
                        "backend": backend if world > 1 else None,
                        "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "rulebook_prefetch": bool(args.prefetch), "dweight_side_stream": dw_side,
+                       "deterministic_dweight": bool(SCN.DETERMINISTIC_DW),
+                       "weight_repack": "every (weight, orientation) pair re-laid out once per step in one launch "
+                                        "(SCN weight epochs): %d multi-tensor launches, %d single ones in the timed region"
+                                        % (wpack_after["batch"] - wpack_before["batch"], wpack_after["single"] - wpack_before["single"]),
                        "source_hash": source_hash()},
             "roofline": roof, "kernels": kernels, "peaks_measured": peaks,
         }

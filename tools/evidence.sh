@@ -32,8 +32,14 @@ python3 tools/pmc_summary.py $E/pmc_tile4 k_dw_tile > $E/pmc_dw_tile.txt 2>&1
 # 6. what an instruction beside an f32 MFMA costs; occupancy probe of k_conv_tile4; k_conv_tile6 against k_conv_tile4
 python3 tools/mfma_probe.py > $E/mfma_probe.txt 2>&1
 python3 tools/bench_conv.py --levels 0,1 --variants 4 --extra-lds 0,2000,15200 > $E/occupancy_probe.txt 2>&1
-python3 tools/ab_tile6.py --rounds 2 > $E/ab_tile6.txt 2>&1
 python3 tools/ab_step.py DW_SIDE_STREAM=0,1 > $E/ab_dw_side_stream.txt 2>&1
+python3 tools/ab_step.py BN_BWD_STATS_FROM_CONV=0,1 > $E/ab_bn_bwd_stats_from_conv.txt 2>&1
+python3 tools/ab_step.py containers.GRAD_JOIN=0,1 > $E/ab_grad_join.txt 2>&1
+python3 tools/ab_step.py DETERMINISTIC_DW=0,1 > $E/ab_deterministic_dw.txt 2>&1
+python3 tools/ab_step.py tune12=0,1 > $E/ab_dw_direct.txt 2>&1
+python3 tools/ab_tile_order.py > $E/ab_tile_order_layers.txt 2>&1
+python3 tools/cold_cache.py > $E/cold_cache.txt 2>&1
+python3 tools/run_configs.py > $E/configs_cfg2_cfg5.json 2> $E/configs.err
 # keep the merge small: raw traces stay on the box
 find $E -name "*.db" -delete
 find $E -name "*kernel_trace.csv" -size +2M -delete
