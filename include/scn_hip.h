@@ -157,10 +157,11 @@ int scn_tile_order(const int32_t *bases, int K, int64_t n_out, int light_permill
  *   the big launches (k_conv_tile4) start them.  A caller that knows the pair count of every tile (from `bases`) puts the
  *   light tiles last, so that the last round of workgroups -- the tail in which the chip runs dry -- is short.  Results do
  *   not depend on it (every tile is computed by one workgroup in a fixed summation order).
- *   workspace: scn_conv_workspace_bytes(...) bytes (0 for most launches).  Launches with few output tiles (the coarse
- *   UNet levels) split their offsets over several workgroups per tile; the partial tiles go to the workspace and are
- *   added in a fixed order, so every launch is bitwise reproducible run to run (the reference scatters with float
- *   atomics, sparseconvnet/SCN/CUDA/Convolution.cu:529,1147). */
+ *   workspace: scn_conv_workspace_bytes(...) bytes.  Launches with few output tiles (the coarse UNet levels) split their
+ *   offsets over several workgroups per tile; the partial tiles go to the workspace and are added in a fixed order, so
+ *   every launch is bitwise reproducible run to run (the reference scatters with float atomics,
+ *   sparseconvnet/SCN/CUDA/Convolution.cu:529,1147).  The big launches (k_conv_tile4) keep the pass table of every
+ *   workgroup there (<= 5.3 KB each) and walk it with scalar loads; without a workspace they keep it in LDS. */
 size_t scn_conv_wpack_bytes(int K, int Ci, int Co);
 size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique);
 /* which kernel scn_conv_forward runs for this shape (for per-kernel reporting): 100 * kind + offset split, kind

@@ -745,17 +745,21 @@ __global__ void __launch_bounds__(256)
 // them in FRONT of the wait), nothing but row registers (fixed variables of a 3-way unrolled loop) is in flight over
 // the back edge, and tools/check_asm_loads.py (run by build.py) proves on the emitted assembly that no instruction
 // touches a register with a load in flight.
-template <int DBG = 0, int INCOL = -1>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
+// GT = 1: the pass table lives in GLOBAL memory (a 64-byte aligned region per workgroup of the launcher's workspace) and is
+// read with scalar loads: an entry in LDS costs a v_mov (address) + ds_read + two v_readfirstlane per pass -- three
+// vector-ALU instructions at 8-12 matrix-pipe cycles each -- a scalar load none.
+template <int DBG = 0, int INCOL = -1, int GT = 0>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (<= 256 registers: hipcc then keeps the accumulators in VGPRs, no v_accvgpr_read)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
-                 unsigned in_bytes, unsigned wp_bytes, int ksplit, const int32_t *__restrict__ tile_order) {
+                 unsigned in_bytes, unsigned wp_bytes, int ksplit, const int32_t *__restrict__ tile_order,
+                 unsigned long long *__restrict__ gtab = nullptr, int gstride = 0) {
   constexpr int M = 128, COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
   constexpr int TMAX = KMAX * 4 * SCN_TILE4_MAX_CHUNKS + 8;  // passes per tile: <= 4 per (offset, chunk); + sentinels
   __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
-  __shared__ __attribute__((aligned(8))) unsigned ptab[TMAX][2];  // {byte offset of the pass's first pair in `rules`,
+  __shared__ __attribute__((aligned(8))) unsigned ptab[GT ? 1 : TMAX][2];  // {byte offset of the pass's first pair in `rules`,
                                                                   //  pairs left in the list | chunk<<8 | k<<12 | first<<20}
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -850,18 +854,29 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int total = __shfl(pos, 63);
     pos -= npl * nch;
     const unsigned first = (unsigned)(((int64_t)tid * stride + s) * 8);
+    uint2 *gt = GT ? (uint2 *)(gtab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (size_t)gstride) : nullptr;
     for (int chn = 0; chn < nch; ++chn)
       for (int j = 0; j < npl; ++j) {
-        ptab[pos][0] = first + (unsigned)j * 256u;
-        ptab[pos][1] = (unsigned)(c - 32 * j) | (unsigned)chn << 8 | (unsigned)tid << 12 | (j == 0 ? 1u << 20 : 0u);
+        const unsigned e0 = first + (unsigned)j * 256u;
+        const unsigned e1 = (unsigned)(c - 32 * j) | (unsigned)chn << 8 | (unsigned)tid << 12 | (j == 0 ? 1u << 20 : 0u);
+        if (GT) gt[pos] = make_uint2(e0, e1);
+        else { ptab[pos][0] = e0; ptab[pos][1] = e1; }
         ++pos;
       }
     if (tid < 8) {  // sentinels: empty passes
-      ptab[total + tid][0] = 0u;
-      ptab[total + tid][1] = 0u;
+      if (GT) gt[total + tid] = make_uint2(0u, 0u);
+      else { ptab[total + tid][0] = 0u; ptab[total + tid][1] = 0u; }
     }
+    if (GT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the table is in L2 before the barrier lets anybody read it
   }
   __syncthreads();  // the only barrier
+  if (GT) asm volatile("s_dcache_inv" ::: "memory");  // (the scalar cache is not coherent with this kernel's vector stores)
+  unsigned long long gt_s = 0;  // this workgroup's region, in a scalar register pair
+  if (GT) {
+    const unsigned long long a = (unsigned long long)(gtab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (size_t)gstride);
+    gt_s = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32;
+  }
   auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   // offset of the loads a pass does not need (absent second group, passes past the end): the first bytes of the buffer
   // (always valid; what they fetch is multiplied by nothing or lands in the sink row).  Pointing them past the end of the
@@ -869,6 +884,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   constexpr unsigned OOB = (DBG & 8192) ? 0x80000000u : 0u;
   struct Ent { unsigned base, meta; };  // meta & 255: pairs left (0: no such pass)
   auto entry = [&](int p) __attribute__((always_inline)) {
+    if (GT) {
+      unsigned long long v;
+      const int off = uni(p) * 8;
+      asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(gt_s), "s"(off) : "memory");
+      return Ent{(unsigned)v, (unsigned)(v >> 32)};
+    }
     const uint2 v = *(const uint2 *)ptab[p];
     return Ent{(unsigned)uni((int)v.x), (unsigned)uni((int)v.y)};
   };
@@ -1023,13 +1044,16 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       index_offsets(E3, ioff);
     }
 
+    unsigned wlane16 = (DBG & 8) ? OOB : (unsigned)lane * 16u;
+    asm volatile("" : "+v"(wlane16));  // (one register for the whole loop, not rematerialised)
     auto body = [&](floatx4 (&rc)[2][NS16], floatx4 (&rm)[2][NS16], floatx4 (&rn)[2][NS16], int (&oc)[2], int (&on)[2]) __attribute__((always_inline)) {
       const bool two = rem(E0) > 16;
       const unsigned m0 = lane_mask(rem(E0), 0), m1 = lane_mask(rem(E0), 1);
       floatx4 old[2][COS];
       Ent E4 = E3;
+      unsigned long long eraw = 0;
       int w_so[NS16], rso = 0;
-      unsigned w_off = OOB;
+      unsigned w_off_unused = OOB;
       bool w_new = false;
       // (the accumulators are not zeroed: the first MFMA of a chain takes C = 0; those of an absent second group keep what
       //  they held, which goes to the sink row)
@@ -1056,13 +1080,18 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         } else if (m == 2) {     // weights of pass p+1 only when it starts a new (offset, chunk) phase: they are OLDER than
           // the row loads, so the vmcnt(8) below is right either way.  (The condition is re-read from the scalar table entry
           // every time: kept in a bool across the pieces, hipcc parks it in a VGPR -- v_cndmask + v_cmp per pass.)
-          if (next_is_new()) weight_scalars(E1, w_so, w_off, w_new);
+          if (next_is_new()) weight_scalars(E1, w_so, w_off_unused, w_new);
         } else if (m >= 3 && m <= 6) {
-          if (next_is_new()) load_weights(m - 3, w_off, w_so[m - 3], wn);
+          // (the per-lane offset is loop invariant: as a variable set inside the branch above it cost a v_mov per pass)
+          if (next_is_new()) load_weights(m - 3, wlane16, w_so[m - 3], wn);
         } else if (m == 7) {     // group 1 of the previous pass -> output tile: read its rows ...
           if (!(DBG & 1)) tile_read2(op1, old[1]);
         } else if (m == 8) {     // indices of pass p+3 (pr was consumed by pieces 0-1)
           load_idx(E3, ioff, pr);
+          if (GT) {  // table entry p+4 requested here, picked up in piece 15 (a scalar load: nothing else names `eraw` meanwhile)
+            const int eoff = uni(pnext) * 8;
+            asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(eraw) : "s"(gt_s), "s"(eoff) : "memory");
+          }
         } else if (m >= 9 && m <= 12) {  // rows of pass p+2: the long-latency gathers, in flight until the end of pass p+1
           const int i = (m - 9) >> 1;
           if ((m - 9) & 1) {
@@ -1078,7 +1107,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         } else if (m == 14) {    // group 0 of THIS pass: read its rows (added and written beside the second group's MFMAs)
           if (!(DBG & 1)) tile_read2(oc[0], old[0]);
         } else if (m == 15) {    // table entry p+4
-          E4 = entry(pnext);
+          if (GT) {
+            unsigned long long ev;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, %1" : "=s"(ev) : "s"(eraw) : "memory");
+            E4 = Ent{(unsigned)ev, (unsigned)(ev >> 32)};
+          } else {
+            E4 = entry(pnext);
+          }
         }
       };
       if (!(DBG & 16)) {
@@ -2714,6 +2749,7 @@ SCN_KNOB g_conv_extra_lds = 0;  // tuning key 10: bytes of unused dynamic LDS ad
 SCN_KNOB g_dw_direct = 0;       // tuning key 12: 1 = k_dw_direct (no LDS staging) for 64-plane blocks.  Round 3: correct (all dW parity
                                 // tests), 107-130 against 105-126 TFLOP/s on the six big layer shapes in isolation, but the train
                                 // step is 1.8 ms SLOWER with it (50.3 against 48.4 ms, tools/ab_step.py tune12=0,1): off
+SCN_KNOB g_conv_gtab = 1;       // tuning key 13: 0 = k_conv_tile4 keeps its pass table in LDS (A/B)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 // Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.
@@ -2845,6 +2881,10 @@ constexpr size_t tile6_lds_bytes() { return (size_t)(M * 68 + (KMAX * (M / 32) *
 // rows per tile of a kind-4 launch
 static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ? 96 : 128; }
 
+// entries (8 bytes each) of one workgroup's region of k_conv_tile4's global pass table: <= 4 passes per (offset, chunk), 8
+// sentinels, rounded to whole 64-byte lines (a scalar-cache line never holds entries of two workgroups)
+static int tile4_gtab_stride(int K, int Ci) { return (K * 4 * (Ci / 64) + 8 + 7) / 8 * 8; }
+
 static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, StatsArg colstats, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
                         int Ci, int Co, int ksplit, float *part, const int32_t *tile_order, hipStream_t stream) {
@@ -2854,6 +2894,9 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   const int ncb = Co / 64;
   const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
   float *dst4 = ksplit > 1 ? part : out;
+  // unsplit launches: the workspace holds the pass tables (scn_conv_workspace_bytes)
+  unsigned long long *gtab = (ksplit == 1 && g_conv_gtab) ? (unsigned long long *)part : nullptr;
+  const int gstride = tile4_gtab_stride(K, Ci);
   const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #ifdef SCN_TUNING  // k_conv_tile6: experimental (tools/ab_tile6.py), not faster than k_conv_tile4
   if (M != 128 || g_conv_tile6 == 128) {
@@ -2919,7 +2962,13 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 4097: SCN_LAUNCH_TILE4(4096 + 11); break;  // ... and no weight loads
     case 8192: SCN_LAUNCH_TILE4(8192); break;  // A/B: unneeded loads point out of range instead of reading offset 0
     default:
-      if (in_col)
+      if (gtab != nullptr && in_col)
+        k_conv_tile4<0, 1, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
+                                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order, gtab, gstride);
+      else if (gtab != nullptr)
+        k_conv_tile4<0, 0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
+                                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order, gtab, gstride);
+      else if (in_col)
         k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
                                                                               stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
       else
@@ -2927,7 +2976,14 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
                                                                               stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
   }
 #else
-  if (in_col)
+  if (gtab != nullptr) {  // pass table in global memory, read with scalar loads (see k_conv_tile4's GT)
+    if (in_col)
+      k_conv_tile4<0, 1, 1><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
+                                                       stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order, gtab, gstride);
+    else
+      k_conv_tile4<0, 0, 1><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
+                                                       stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order, gtab, gstride);
+  } else if (in_col)
     k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
                                                                           stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
   else
@@ -2985,6 +3041,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 9) { g_conv_tile5 = value; return 0; }
   if (key == 11 && (value == 0 || value == 96 || value == 128)) { g_conv_tile6 = value; return 0; }
   if (key == 12) { g_dw_direct = value; return 0; }
+  if (key == 13) { g_conv_gtab = value; return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
@@ -2995,6 +3052,8 @@ size_t scn_conv_wpack_bytes(int K, int Ci, int Co) { return (size_t)K * Ci * Co 
 size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique) {
   if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
   const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
+  if (p.kind == 4 && p.ksplit == 1)  // k_conv_tile4's pass tables, one region per workgroup
+    return (size_t)((n_out + 127) / 128) * (size_t)(Co / 64) * (size_t)tile4_gtab_stride(K, Ci) * 8;
   return p.ksplit > 1 ? (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4 : 0;
 }
 
@@ -3107,6 +3166,9 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
       SCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4,
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     float *part = (float *)workspace;
+    if (p.kind == 4 && p.ksplit == 1 && workspace != nullptr)
+      SCN_REQUIRE(workspace_bytes >= (size_t)((n_out + 127) / 128) * (size_t)(Co / 64) * (size_t)tile4_gtab_stride(K, Ci) * 8,
+                  "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     if (p.kind == 4)
       return launch_tile4(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part,
                           p.ksplit == 1 ? tile_order : nullptr, stream);
