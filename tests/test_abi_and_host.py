@@ -27,8 +27,10 @@ def test_library_exports_every_declared_symbol():
     # tuning / ablation entry points are not part of the product library (only of libscn_hip_tuning.so)
     assert not hasattr(lib, "scn_set_tuning") and not hasattr(lib, "scn_debug_stamps")
     assert os.path.exists(_lib.TUNING_LIB_PATH)
-    # launches with many output tiles need no workspace; a coarse level (few tiles) splits its offsets 9- or 27-fold
-    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64, 0) == 0
+    # big launches (k_conv_tile4) keep one pass table per workgroup in the workspace: 4688 tiles x 116 entries -> 120 entries
+    # (whole 64-byte lines) x 8 bytes; a coarse level (few tiles) splits its offsets 9- or 27-fold
+    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64, 0) == 4688 * 120 * 8
+    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 20, 12, 0) == 0  # generic kernel: none
     ws = lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384, 0)
     assert ws % (2000 * 384 * 4) == 0 and ws // (2000 * 384 * 4) in (3, 9, 27)
     # size queries are host-only arithmetic: safe without a GPU
