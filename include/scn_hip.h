@@ -153,6 +153,11 @@ int scn_tile_order(const int32_t *bases, int K, int64_t n_out, int light_permill
  *   wpack_ready = 0: scn_conv_forward packs (W, w_transposed, w_reverse) into it first; 1: the caller already ran
  *   scn_weight_pack for exactly this (W contents, w_transposed, w_reverse) -- weights change once per optimizer
  *   step, not once per call -- and W is not read (planes that are not multiples of 16 always read W itself).
+ *   ld_in / ld_out (0 = contiguous): leading dimension in floats of `in` / `out` when they are column slices of wider
+ *   row-major tensors -- the two halves of a concatenation (sparseconvnet/tables.py:13-55, JoinTable): a deconvolution then
+ *   writes its result straight into the right half of the joined tensor and its backward pass reads the right half of the
+ *   joined gradient in place.  ld_in: planes that are multiples of 16 (the pipelined kernels); ld_out: out_unique launches with
+ *   planes % 64 == 0 only (scn_conv_plan = 5xx).  residual / colstats / bn_bwd->x stay contiguous [n_out, Co].
  *   tile_order (may be NULL): int32 [ceil(n_out / 128)], a permutation of the 128-row output tiles = the order in which
  *   the big launches (k_conv_tile4) start them.  A caller that knows the pair count of every tile (from `bases`) puts the
  *   light tiles last, so that the last round of workgroups -- the tail in which the chip runs dry -- is short.  Results do
@@ -203,14 +208,15 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
                      const int32_t *rules,
                      const int32_t *bases, const int32_t *tile_order, const int32_t *counts,
                      int K, int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in,
-                     int64_t n_out, int Ci, int Co, void *wpack, int wpack_ready, void *workspace,
-                     size_t workspace_bytes, void *stream);
+                     int64_t n_out, int Ci, int Co, int64_t ld_in, int64_t ld_out, void *wpack, int wpack_ready,
+                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* scn_set_tuning / scn_debug_stamps (kernel-variant selection, timing-only ablation builds, cycle stamps) are NOT
  * part of this ABI: they exist only in libscn_hip_tuning.so (same sources compiled with -DSCN_TUNING), which
  * tools/ and the variant-equivalence test load explicitly. */
 
-/* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller,
+/* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller; ld_in / ld_dout: leading dimensions of
+ * `in` / `dout` when they are column slices of wider tensors, 0 = contiguous, planes % 32 == 0 then;
  * as the reference's callers do: sparseconvnet/submanifoldConvolution.py:114-115).
  * Replaces dConvolution_KMxKN_backward_dW_* (sparseconvnet/SCN/CUDA/Convolution.cu:265-442,:695-753).
  * bases: scn_tile_bases(.., out_col, n_dout) or NULL; with it, narrow inputs (Ci <= 4: the 3 -> m stem) are processed
@@ -222,8 +228,8 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
 size_t scn_conv_dweight_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_dout, int Ci, int Co, int has_bases);
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, const int32_t *bases, int K, int64_t stride, int in_col,
-                     int out_col, int64_t n_in, int64_t n_dout, int Ci, int Co, void *workspace,
-                     size_t workspace_bytes, void *stream);
+                     int out_col, int64_t n_in, int64_t n_dout, int Ci, int Co, int64_t ld_in, int64_t ld_dout,
+                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* column sums: d_bias[c] = sum_rows dOut[r][c] (sparseconvnet/SCN/CUDA/Convolution.cu:52-75) */
 int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream);
@@ -263,13 +269,13 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
 /* The SCN_BN_MASK_FROM_X backward pass with two things handed in (both may be NULL / 0):
  *   partial [nblk][2][C]: the two reductions, emitted by the kernel that produced d_out (scn_conv_forward's bn_bwd):
  *   the statistics pass is skipped, d_out and x are read once (12 instead of 20 bytes per element);
- *   d_x_add [N, C]: added to the result, d_x = (batch norm's d_input) + d_x_add -- the gradient arriving at x along
+ *   d_x_add [N, C] (leading dimension ld_add floats, 0 = C: it may be the left half of a joined gradient): added to the result, d_x = (batch norm's d_input) + d_x_add -- the gradient arriving at x along
  *   another path (the shortcut of a residual block), which autograd would otherwise add with a kernel of its own.
  * flags: SCN_BN_ACCUMULATE_DPARAMS only. */
 int scn_bn_backward_ext(const float *x, float *d_x, const float *d_out, const float *save_mean,
                         const float *save_invstd, const float *weight, const float *bias, float *d_weight,
                         float *d_bias, double leakiness, int64_t N, int C, int flags, void *temp,
-                        const float *partial, int nblk, const float *d_x_add, void *stream);
+                        const float *partial, int nblk, const float *d_x_add, int64_t ld_add, void *stream);
 
 /* ------------------------------------------------------ input / output ---
  * Replaces InputLayer_fp/bp (sparseconvnet/SCN/CUDA/IOLayers.cu:17-76) and the four wrappers of

@@ -676,8 +676,14 @@ class BnLink(object):
 BN_BWD_STATS_FROM_CONV = True  # A/B switch
 
 
+def _row_slice(t):
+    """2-D, unit stride along the planes, 16-byte aligned rows: a column slice of a wider row-major float tensor"""
+    return (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.size(1) and t.stride(0) % 4 == 0
+            and t.data_ptr() % 16 == 0 and t.size(0) > 0)
+
+
 def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False, residual=None,
-          stats_out=None, bn_link=None):
+          stats_out=None, bn_link=None, out_view=None):
     """out = gather-mm-scatter over rb; weight is the module's [K, a, b] tensor, used as [K, Ci, Co]
     (forward) or, with w_transposed, as its per-offset transpose (dInput).  When every output row appears in exactly
     one pair of the rulebook (rb.unique_col == out_col: the fine column of a strided rulebook, the identity list)
@@ -686,13 +692,28 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     K = weight.size(0)
     Ci, Co = (weight.size(2), weight.size(1)) if w_transposed else (weight.size(1), weight.size(2))
     assert K == rb.K, (K, rb.K)
-    assert inp.is_contiguous() and weight.is_contiguous() and inp.size(1) == Ci
-    out.resize_(n_out, Co)
+    assert weight.is_contiguous() and inp.size(1) == Ci
+    uniq = int(rb.unique_col is not None and (rb.unique_col == out_col or rb.unique_col == 2))
+    kind = lib.scn_conv_plan(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq) // 100
+    # `inp` may be a column slice of a wider row-major tensor (the right half of a joined gradient): the pipelined kernels
+    # read it in place through its leading dimension; `out_view`: a preallocated slice the result is written into (the
+    # right half of a joined tensor; the one-contribution-per-row kernel only)
+    ld_in = 0
+    if not inp.is_contiguous():
+        if _row_slice(inp) and kind in (2, 4, 5):
+            ld_in = inp.stride(0)
+        else:
+            inp = inp.contiguous()
+    ld_out = 0
+    if out_view is not None:
+        assert kind == 5 and _row_slice(out_view) and tuple(out_view.shape) == (n_out, Co), (kind, out_view.shape)
+        out, ld_out = out_view, out_view.stride(0)
+    else:
+        out.resize_(n_out, Co)
     if residual is not None:
         assert residual.is_contiguous() and tuple(residual.shape) == (n_out, Co) and residual.data_ptr() != out.data_ptr()
     wpack, ready = _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co)
     # launches with few output tiles split their offsets over workgroups; partial tiles go through this workspace
-    uniq = int(rb.unique_col is not None and (rb.unique_col == out_col or rb.unique_col == 2))
     ws_bytes = lib.scn_conv_workspace_bytes(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=inp.device) if ws_bytes else None
     # column statistics of the result for the batch norm that consumes it (stats_out: a list that receives the tensor)
@@ -714,7 +735,7 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                                ptr(bias) if bias is not None and bias.numel() else None, ptr(residual), ptr(cstats),
                                ctypes.byref(bnb) if bnb is not None else None, ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.order.get(out_col)), ptr(rb.counts), K, rb.stride,
                                in_col, out_col, uniq,
-                               inp.size(0), n_out, Ci, Co, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
+                               inp.size(0), n_out, Ci, Co, ld_in, ld_out, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
     if bn_link is not None:
         bn_link.offer(out, cstats if bnb is not None else None)
     # algorithmic work of one launch: flops = 2 R Ci Co;
@@ -836,7 +857,14 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
     bn_link: see BnLink; d_in_add: a tensor added to d_in inside the dInput kernel (its `residual`)."""
     lib = _lib_()
     K, Ci, Co = weight.shape
-    d_out = d_out.contiguous()
+    # d_out may be a column slice of a wider gradient (the right half of what a JoinTable received): read in place by the
+    # dInput launch (_conv) and, for planes that are multiples of 32, by the dWeight kernel
+    ld_dout = 0
+    if not d_out.is_contiguous():
+        if _row_slice(d_out) and Ci % 32 == 0 and Co % 32 == 0 and not (d_bias is not None and d_bias.numel()):
+            ld_dout = d_out.stride(0)
+        else:
+            d_out = d_out.contiguous()
     _BWD_SEEN[0] = True  # (weight epochs: the next forward-direction call may see updated weights)
 
     def d_input():
@@ -860,7 +888,7 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
             ws, wsb = _dw_workspace(rb, out_col, K, inp.size(0), d_out.size(0), Ci, Co, inp.device)
             check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts),
                                        ptr(rb.bases.get(out_col)), K, rb.stride, in_col, out_col, inp.size(0),
-                                       d_out.size(0), Ci, Co, ptr(ws), wsb, stream()))
+                                       d_out.size(0), Ci, Co, 0, ld_dout, ptr(ws), wsb, stream()))
             R = rb.total_pairs
             _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else "dw_narrow", 2.0 * R * Ci * Co,
                       4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
@@ -995,14 +1023,22 @@ def Convolution_backward(inputSize, outputSize, filterSize, filterStride, m, inp
                    rb, 0, 1, n_in, reverse=False, bn_link=_bn_link)
 
 
+def deconvolution_can_write_a_slice(inputSize, outputSize, filterSize, filterStride, m, nIn, nOut):
+    """True when Deconvolution_updateOutput(..., _out_view) can write its result into a column slice of a wider tensor"""
+    rb = m.getRuleBook(outputSize, inputSize, filterSize, filterStride)
+    uniq = int(rb.unique_col is not None and (rb.unique_col == 0 or rb.unique_col == 2))
+    return _lib_().scn_conv_plan(rb.K, rb.stride, m.getNActive(inputSize), m.getNActive(outputSize), nIn, nOut, uniq) // 100 == 5
+
+
 def Deconvolution_updateOutput(inputSize, outputSize, filterSize, filterStride, m, input_features,
-                               output_features, weight, bias, stats_out=None):
+                               output_features, weight, bias, stats_out=None, _out_view=None):
     """sparseconvnet/SCN/pybind.cpp:82-87 -> sparseconvnet/SCN/CUDA/Deconvolution.cpp:20-49: the conv rulebook
     of (outputSize -> inputSize) with the columns swapped."""
     _need_cuda(input_features, "Deconvolution_updateOutput")
     rb = m.getRuleBook(outputSize, inputSize, filterSize, filterStride)
     n_out = m.getNActive(outputSize)
-    _conv(input_features.contiguous(), output_features, weight, bias, rb, 1, 0, n_out, stats_out=stats_out)
+    _conv(input_features.contiguous(), output_features, weight, bias, rb, 1, 0, n_out, stats_out=stats_out,
+          out_view=_out_view)
     return float(rb.total_pairs) * weight.size(1) * weight.size(2)
 
 
@@ -1072,11 +1108,12 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
         # gradient of input_features added to the result inside the apply pass
         assert _mask_from_x
         assert _partials is None or (_partials.is_contiguous() and tuple(_partials.shape[1:]) == (2, C))
-        assert _d_x_add is None or (_d_x_add.is_contiguous() and tuple(_d_x_add.shape) == (N, C))
+        assert _d_x_add is None or (tuple(_d_x_add.shape) == (N, C) and (_d_x_add.is_contiguous() or _row_slice(_d_x_add)))
         check(_lib_().scn_bn_backward_ext(ptr(x), ptr(d_input_features), ptr(d_output_features), ptr(saveMean),
                                           ptr(saveInvStd), ptr(weight), ptr(bias), ptr(d_weight), ptr(d_bias),
                                           float(leakiness), N, C, 2 if _accumulate else 0, ptr(temp), ptr(_partials),
-                                          _partials.size(0) if _partials is not None else 0, ptr(_d_x_add), stream()))
+                                          _partials.size(0) if _partials is not None else 0, ptr(_d_x_add),
+                                          _d_x_add.stride(0) if _d_x_add is not None else 0, stream()))
         _prof_end(ev, "bn_bwd", 0.0, (12.0 if _partials is not None else 20.0) * N * C + (4.0 * N * C if _d_x_add is not None else 0.0),
                   (N, C, "ext"))
         return
@@ -1191,7 +1228,7 @@ def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weig
         ws, wsb = _dw_workspace(rb, 1, 1, n, n, Ci, Co, input_features.device)
         check(_lib_().scn_conv_dweight(ptr(input_features.contiguous()), ptr(d_output_features.contiguous()),
                                        ptr(d_weight), ptr(rb.rules), ptr(rb.counts), ptr(rb.bases.get(1)), 1, rb.stride,
-                                       0, 1, n, n, Ci, Co, ptr(ws), wsb, stream()))
+                                       0, 1, n, n, Ci, Co, 0, 0, ptr(ws), wsb, stream()))
         _prof_end(ev, "dw_tile", 2.0 * n * Ci * Co, 4.0 * n * (Ci + Co) + 8.0 * n + 4.0 * Ci * Co, (1, n, Ci, Co, 0, 0))
         return
     if n:

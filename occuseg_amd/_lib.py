@@ -39,10 +39,10 @@ SIGNATURES = {
     "scn_weight_pack_batch": (c_int, [_P, c_int, c_int64, _P]),
     "scn_conv_stats_blocks": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
-                                 c_int64, c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
+                                 c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P, c_int, _P, c_size_t, _P]),
     "scn_conv_dweight_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
-    "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, _P,
-                                 c_size_t, _P]),
+    "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64,
+                                 c_int64, _P, c_size_t, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
     "scn_bn_temp_bytes": (c_size_t, [c_int]),
     "scn_bn_forward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_int, c_double,
@@ -50,7 +50,8 @@ SIGNATURES = {
     "scn_bn_forward_ext": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_double, c_int64, c_int, _P,
                                    c_int, ctypes.POINTER(c_int32), ctypes.POINTER(_P), ctypes.POINTER(c_int32), _P]),
     "scn_bn_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P]),
-    "scn_bn_backward_ext": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P, c_int, _P, _P]),
+    "scn_bn_backward_ext": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P, c_int, _P,
+                                    c_int64, _P]),
     "scn_input_forward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_input_backward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_output_forward": (c_int, [_P, _P, _P, c_int64, c_int, _P]),

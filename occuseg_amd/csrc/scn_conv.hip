@@ -38,6 +38,10 @@ struct StatsArg {
   float *out;
   const float *x, *mean, *invstd, *gamma, *beta;
   float leak;
+  // (rides along to every gather-mm kernel:) leading dimensions, in floats, of the launch's `in` and `out` when they are
+  // column slices of wider row-major tensors (0 = contiguous: C_i / C_o).  ldi: k_conv_tile4, k_conv_tile2, k_conv_expand;
+  // ldo: k_conv_expand only (scn_conv_forward checks)
+  int ldi, ldo;
 };
 // per-lane constants of four consecutive planes c .. c+3 and the two sums for one float4 of the result
 struct StatsCols {
@@ -411,7 +415,7 @@ __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per
     for (int j = 0; j < NIDX; ++j) {
       const int r = tid + j * NT;
       if (r < M) {
-        srcbuf[b][(r % RPS) * NSLOT + r / RPS] = (unsigned)(in_col ? pr[j].y : pr[j].x) * (unsigned)(Ci * 4);
+        srcbuf[b][(r % RPS) * NSLOT + r / RPS] = (unsigned)(in_col ? pr[j].y : pr[j].x) * (unsigned)((colstats.ldi ? colstats.ldi : Ci) * 4);
         olbuf[b][r] = (r < c) ? (int)((in_col ? pr[j].x : pr[j].y) - o0) : M;
       }
     }
@@ -772,7 +776,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a_), "s"(b_), "v"(c_));
     return r;
   };
-  const unsigned row_bytes = (unsigned)(Ci * 4), lq16 = (unsigned)(lq * 16), os_u = (unsigned)(OS * 4);
+  const unsigned row_bytes = (unsigned)((colstats.ldi ? colstats.ldi : Ci) * 4), lq16 = (unsigned)(lq * 16), os_u = (unsigned)(OS * 4);
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ru_rsrc =
@@ -2052,7 +2056,7 @@ __global__ void __launch_bounds__(64)
     const int p = p0 + 16 * g + li;
     live[g] = p < cnt;
     const int2 pr = rk[min(p, cnt - 1)];
-    roff[g] = (unsigned)(in_col ? pr.y : pr.x) * (unsigned)(Ci * 4) + (unsigned)(lq * 16);
+    roff[g] = (unsigned)(in_col ? pr.y : pr.x) * (unsigned)((colstats.ldi ? colstats.ldi : Ci) * 4) + (unsigned)(lq * 16);
     orow[g] = in_col ? pr.x : pr.y;
   }
   const int nch = Ci / CK;
@@ -2105,7 +2109,7 @@ __global__ void __launch_bounds__(64)
         floatx4 v = acc[g][q];
         if (bias) v += *(const floatx4 *)(bias + co0 + 16 * q + 4 * lq);
         if (residual) v += *(const floatx4 *)(residual + orow[g] * Co + co0 + 16 * q + 4 * lq);
-        *(floatx4 *)(out + orow[g] * Co + co0 + 16 * q + 4 * lq) = v;
+        *(floatx4 *)(out + orow[g] * (colstats.ldo ? colstats.ldo : Co) + co0 + 16 * q + 4 * lq) = v;
         acc[g][q] = v;
       }
     } else {
@@ -2244,6 +2248,7 @@ __global__ void __launch_bounds__(256)
 struct DwOut {
   float *dW, *part;
   int64_t elems;  // K * Ci * Co
+  int ldi, ldd;   // leading dimensions (floats) of `in` / `dout` when they are column slices of wider tensors (k_dw_tile only)
   __device__ __forceinline__ void add(int64_t slot, int64_t idx, float v) const {
     if (part) part[slot * elems + idx] = v;
     else unsafeAtomicAdd(dW + idx, v);
@@ -2341,7 +2346,7 @@ __global__ void __launch_bounds__(256)
   for (int j = 0; j < NI; ++j) { pio[j] = (unsigned)((tid + j * 256) / (CIB / 4)) * 8u; cio[j] = (unsigned)((tid + j * 256) % (CIB / 4)) * 16u; }
 #pragma unroll
   for (int j = 0; j < ND; ++j) { pdo[j] = (unsigned)((tid + j * 256) / (COB / 4)) * 8u; cdo[j] = (unsigned)((tid + j * 256) % (COB / 4)) * 16u; }
-  const unsigned ci4 = (unsigned)Ci * 4u, co4 = (unsigned)Co * 4u;
+  const unsigned ci4 = (unsigned)dwo.ldi * 4u, co4 = (unsigned)dwo.ldd * 4u;
   auto load_pairs = [&](int pb) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) pi_[j] = __builtin_amdgcn_raw_buffer_load_b32(ru_rsrc, pio[j], pb * 8 + 4 * in_col, 0);
@@ -2477,7 +2482,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
   const __amdgpu_buffer_rsrc_t do_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dout, 0, (int)do_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ru_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)(rules + (int64_t)k * stride), 0, (int)(stride * 8), 0x00020000);
-  const unsigned ci4 = (unsigned)Ci * 4u, co4 = (unsigned)Co * 4u, li16 = (unsigned)li * 16u, lq8 = (unsigned)lq * 8u;
+  const unsigned ci4 = (unsigned)dwo.ldi * 4u, co4 = (unsigned)dwo.ldd * 4u, li16 = (unsigned)li * 16u, lq8 = (unsigned)lq * 8u;
   auto mad24 = [](unsigned a_, unsigned b_, unsigned c_) __attribute__((always_inline)) {
     unsigned r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a_), "s"(b_), "v"(c_));
@@ -2839,7 +2844,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / (NW * COS * 16);
-  const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
+  const unsigned in_bytes = (unsigned)((n_in - 1) * (colstats.ldi ? colstats.ldi : Ci) * 4 + Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
   float *dst = ksplit > 1 ? part : out;
   const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
 #define SCN_LAUNCH_T2(D)                                                                                   \
@@ -2892,7 +2897,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
   const int ncb = Co / 64;
-  const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
+  const unsigned in_bytes = (unsigned)((n_in - 1) * (colstats.ldi ? colstats.ldi : Ci) * 4 + Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
   float *dst4 = ksplit > 1 ? part : out;
   // unsplit launches: the workspace holds the pass tables (scn_conv_workspace_bytes)
   unsigned long long *gtab = (ksplit == 1 && g_conv_gtab) ? (unsigned long long *)part : nullptr;
@@ -3115,20 +3120,28 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
                      const int32_t *rules, const int32_t *bases,
                      const int32_t *tile_order, const int32_t *counts, int K,
                      int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in, int64_t n_out, int Ci,
-                     int Co, void *wpack, int wpack_ready, void *workspace, size_t workspace_bytes, void *stream_) {
+                     int Co, int64_t ld_in, int64_t ld_out, void *wpack, int wpack_ready, void *workspace,
+                     size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
-  StatsArg colstats{colstats_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f};
+  SCN_REQUIRE((ld_in == 0 || (ld_in >= Ci && ld_in % 4 == 0 && ld_in < (1 << 20))) &&
+              (ld_out == 0 || (ld_out >= Co && ld_out % 4 == 0 && ld_out < (1 << 20))), "scn_conv_forward: bad leading dimensions");
+  if (ld_in == Ci) ld_in = 0;
+  if (ld_out == Co) ld_out = 0;
+  StatsArg colstats{colstats_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, (int)ld_in, (int)ld_out};
   if (bn_bwd != nullptr && colstats_out != nullptr) {
     SCN_REQUIRE(bn_bwd->x != nullptr && bn_bwd->save_mean != nullptr && bn_bwd->save_invstd != nullptr,
                 "scn_conv_forward: bn_bwd needs x, save_mean and save_invstd");
     colstats = StatsArg{colstats_out, bn_bwd->x, bn_bwd->save_mean, bn_bwd->save_invstd, bn_bwd->weight, bn_bwd->bias,
-                        (float)bn_bwd->leakiness};
+                        (float)bn_bwd->leakiness, (int)ld_in, (int)ld_out};
   }
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_forward: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_forward: in_col/out_col must be 0/1 or 1/0");
   SCN_REQUIRE(Ci > 0 && Co > 0, "scn_conv_forward: bad plane counts");
   if (n_out <= 0) return 0;
-  const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique && counts != nullptr);
+  const ConvPlan p = conv_plan(K, stride, ld_in ? (n_in * ld_in + Ci - 1) / Ci : n_in, n_out, Ci, Co, out_unique && counts != nullptr);
+  // column slices of wider tensors: `in` for the pipelined kernels, `out` for the one-contribution-per-row kernel only
+  SCN_REQUIRE(ld_in == 0 || p.kind == 2 || p.kind == 4 || p.kind == 5, "scn_conv_forward: ld_in needs planes that are multiples of 16 and < 4 GiB of input");
+  SCN_REQUIRE(ld_out == 0 || p.kind == 5, "scn_conv_forward: ld_out is supported by out_unique launches with planes % 64 == 0 only (scn_conv_plan = 5xx)");
   if (p.kind != 0) {
     SCN_REQUIRE(wpack != nullptr, "scn_conv_forward: wpack workspace required");
     float *Wp = (float *)wpack;
@@ -3156,7 +3169,7 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     if (p.kind == 5) {
       const int ncb = Co / 64;
       const int64_t nblk = (n_out + 31) / 32 + K;  // every output row in exactly one pair: sum_k ceil(count_k / 32) <= this
-      const unsigned in_bytes = (unsigned)(n_in * Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
+      const unsigned in_bytes = (unsigned)((n_in - 1) * (colstats.ldi ? colstats.ldi : Ci) * 4 + Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
       k_conv_expand<<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, stride,
                                                              in_col, Ci, Co, ncb, in_bytes, wp_bytes);
       SCN_CHECK_LAUNCH();
@@ -3217,8 +3230,13 @@ size_t scn_conv_dweight_workspace_bytes(int K, int64_t stride, int64_t n_in, int
 
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, const int32_t *bases, int K, int64_t stride, int in_col, int out_col,
-                     int64_t n_in, int64_t n_dout, int Ci, int Co, void *workspace, size_t workspace_bytes, void *stream_) {
+                     int64_t n_in, int64_t n_dout, int Ci, int Co, int64_t ld_in, int64_t ld_dout, void *workspace,
+                     size_t workspace_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
+  if (ld_in == 0) ld_in = Ci;
+  if (ld_dout == 0) ld_dout = Co;
+  SCN_REQUIRE((ld_in == Ci || (ld_in > Ci && ld_in % 4 == 0 && ld_in < (1 << 20))) &&
+              (ld_dout == Co || (ld_dout > Co && ld_dout % 4 == 0 && ld_dout < (1 << 20))), "scn_conv_dweight: bad leading dimensions");
   SCN_REQUIRE(K >= 1 && K <= KMAX, "scn_conv_dweight: filter volume must be 1..27");
   SCN_REQUIRE((in_col == 0 && out_col == 1) || (in_col == 1 && out_col == 0), "scn_conv_dweight: in_col/out_col must be 0/1 or 1/0");
   if (stride <= 0) return 0;
@@ -3229,7 +3247,7 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     SCN_REQUIRE(workspace_bytes >= (size_t)nslots * (size_t)elems * 4, "scn_conv_dweight: workspace smaller than scn_conv_dweight_workspace_bytes()");
     SCN_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)nslots * (size_t)elems * 4, stream));
   }
-  const DwOut dwo{dW, (float *)workspace, elems};
+  const DwOut dwo{dW, (float *)workspace, elems, (int)ld_in, (int)ld_dout};
   auto finish = [&]() -> int {
     if (workspace) {
       if (elems % 4 == 0) {
@@ -3244,10 +3262,12 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     return 0;
   };
   // (k_dw_tile: 32-bit byte offsets, row numbers through v_mad_u32_u24, 31-bit byte offsets into one rule list)
-  const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 32) || n_dout * Co * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
+  const bool huge = n_in * ld_in * 4 >= ((int64_t)1 << 32) || n_dout * ld_dout * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
                     n_dout >= (1 << 24) || stride >= (1 << 28);
+  SCN_REQUIRE((ld_in == Ci && ld_dout == Co) || (Ci % 32 == 0 && Co % 32 == 0 && !huge),
+              "scn_conv_dweight: column slices (ld_in / ld_dout) need planes that are multiples of 32 and < 4 GiB operands");
   if (Ci % 32 == 0 && Co % 32 == 0 && !huge) {
-    const unsigned in_bytes = (unsigned)(n_in * Ci * 4), do_bytes = (unsigned)(n_dout * Co * 4);
+    const unsigned in_bytes = (unsigned)((n_in - 1) * ld_in * 4 + Ci * 4), do_bytes = (unsigned)((n_dout - 1) * ld_dout * 4 + Co * 4);
     // slices per list: enough workgroups per (k, plane block) to fill the chip, few enough that the float atomics of
     // the partial sums (one CIB x COB tile per workgroup) stay far below the ~1.3 TB/s atomic rate.  The longest list
     // (the centre offset: one pair per site) gets ~2400 pairs per workgroup, an average one about half of that.

@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256)
 template <int VEC, bool FROM_X>
 __global__ void __launch_bounds__(256)
     k_bn_bwd_apply(const float *x, const float *d_out, float *d_x, const float *save_mean,
-                   int64_t total_vec, int C, const float *coef, float leak, const float *add = nullptr) {
+                   int64_t total_vec, int C, const float *coef, float leak, const float *add = nullptr, int ld_add = 0) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)((i * VEC) % C);
     if (VEC == 4) {
@@ -265,14 +265,16 @@ __global__ void __launch_bounds__(256)
       o.z = (d.z - gm.z - (xv.z - m.z) * kk.z) * sc.z;
       o.w = (d.w - gm.w - (xv.w - m.w) * kk.w) * sc.w;
       if (add) {  // the gradient arriving at x along another path (shortcut): one read here instead of an add kernel
-        const float4 e = ((const float4 *)add)[i];
+        // (ld_add: it may be a column slice of a wider tensor -- the left half of a joined gradient)
+        const float4 e = ld_add ? *(const float4 *)(add + ((i * 4) / C) * (int64_t)ld_add + c) : ((const float4 *)add)[i];
         o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
       }
       ((float4 *)d_x)[i] = o;
     } else {
       float d = d_out[i];
       if (FROM_X && leak != 1.f) d *= fmaf(x[i], coef[3 * C + c], coef[4 * C + c]) > 0 ? 1.f : leak;
-      d_x[i] = (d - coef[c] - (x[i] - save_mean[c]) * coef[C + c]) * coef[2 * C + c] + (add ? add[i] : 0.f);
+      d_x[i] = (d - coef[c] - (x[i] - save_mean[c]) * coef[C + c]) * coef[2 * C + c] +
+               (add ? (ld_add ? add[(i / C) * (int64_t)ld_add + c] : add[i]) : 0.f);
     }
   }
 }
@@ -356,7 +358,8 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_bn_small_bwd(const float *__restrict__ x, const float *__restrict__ d_out, float *__restrict__ d_x, int64_t N, int C,
                    const float *save_mean, const float *save_invstd, const float *weight, const float *bias,
-                   float *d_weight, float *d_bias, float leak, int accumulate, const float *__restrict__ add = nullptr) {
+                   float *d_weight, float *d_bias, float leak, int accumulate, const float *__restrict__ add = nullptr,
+                   int ld_add = 0) {
   __shared__ float coef[3][16];
   const int cgl = threadIdx.x & 3, slot = threadIdx.x >> 2;
   const int c0 = blockIdx.x * 16 + cgl * 4;
@@ -413,7 +416,7 @@ __global__ void __launch_bounds__(256)
     o.z = (d.z - gm.z - (xv.z - m[2]) * kk.z) * sc.z;
     o.w = (d.w - gm.w - (xv.w - m[3]) * kk.w) * sc.w;
     if (add) {
-      const float4 e = *(const float4 *)(add + r * C + c0);
+      const float4 e = *(const float4 *)(add + r * (int64_t)(ld_add ? ld_add : C) + c0);
       o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
     }
     *(float4 *)(d_x + r * C + c0) = o;
@@ -670,19 +673,21 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
 int scn_bn_backward_ext(const float *x, float *d_x, const float *d_out, const float *save_mean,
                         const float *save_invstd, const float *weight, const float *bias, float *d_weight,
                         float *d_bias, double leakiness, int64_t N, int C, int flags, void *temp,
-                        const float *partial_in, int nblk_in, const float *d_x_add, void *stream_) {
+                        const float *partial_in, int nblk_in, const float *d_x_add, int64_t ld_add, void *stream_) {
   const int accumulate = (flags >> 1) & 1;
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(C > 0 && N > 0, "scn_bn_backward_ext: bad shape");
   SCN_REQUIRE((flags & ~SCN_BN_ACCUMULATE_DPARAMS) == 0, "scn_bn_backward_ext: only SCN_BN_ACCUMULATE_DPARAMS may be set");
   SCN_REQUIRE(partial_in == nullptr || nblk_in > 0, "scn_bn_backward_ext: partial sums without blocks");
+  SCN_REQUIRE(ld_add == 0 || (ld_add >= C && ld_add % 4 == 0 && ld_add < (1 << 24)), "scn_bn_backward_ext: bad ld_add");
+  const int lda = (ld_add == C) ? 0 : (int)ld_add;
   float *partial = (float *)temp;
   float *coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
   const bool v4 = (C % 4) == 0;
   const float leak = (float)leakiness;
   if (partial_in == nullptr && v4 && N <= BN_SMALL_ROWS) {
     k_bn_small_bwd<<<(C + 15) / 16, 256, 0, stream>>>(x, d_out, d_x, N, C, save_mean, save_invstd, weight, bias, d_weight,
-                                                      d_bias, leak, accumulate, d_x_add);
+                                                      d_bias, leak, accumulate, d_x_add, lda);
     SCN_CHECK_LAUNCH();
     return 0;
   }
@@ -706,8 +711,8 @@ int scn_bn_backward_ext(const float *x, float *d_x, const float *d_out, const fl
                                                         coef, accumulate);
   SCN_CHECK_LAUNCH();
   const int64_t total = N * C;
-  if (v4) k_bn_bwd_apply<4, true><<<grid_for(total / 4), 256, 0, stream>>>(x, d_out, d_x, save_mean, total / 4, C, coef, leak, d_x_add);
-  else k_bn_bwd_apply<1, true><<<grid_for(total), 256, 0, stream>>>(x, d_out, d_x, save_mean, total, C, coef, leak, d_x_add);
+  if (v4) k_bn_bwd_apply<4, true><<<grid_for(total / 4), 256, 0, stream>>>(x, d_out, d_x, save_mean, total / 4, C, coef, leak, d_x_add, lda);
+  else k_bn_bwd_apply<1, true><<<grid_for(total), 256, 0, stream>>>(x, d_out, d_x, save_mean, total, C, coef, leak, d_x_add, lda);
   SCN_CHECK_LAUNCH();
   return 0;
 }

@@ -11,7 +11,7 @@ forward_pass_multiplyAdd_count = 0
 forward_pass_hidden_states = 0
 
 from .. import SCN  # noqa: E402,F401
-from .containers import (AddTable, ConcatTable, Identity, JoinTable, NetworkInNetwork,  # noqa: E402,F401
+from .containers import (AddTable, ConcatTable, Identity, JoinConcatTable, JoinTable, NetworkInNetwork,  # noqa: E402,F401
                          ResidualConcatTable, Sequential)
 from .conv import Convolution, Deconvolution, SubmanifoldConvolution, ValidConvolution  # noqa: E402,F401
 from .io import InputLayer, OutputLayer  # noqa: E402,F401

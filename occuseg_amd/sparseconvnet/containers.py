@@ -84,12 +84,76 @@ class ResidualConcatTable(ConcatTable):
         return [body[-1](x, residual=shortcut.features, join=join if nin_join is None else None)]
 
 
+class JoinConcatTable(ConcatTable):
+    """ConcatTable(Identity, path) whose results a JoinTable concatenates (the level of scn.UNet,
+    sparseconvnet/networkArchitectures.py:294-301): same children, same state_dict keys, same results.  When the path starts
+    with a batch norm, the two gradients of the common input -- out of that batch norm, and the left half of the joined
+    gradient -- can be added inside the batch norm's apply pass instead of by an autograd add kernel: a GradJoin is handed
+    to the batch norm and offered (un-armed) to whoever consumes the table; a JoinTable arms it."""
+
+    def forward(self, input):
+        from .norm import BatchNormalization
+        children = list(self._modules.values())
+        path = list(children[1]._modules.values()) if len(children) == 2 and isinstance(children[1], Sequential) else []
+        hooked = len(children) == 2 and (children[1]._forward_hooks or children[1]._forward_pre_hooks)
+        if not (GRAD_JOIN and path and isinstance(children[0], Identity) and isinstance(path[0], BatchNormalization)
+                and self.training and not hooked and torch.is_grad_enabled()):
+            return ConcatTable.forward(self, input)
+        join = GradJoin(armed=False)
+        x = path[0](input, join=join)
+        for mod in path[1:]:
+            x = mod(x)
+        x.left_join = join
+        return [children[0](input), x]
+
+
+class _JoinFunction(Function):
+    """[left | right] -> joined.  `base` (may be None): a [rows, 2 planes] buffer whose right half `right` already is (a
+    Deconvolution with join_right wrote it there): only the left half is copied in.  Backward: the two halves of the
+    joined gradient as column slices, no copies; with an armed GradJoin the left one is left for the batch norm at the
+    head of the other path to add."""
+
+    @staticmethod
+    def forward(ctx, left, right, base, join):
+        ctx.p, ctx.join = left.size(1), join
+        if base is None:
+            return torch.cat([left, right], 1)
+        base[:, :left.size(1)].copy_(left)
+        ctx.mark_dirty(base)
+        return base
+
+    @staticmethod
+    def backward(ctx, g):
+        g_left, g_right = g[:, :ctx.p], g[:, ctx.p:]
+        join, ctx.join = ctx.join, None
+        if join is not None and ctx.needs_input_grad[0]:
+            other = join.take()
+            if other is None:
+                join.put(g_left)
+                g_left = None
+            else:
+                g_left = g_left + other
+        return g_left, g_right, None, None
+
+
 class JoinTable(torch.nn.Sequential):
     """concatenate feature planes of a list of tensors living on the same sites"""
 
     def forward(self, input):
-        out = _like(input[0], torch.cat([t.features for t in input], 1))
-        stats = [t.get_colstats() for t in input]
+        stats = [t.get_colstats() for t in input]  # (before anything is written: they are keyed on the tensors' versions)
+        if len(input) == 2 and input[0].features.dim() == 2 and input[0].features.size(0) == input[1].features.size(0) \
+                and input[0].features.size(0) > 0:
+            left, right = input[0].features, input[1].features
+            base = getattr(input[1], "join_base", None)
+            if base is not None and not (base.size(1) == left.size(1) + right.size(1) and right.data_ptr() ==
+                                         base.data_ptr() + 4 * left.size(1) and left.dtype == base.dtype):
+                base = None
+            join = getattr(input[1], "left_join", None)
+            if join is not None:
+                join.armed = True
+            out = _like(input[0], _JoinFunction.apply(left, right, base, join))
+        else:
+            out = _like(input[0], torch.cat([t.features for t in input], 1))
         if all(stats):  # the statistics of a concatenation are the concatenation of the statistics
             out.set_colstats([seg for st in stats for seg in st])
         return out

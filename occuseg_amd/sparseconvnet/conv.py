@@ -30,6 +30,7 @@ def grad_owner(*params):
     return owner
 
 
+JOIN_IN_PLACE = True  # A/B switch: a Deconvolution marked `join_right` (scn.UNet's) writes into the right half of the joined tensor
 EMIT_COLSTATS = True  # A/B switch: convolutions hand their output's column statistics to the following batch norm
 
 
@@ -38,7 +39,7 @@ class _RuleConvFunction(Function):
 
     @staticmethod
     def forward(ctx, features, weight, bias, kind, metadata, in_size, out_size, filter_size, filter_stride,
-                dilated_rate, residual=None, stats_out=None, bn_link=None, join=None):
+                dilated_rate, residual=None, stats_out=None, bn_link=None, join=None, join_base=None):
         ctx.kind, ctx.scn_meta, ctx.dilated_rate = kind, metadata, dilated_rate
         ctx.bn_link, ctx.join = bn_link, join
         ctx.sizes = (in_size, out_size, filter_size, filter_stride)
@@ -51,8 +52,20 @@ class _RuleConvFunction(Function):
             macs = SCN.Convolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, features,
                                                 out, weight, bias, stats_out=stats_out)
         else:
+            # join_base (a list that receives it): the result is written straight into the RIGHT half of a [rows, 2 nOut]
+            # buffer -- the JoinTable that follows copies only the other half in (`_JoinFunction`) -- when the launch is one
+            # that can write a column slice
+            view = None
+            if join_base is not None and features.size(0) > 0 and SCN.deconvolution_can_write_a_slice(
+                    in_size, out_size, filter_size, filter_stride, metadata, weight.size(1), weight.size(2)):
+                n_out, co = metadata.getNActive(out_size), weight.size(2)
+                base = torch.empty((n_out, 2 * co), dtype=features.dtype, device=features.device)
+                view = base[:, co:]
+                join_base.append(base)
             macs = SCN.Deconvolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, features,
-                                                  out, weight, bias, stats_out=stats_out)
+                                                  out, weight, bias, stats_out=stats_out, _out_view=view)
+            if view is not None:
+                out = view
         counters.add(macs, out.nelement())
         ctx.save_for_backward(features, weight, bias)
         return out
@@ -61,9 +74,10 @@ class _RuleConvFunction(Function):
     def backward(ctx, grad_output):
         features, weight, bias = ctx.saved_tensors
         in_size, out_size, filter_size, filter_stride = ctx.sizes
-        grad_output = grad_output.contiguous()
+        if not (SCN._row_slice(grad_output) and not grad_output.is_contiguous()):  # (a column slice of a joined gradient is read in place)
+            grad_output = grad_output.contiguous()
         # the reference always computes dInput; it is skipped here when autograd does not ask for it
-        grad_input = like_empty(grad_output) if ctx.needs_input_grad[0] else None
+        grad_input = torch.empty(0, dtype=grad_output.dtype, device=grad_output.device) if ctx.needs_input_grad[0] else None
         # The dWeight kernel ACCUMULATES (float atomics into a zeroed buffer, as the reference's does).  When the
         # owner of the gradients says so (occuseg_amd.dp.FlatGradBucket: .grad are views of one zeroed flat buffer,
         # see grad_owner above) it accumulates straight into weight.grad: no zeros_like, no autograd add kernel.
@@ -105,7 +119,7 @@ class _RuleConvFunction(Function):
                 grad_residual = None
             else:
                 grad_residual = grad_residual + other
-        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7 + (grad_residual, None, None, None)
+        return (grad_input, grad_weight, optionalTensorReturn(grad_bias)) + (None,) * 7 + (grad_residual, None, None, None, None)
 
 
 class _RuleConv(Module):
@@ -138,12 +152,15 @@ class _RuleConv(Module):
         # training: the kernel also emits the column statistics of its result (taken from the output tile while it is in
         # LDS) for the batch norm that usually follows
         sink = [] if (self.training and EMIT_COLSTATS) else None
+        base = [] if (self.kind == "deconv" and getattr(self, "join_right", False) and JOIN_IN_PLACE) else None
         output.features = _RuleConvFunction.apply(
             input.features, self.weight, optionalTensor(self, "bias"), self.kind, input.metadata,
             input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate, residual, sink,
-            input.get_bn_link() if hasattr(input, "get_bn_link") else None, join if residual is not None else None)
+            input.get_bn_link() if hasattr(input, "get_bn_link") else None, join if residual is not None else None, base)
         if sink:
             output.set_colstats([(self.nOut, sink[0])])
+        if base:
+            output.join_base = base[0]  # features IS its right half (see containers.JoinTable)
         return output
 
     def _fmt(self, t):

@@ -51,9 +51,11 @@ class _BatchNormFunction(Function):
         # (GradJoin): added inside the apply pass instead of by an autograd add kernel
         partials = ctx.link.take(grad_output) if ctx.link is not None else None
         join, extra = ctx.join, None
+        if join is not None and not join.armed:
+            join = None  # nobody took the other end (no JoinTable behind the JoinConcatTable): plain path
         if join is not None and join.pending is not None:
             extra = join.take()
-            if not (extra.is_contiguous() and extra.shape == features.shape):
+            if not (extra.shape == features.shape and (extra.is_contiguous() or SCN._row_slice(extra))):
                 extra = extra.contiguous()
         SCN.BatchNormalization_backward(features, grad_input, out, grad_output, save_mean, save_invstd,
                                         running_mean, running_var, weight, bias, grad_weight, grad_bias,

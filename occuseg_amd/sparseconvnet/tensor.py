@@ -22,10 +22,11 @@ class GradJoin(object):
     to autograd; the second adds it INSIDE its own kernel (batch norm backward's apply pass, the NiN dInput's output
     tile) and returns the sum: the elementwise add kernel autograd would launch at x disappears.  Whichever order the
     engine runs the two in, the sum is the same.  One object per forward pass: nothing survives a failed backward."""
-    __slots__ = ("pending",)
+    __slots__ = ("pending", "armed")
 
-    def __init__(self):
+    def __init__(self, armed=True):
         self.pending = None
+        self.armed = armed  # False: created by one side only (JoinConcatTable); the other side (JoinTable) arms it in forward
 
     def put(self, grad):
         assert self.pending is None
@@ -45,6 +46,8 @@ class SparseConvNetTensor(object):
         self.spatial_size = spatial_size
         self._colstats = None  # (version of the features tensor, [(planes, partial column sums), ...]) -- see set_colstats
         self._bn_link = None   # (version, SCN.BnLink) left by the batch norm that produced `features` -- see set_bn_link
+        self.join_base = None  # [rows, 2 planes] buffer whose right half `features` is (a Deconvolution with join_right)
+        self.left_join = None  # GradJoin offered by a JoinConcatTable for the gradient of the OTHER table entry
 
     @property
     def features(self):
@@ -56,6 +59,7 @@ class SparseConvNetTensor(object):
         self._features = value
         self._colstats = None
         self._bn_link = None
+        self.join_base = None
 
     def set_colstats(self, segments):
         """Column statistics of ``features`` emitted by the kernel(s) that produced it (not in the reference).  They

@@ -4,7 +4,7 @@ Same module tree (hence the same state_dict keys) as sparseconvnet/networkArchit
 per level  block* ; ConcatTable(Identity, BN -> Conv 2/2 -> U(next) -> BN -> Deconv 2/2) ; JoinTable ; block*,
 residual block = ConcatTable(Identity | NiN, BN -> SC3 -> BN -> SC3) -> AddTable.
 """
-from .containers import (AddTable, ConcatTable, Identity, JoinTable, NetworkInNetwork, ResidualConcatTable,
+from .containers import (AddTable, Identity, JoinConcatTable, JoinTable, NetworkInNetwork, ResidualConcatTable,
                          Sequential)
 from .conv import Convolution, Deconvolution, SubmanifoldConvolution
 from .norm import BatchNormLeakyReLU
@@ -37,7 +37,11 @@ def UNet(dimension, reps, nPlanes, residual_blocks=False, downsample=[2, 2], lea
                        .add(level(planes[1:]))
                        .add(bn(planes[1]))
                        .add(Deconvolution(dimension, planes[1], planes[0], downsample[0], downsample[1], False)))
-            m.add(ConcatTable().add(Identity()).add(down_up))
+            # (modules are created in the reference's order: same seed, same parameters)  The deconvolution's result is the
+            # right half of the JoinTable below: it is written there directly
+            list(down_up._modules.values())[-1].join_right = True
+            # JoinConcatTable: a ConcatTable that lets the first batch norm of down_up add the left half of the joined gradient
+            m.add(JoinConcatTable().add(Identity()).add(down_up))
             m.add(JoinTable())
             for i in range(reps):
                 add_block(m, planes[0] * (2 if i == 0 else 1), planes[0])

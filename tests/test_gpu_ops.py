@@ -549,3 +549,65 @@ def test_bn_backward_reductions_from_the_dinput_launch(gpu, ci, co, n, extent, l
                                         _bn_link=link2)
     d2.add_(1.0)
     assert link2.take(d2) is None
+
+
+@pytest.mark.parametrize("p,n,extent", [(64, 72000, 60), (128, 20000, 40), (64, 3000, 20)])
+def test_deconvolution_into_and_out_of_a_joined_tensor(gpu, p, n, extent):
+    """scn_conv_forward's ld_out / ld_in, scn_conv_dweight's ld_dout, scn_bn_backward_ext's ld_add: a deconvolution writes its
+    result into the RIGHT half of a [rows, 2p] tensor (k_conv_expand), its backward pass reads the right half of a joined
+    gradient in place (dInput through k_conv_tile4 / k_conv_tile2 incl. the offset split, dWeight through k_dw_tile), a batch
+    norm's apply pass adds the LEFT half -- all against the same calls on contiguous copies (bitwise for the forward and the
+    dInput, whose summation order does not change; 1e-5 for dWeight: float atomics) and the forward against the oracle."""
+    from occuseg_amd import SCN
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu, seed=17, n=n, batch=2, extent=extent)
+    coarse, srules, _ = R.strided_rules(grid)
+    half = size // 2
+    m.getRuleBook(size, half, F2, F2)
+    nf, nc = grid.n, coarse.n
+    ci, co = 2 * p, p  # deconvolution 2p -> p (coarse -> fine)
+    rng = np.random.default_rng(p)
+    xc = rng.normal(size=(nc, ci)).astype(np.float32)
+    w = (rng.normal(size=(8, ci, co)) * (2.0 / ci / 8) ** 0.5).astype(np.float32)
+    e = torch.empty(0, device=gpu)
+    # forward into the right half of a joined buffer
+    plain = torch.empty(0, device=gpu)
+    SCN.Deconvolution_updateOutput(half, size, F2, F2, m, _t(xc, gpu), plain, _t(w, gpu), e)
+    want, _ = A.conv_forward(xc, w, srules, nf, None, in_col=1, out_col=0, dtype=np.float64)
+    assert_close(plain.cpu().numpy(), want, "deconvolution forward")
+    if SCN.deconvolution_can_write_a_slice(half, size, F2, F2, m, ci, co):
+        joined = torch.full((nf, 2 * co), 7.0, device=gpu)
+        SCN.Deconvolution_updateOutput(half, size, F2, F2, m, _t(xc, gpu), torch.empty(0, device=gpu), _t(w, gpu), e,
+                                       _out_view=joined[:, co:])
+        assert torch.equal(joined[:, co:], plain) and bool((joined[:, :co] == 7.0).all())
+    else:
+        assert n == 3000  # planes % 64 == 0 everywhere else
+    # backward out of the right half of a joined gradient
+    g = torch.from_numpy(rng.normal(size=(nf, 2 * co)).astype(np.float32)).to(gpu)
+    g_right = g[:, co:]
+    assert not g_right.is_contiguous()
+    res = {}
+    for name, d_out in (("slice", g_right), ("copy", g_right.contiguous())):
+        d_in, d_w = torch.empty(0, device=gpu), torch.zeros(8, ci, co, device=gpu)
+        SCN.Deconvolution_backward(half, size, F2, F2, m, _t(xc, gpu), d_in, d_out, _t(w, gpu), d_w, e)
+        res[name] = (d_in, d_w)
+    assert torch.equal(res["slice"][0], res["copy"][0])
+    assert_close(res["slice"][1].cpu().numpy(), res["copy"][1].cpu().numpy(), "dWeight from a column slice", rel=1e-5)
+    d_in_o, d_w_o, _ = A.conv_backward(xc, g_right.cpu().numpy(), w, srules, in_col=1, out_col=0, dtype=np.float64)
+    assert_close(res["slice"][0].cpu().numpy(), d_in_o, "deconvolution dInput from a column slice")
+    assert_close(res["slice"][1].cpu().numpy(), d_w_o, "deconvolution dWeight from a column slice")
+    # batch norm backward adding the LEFT half of the joined gradient inside its apply pass
+    x = torch.from_numpy(rng.normal(size=(nf, co)).astype(np.float32)).to(gpu)
+    gam, bet = torch.from_numpy(rng.normal(size=co).astype(np.float32)).to(gpu), torch.zeros(co, device=gpu)
+    y, sm, si = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+    SCN.BatchNormalization_updateOutput(x, y, sm, si, torch.zeros(co, device=gpu), torch.ones(co, device=gpu), gam, bet,
+                                        1e-4, 0.9, True, 0.0)
+    dy = torch.from_numpy(rng.normal(size=(nf, co)).astype(np.float32)).to(gpu)
+    outs = []
+    for add in (g[:, :co], g[:, :co].contiguous()):
+        dx = torch.empty(0, device=gpu)
+        SCN.BatchNormalization_backward(x, dx, y, dy, sm, si, None, None, gam, bet, torch.zeros(co, device=gpu),
+                                        torch.zeros(co, device=gpu), 0.0, _rewrite_d_output=False, _mask_from_x=True,
+                                        _d_x_add=add)
+        outs.append(dx)
+    assert torch.equal(outs[0], outs[1])
