@@ -215,9 +215,10 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
  * part of this ABI: they exist only in libscn_hip_tuning.so (same sources compiled with -DSCN_TUNING), which
  * tools/ and the variant-equivalence test load explicitly. */
 
-/* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller; ld_in / ld_dout: leading dimensions of
- * `in` / `dout` when they are column slices of wider tensors, 0 = contiguous, planes % 32 == 0 then;
+/* dW[k] += in[list_k.in_col]^T . dOut[list_k.out_col]   (dW must be zeroed by the caller,
  * as the reference's callers do: sparseconvnet/submanifoldConvolution.py:114-115).
+ * ld_in / ld_dout (0 = contiguous): leading dimensions in floats of `in` / `dout` when they are column slices of wider
+ * tensors (the right half of a joined gradient); planes must then be multiples of 32.
  * Replaces dConvolution_KMxKN_backward_dW_* (sparseconvnet/SCN/CUDA/Convolution.cu:265-442,:695-753).
  * bases: scn_tile_bases(.., out_col, n_dout) or NULL; with it, narrow inputs (Ci <= 4: the 3 -> m stem) are processed
  * output-row major (every dOut row read once instead of once per pair).

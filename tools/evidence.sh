@@ -35,6 +35,8 @@ python3 tools/bench_conv.py --levels 0,1 --variants 4 --extra-lds 0,2000,15200 >
 python3 tools/ab_step.py DW_SIDE_STREAM=0,1 > $E/ab_dw_side_stream.txt 2>&1
 python3 tools/ab_step.py BN_BWD_STATS_FROM_CONV=0,1 > $E/ab_bn_bwd_stats_from_conv.txt 2>&1
 python3 tools/ab_step.py containers.GRAD_JOIN=0,1 > $E/ab_grad_join.txt 2>&1
+python3 tools/ab_step.py conv.JOIN_IN_PLACE=0,1 > $E/ab_join_in_place.txt 2>&1
+python3 tools/ab_step.py tune13=0,1 > $E/ab_tile4_global_pass_table.txt 2>&1
 python3 tools/ab_step.py DETERMINISTIC_DW=0,1 > $E/ab_deterministic_dw.txt 2>&1
 python3 tools/ab_step.py tune12=0,1 > $E/ab_dw_direct.txt 2>&1
 python3 tools/ab_tile_order.py > $E/ab_tile_order_layers.txt 2>&1
