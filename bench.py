@@ -216,6 +216,17 @@ def main():
     from occuseg_amd import SCN, dp, scenes
     scn = occuseg_amd.install()
     SCN.DETERMINISTIC_DW = bool(args.deterministic)
+    for sw in filter(None, os.environ.get("SCN_BENCH_SWITCHES", "").split(",")):  # debugging: e.g. conv.JOIN_IN_PLACE=0,tune13=0
+        name, val = sw.split("=")
+        if name.startswith("tune"):
+            from occuseg_amd import _lib as _l
+            _l.use_tuning_build().scn_set_tuning(int(name[4:]), int(val))
+        elif "." in name:
+            import importlib
+            mod, attr = name.split(".")
+            setattr(importlib.import_module("occuseg_amd.sparseconvnet." + mod), attr, int(val))
+        else:
+            setattr(SCN, name, int(val))
 
     torch.manual_seed(0)  # identical replicas
     net = build_net(scn, args.m).to(dev)
@@ -242,18 +253,25 @@ def main():
     input_layer = next(mod for mod in net.modules() if isinstance(mod, scn.InputLayer))
     counter = [0]
 
+    trace = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if os.environ.get("SCN_BENCH_TRACE") else (lambda *a: None)
+
     def step():
         i = counter[0]
         counter[0] += 1
+        trace("step", i)
         bucket.zero()
         out = net(batches[i % len(batches)])
+        trace("forward issued")
         out.sum().backward()
+        trace("backward issued")
         bucket.all_reduce_mean()
         opt.step()
+        trace("optimizer issued")
         if args.prefetch:
             # software pipelining across steps: the NEXT batch's voxel hash + rulebooks are built on a side stream
             # while this step's kernels drain (every step still builds its own)
             input_layer.prefetch(batches[(i + 1) % len(batches)], wait_for_current_stream=False)
+            trace("prefetch done")
         return out
 
     for _ in range(args.warmup):

@@ -874,7 +874,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (GT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the table is in L2 before the barrier lets anybody read it
   }
   __syncthreads();  // the only barrier
-  if (GT) asm volatile("s_dcache_inv" ::: "memory");  // (the scalar cache is not coherent with this kernel's vector stores)
+  // (the scalar cache is not coherent with this kernel's vector stores; the invalidate is a scalar-memory operation like the
+  //  loads behind it and those may complete out of order: wait for it)
+  if (GT) asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   unsigned long long gt_s = 0;  // this workgroup's region, in a scalar register pair
   if (GT) {
     const unsigned long long a = (unsigned long long)(gtab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (size_t)gstride);

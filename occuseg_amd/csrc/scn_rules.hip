@@ -8,6 +8,7 @@
 // the device.  Semantics: SURVEY.md Appendix A.
 #include "scn_common.h"
 
+#include <cstdlib>
 #include <rocprim/rocprim.hpp>
 
 namespace scn {
@@ -429,12 +430,35 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
 struct GridTemp {
   size_t keys_in, idx_in, blk_cnt, info, sort, total, sort_bytes;
 };
+// The 48-bit key sort.  rocPRIM's default Onesweep configuration for (u64, u32) on gfx950 compiles to a kernel with 80
+// bytes of SCRATCH (private memory) per lane -- the only kernel of this library that has any.  A queue's first dispatch
+// with scratch makes the runtime (re)size that queue's scratch buffer; with the rule build on its own high-priority
+// stream (SCN.prefetch_input) beside a deep main-stream queue, runs under rocprofv3 --kernel-trace died with "Memory
+// access fault by GPU" on some boxes (never without the profiler, never with the build on the main stream, never with
+// serialized launches; tools/guard_run.py finds no access outside a tensor).  8-bit digits, 256 x 12 keys per block: no
+// scratch, six passes over the 48 bits.  SCN_SORT_ROCPRIM_DEFAULT=1 selects rocPRIM's default again (A/B).
+using SortNoScratch = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<256, 12>, 8>>;
+static bool sort_rocprim_default() {
+  static const bool v = [] {
+    const char *e = getenv("SCN_SORT_ROCPRIM_DEFAULT");
+    return e != nullptr && e[0] == '1';
+  }();
+  return v;
+}
+static hipError_t sort_keys(void *temp, size_t &temp_bytes, uint64_t *keys_in, uint64_t *keys_out, uint32_t *idx_in,
+                            uint32_t *idx_out, size_t P, hipStream_t stream) {
+  if (sort_rocprim_default())
+    return rocprim::radix_sort_pairs<rocprim::default_config, uint64_t *, uint64_t *, uint32_t *, uint32_t *>(
+        temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, P, 0, 47, stream, false);
+  return rocprim::radix_sort_pairs<SortNoScratch, uint64_t *, uint64_t *, uint32_t *, uint32_t *>(
+      temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, P, 0, 47, stream, false);
+}
 static int grid_temp_layout(int64_t P, GridTemp &t) {
   const int64_t nblk = (P + 255) / 256;
   size_t sort_bytes = 0;
-  hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, uint64_t *, uint64_t *,
-                                           uint32_t *, uint32_t *>(
-      nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)P, 0, 47, 0, false);
+  hipError_t e = sort_keys(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)P, 0);
   if (e != hipSuccess) return 1;
   size_t off = 0;
   t.keys_in = off; off += align256((size_t)P * 8);
@@ -488,8 +512,7 @@ int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, i
     k_make_keys<2><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
   SCN_CHECK_LAUNCH();
   size_t sb = t.sort_bytes;
-  SCN_CHECK_HIP((rocprim::radix_sort_pairs(base + t.sort, sb, keys_in, keys_sorted, idx_in,
-                                           (uint32_t *)order, (size_t)P, 0, 47, stream, false)));
+  SCN_CHECK_HIP(sort_keys(base + t.sort, sb, keys_in, keys_sorted, idx_in, (uint32_t *)order, (size_t)P, stream));
   k_mark_first<<<nblk, 256, 0, stream>>>(keys_sorted, P, blk_cnt);
   SCN_CHECK_LAUNCH();
   k_excl_scan_rows<<<1, 1024, 0, stream>>>(blk_cnt, nblk, info);

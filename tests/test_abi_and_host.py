@@ -125,3 +125,15 @@ def test_scenes_are_deterministic_and_inside_the_key_box():
     assert a[:, 0].max() < 1024 and a[:, 1].max() < 2048 and a[:, 2].max() < 1024 and a[:, :3].min() >= 10
     assert np.all(np.diff(a[:, 3]) >= 0) and set(a[:, 3]) == {0, 1}
     assert len(scenes.solid_block(6)) == 216 and scenes.bernoulli_grid(32, 0.25, 0).shape[1] == 3
+
+
+def test_no_kernel_uses_scratch():
+    """no kernel of the product library spills or indexes private arrays (tools/check_scratch.py: why it matters)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_scratch", os.path.join(ROOT, "tools", "check_scratch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ks = mod.kernels(os.path.join(ROOT, "occuseg_amd", "libscn_hip.so"))
+    assert len(ks) > 100
+    bad = [(n, s) for n, s, _, _ in ks if s > 0 and not mod.ALLOWED.search(n)]
+    assert not bad, bad

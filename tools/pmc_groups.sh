@@ -10,7 +10,7 @@ while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
   # shellcheck disable=SC2086
-  rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 tools/bench_conv.py --levels "$LEVEL" --variants 4 > "$OUT/g$i.log" 2>&1
+  timeout 300 rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 tools/bench_conv.py --levels "$LEVEL" --variants 4 > "$OUT/g$i.log" 2>&1
 done <<'GROUPS'
 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
