@@ -2018,17 +2018,22 @@ __device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], con
 // in registers (A = weight fragments, B = the gathered rows fetched straight from global memory in fragment shape, as
 // in k_conv_tile4), the result is stored straight to the 32 output rows.  No LDS, no barrier, no atomics.  C_i is
 // walked in chunks of 32 planes, the loads of chunk c+1 requested before the MFMAs of chunk c.
+// NB (round 3 experiment, tuning key 14): a wave owns NB consecutive blocks of 32 pairs and multiplies them with the SAME weight
+// fragments (with one block per wave a launch reads C_i x 64 weights, 16-32 KB from L2, for every 32 gathered rows, 8-16 KB
+// from HBM).  NB = 2 (240 VGPRs, two waves per SIMD) measures the same as NB = 1, NB = 4 (436 VGPRs) 20 % slower: the
+// weight traffic is not the limit.  NB = 1 stays.
+template <int NB>
 __global__ void __launch_bounds__(64)
     k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                   const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
                   int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes, unsigned wp_bytes) {
-  // chunks of 32 reduction planes: 2 x (8 row + 32 weight) registers in flight + 32 accumulators keep the wave at
+  // chunks of 32 reduction planes: 2 x (8 row + 32 weight) registers in flight + 32 accumulators keep the NB = 1 wave at
   // ~150 VGPRs = three waves per SIMD (with 64-plane chunks it needed 272: one wave per SIMD, and a launch of
   // single-chunk waves -- NiN 64 -> 128 on 600k rows -- ran at a third of the speed of the tile kernel it replaced)
-  constexpr int CK = 32, NS16 = 2, COS = 4, PB = 32;
+  constexpr int CK = 32, NS16 = 2, COS = 4, PB = 32 * NB;
   const int lane = threadIdx.x;
   const int li = lane & 15, lq = lane >> 4;
-  // (list, block of 32 pairs, plane block) of this wave: blocks are numbered list after list
+  // (list, block of PB pairs, plane block) of this wave: blocks are numbered list after list
   int blk = blockIdx.x / ncb;
   const int co0 = (blockIdx.x % ncb) * 64;
   int k = 0, cnt = 0;
@@ -2050,11 +2055,12 @@ __global__ void __launch_bounds__(64)
   const int2 *rk = rules + (int64_t)k * stride;
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
-  unsigned roff[2];
-  int64_t orow[2];
-  bool live[2];
+  constexpr int NG = 2 * NB;  // groups of 16 pairs
+  unsigned roff[NG];
+  int orow[NG];
+  bool live[NG];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NG; ++g) {
     const int p = p0 + 16 * g + li;
     live[g] = p < cnt;
     const int2 pr = rk[min(p, cnt - 1)];
@@ -2062,13 +2068,13 @@ __global__ void __launch_bounds__(64)
     orow[g] = in_col ? pr.x : pr.y;
   }
   const int nch = Ci / CK;
-  floatx4 acc[2][COS];
+  floatx4 acc[NG][COS];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int q = 0; q < COS; ++q) acc[g][q] = floatx4{0.f, 0.f, 0.f, 0.f};
-  floatx4 rA[2][NS16], wA[COS][NS16], rB[2][NS16], wB[COS][NS16];
-  auto load = [&](int c, floatx4 (&r)[2][NS16], floatx4 (&w)[COS][NS16]) __attribute__((always_inline)) {
+  floatx4 rA[NG][NS16], wA[COS][NS16], rB[NG][NS16], wB[COS][NS16];
+  auto load = [&](int c, floatx4 (&r)[NG][NS16], floatx4 (&w)[COS][NS16]) __attribute__((always_inline)) {
     // weight fragment (k, 16-plane reduction block rs, 16-plane output block cs) = 1 KiB at ((k Ci/16 + rs) Co/16 + cs) KiB
     const int blk0 = (k * (Ci / 16) + c * (CK / 16)) * (Co / 16) + co0 / 16;
 #pragma unroll
@@ -2078,13 +2084,13 @@ __global__ void __launch_bounds__(64)
         w[q][sp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
             wp_rsrc, (unsigned)lane * 16u, (blk0 + sp * (Co / 16) + q) * 1024, 0));
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int sp = 0; sp < NS16; ++sp)
         r[g][sp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
             in_rsrc, roff[g] + (unsigned)(sp * 64), c * (CK * 4), 0));
   };
-  auto mma = [&](const floatx4 (&r)[2][NS16], const floatx4 (&w)[COS][NS16]) __attribute__((always_inline)) {
+  auto mma = [&](const floatx4 (&r)[NG][NS16], const floatx4 (&w)[COS][NS16]) __attribute__((always_inline)) {
 #pragma unroll
     for (int sp = 0; sp < NS16; ++sp)
 #pragma unroll
@@ -2092,7 +2098,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int q = 0; q < COS; ++q)
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+          for (int g = 0; g < NG; ++g)
             acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q][sp][e], r[g][sp][e], acc[g][q], 0, 0, 0);
   };
   load(0, rA, wA);
@@ -2103,22 +2109,23 @@ __global__ void __launch_bounds__(64)
     mma(rB, wB);
   }
   // D[i = plane][j = pair]: lane (li, lq) holds planes 16 q + 4 lq .. + 3 of pair li
+  const int64_t ldo = colstats.ldo ? colstats.ldo : Co;
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < NG; ++g)
     if (live[g]) {
 #pragma unroll
       for (int q = 0; q < COS; ++q) {
         floatx4 v = acc[g][q];
         if (bias) v += *(const floatx4 *)(bias + co0 + 16 * q + 4 * lq);
-        if (residual) v += *(const floatx4 *)(residual + orow[g] * Co + co0 + 16 * q + 4 * lq);
-        *(floatx4 *)(out + orow[g] * (colstats.ldo ? colstats.ldo : Co) + co0 + 16 * q + 4 * lq) = v;
+        if (residual) v += *(const floatx4 *)(residual + (int64_t)orow[g] * Co + co0 + 16 * q + 4 * lq);
+        *(floatx4 *)(out + (int64_t)orow[g] * ldo + co0 + 16 * q + 4 * lq) = v;
         acc[g][q] = v;
       }
     } else {
 #pragma unroll
       for (int q = 0; q < COS; ++q) acc[g][q] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
-  // column statistics of the wave's 32 output rows (colstats [pair blocks][2][Co]; blocks past the end of the lists
+  // column statistics of the wave's PB output rows (colstats [waves][2][Co]; waves past the end of the lists
   // wrote zeros above): sum over the 16 pairs of a group = butterfly over the 16 lanes that share lq
   if (colstats.out != nullptr) {
     const int64_t pb = blockIdx.x / ncb;
@@ -2128,7 +2135,7 @@ __global__ void __launch_bounds__(64)
       StatsCols sc;
       sc.init(colstats, co0 + 16 * q + 4 * lq);
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+      for (int g = 0; g < NG; ++g)
         if (!sc.bn || live[g]) sc.add(acc[g][q], colstats.x + (int64_t)orow[g] * Co + co0 + 16 * q + 4 * lq, cs, css);
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1)
@@ -2756,6 +2763,8 @@ SCN_KNOB g_conv_extra_lds = 0;  // tuning key 10: bytes of unused dynamic LDS ad
 SCN_KNOB g_dw_direct = 0;       // tuning key 12: 1 = k_dw_direct (no LDS staging) for 64-plane blocks.  Round 3: correct (all dW parity
                                 // tests), 107-130 against 105-126 TFLOP/s on the six big layer shapes in isolation, but the train
                                 // step is 1.8 ms SLOWER with it (50.3 against 48.4 ms, tools/ab_step.py tune12=0,1): off
+SCN_KNOB g_conv_expand_nb = 1;  // tuning key 14: blocks of 32 pairs per wave of k_conv_expand (1, 2 or 4).  Measured (round 3, 20 launches
+                                // per step): 1.81 / 1.83 / 2.21 ms -- the weight re-reads are not what bounds the kernel
 SCN_KNOB g_conv_gtab = 1;       // tuning key 13: 0 = k_conv_tile4 keeps its pass table in LDS (A/B)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
@@ -2891,6 +2900,9 @@ static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ?
 // entries (8 bytes each) of one workgroup's region of k_conv_tile4's global pass table: <= 4 passes per (offset, chunk), 8
 // sentinels, rounded to whole 64-byte lines (a scalar-cache line never holds entries of two workgroups)
 static int tile4_gtab_stride(int K, int Ci) { return (K * 4 * (Ci / 64) + 8 + 7) / 8 * 8; }
+// k_conv_expand: blocks of 32 pairs per wave, and an upper bound of the waves of a launch (one statistics slot each)
+static int expand_nb() { return g_conv_expand_nb >= 4 ? 4 : g_conv_expand_nb >= 2 ? 2 : 1; }
+static int64_t expand_waves(int64_t n_out, int K) { return (n_out + 32 * expand_nb() - 1) / (32 * expand_nb()) + K; }
 
 static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, StatsArg colstats, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
@@ -3049,6 +3061,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 11 && (value == 0 || value == 96 || value == 128)) { g_conv_tile6 = value; return 0; }
   if (key == 12) { g_dw_direct = value; return 0; }
   if (key == 13) { g_conv_gtab = value; return 0; }
+  if (key == 14) { g_conv_expand_nb = value; return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
@@ -3067,7 +3080,7 @@ size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_o
 int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique) {
   if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
   const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
-  if (p.kind == 5) return (n_out + 31) / 32 + K;
+  if (p.kind == 5) return expand_waves(n_out, K);
   if (p.kind != 2 && p.kind != 4) return 0;  // generic / fallback kernels do not emit statistics
   if (p.ksplit > 1) return 0;  // coarse levels: the batch norm's own statistics pass over a few thousand rows is cheaper
                                // than a reduction kernel that also reduces columns (A/B: +0.2 ms per step)
@@ -3170,10 +3183,17 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     }
     if (p.kind == 5) {
       const int ncb = Co / 64;
-      const int64_t nblk = (n_out + 31) / 32 + K;  // every output row in exactly one pair: sum_k ceil(count_k / 32) <= this
+      const int64_t nblk = expand_waves(n_out, K);  // every output row in exactly one pair: sum_k ceil(count_k / PB) <= this
       const unsigned in_bytes = (unsigned)((n_in - 1) * (colstats.ldi ? colstats.ldi : Ci) * 4 + Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
-      k_conv_expand<<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, stride,
-                                                             in_col, Ci, Co, ncb, in_bytes, wp_bytes);
+#define SCN_LAUNCH_EXPAND(NB_)                                                                                              \
+  k_conv_expand<NB_><<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, \
+                                                               stride, in_col, Ci, Co, ncb, in_bytes, wp_bytes)
+      switch (expand_nb()) {
+        case 4: SCN_LAUNCH_EXPAND(4); break;
+        case 2: SCN_LAUNCH_EXPAND(2); break;
+        default: SCN_LAUNCH_EXPAND(1);
+      }
+#undef SCN_LAUNCH_EXPAND
       SCN_CHECK_LAUNCH();
       return 0;
     }
