@@ -3228,13 +3228,29 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
 }
 
 // slots of the deterministic workspace = workgroups along the pair dimension of the kernel scn_conv_dweight picks
+// pairs of one list per k_dw_tile workgroup: enough workgroups per (k, plane block) to fill the chip, few enough that the
+// float atomics of the partial sums (one CIB x COB tile per workgroup) stay far below the ~1.3 TB/s atomic rate.  The
+// longest list (the centre offset: one pair per site) gets ~2400 pairs per workgroup, an average one about half of that.
+// (Every list is cut into the same NUMBER of slices, whatever its length.)  One list only (NiN: the identity list): the slices
+// of 26 other lists are missing, so the slices get shorter until ~2048 workgroups have work.
+static int dw_pairs_per_wg(int K, int64_t stride, int Ci, int Co) {
+  int per = (int)(((stride + g_dw_slices - 1) / g_dw_slices + 63) / 64 * 64);
+  if (per < 2048) per = 2048;
+  if (per > 16384) per = 16384;
+  if (K == 1) {
+    const int64_t cb = (Ci % 64 == 0 && Co % 64 == 0) ? (int64_t)(Ci / 64) * (Co / 64) : (int64_t)(Ci / 32) * (Co / 32);
+    int64_t p2 = (stride * cb / 2048 + 63) / 64 * 64;
+    if (p2 < 512) p2 = 512;
+    if (p2 < per) per = (int)p2;
+  }
+  return per;
+}
+
 static int64_t dw_slots(int K, int64_t stride, int64_t n_dout, int Ci, int Co, bool has_bases, int64_t n_in) {
   const bool huge = n_in * Ci * 4 >= ((int64_t)1 << 32) || n_dout * Co * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
                     n_dout >= (1 << 24) || stride >= (1 << 28);
   if (Ci % 32 == 0 && Co % 32 == 0 && !huge) {
-    int per = (int)(((stride + g_dw_slices - 1) / g_dw_slices + 63) / 64 * 64);
-    if (per < 2048) per = 2048;
-    if (per > 16384) per = 16384;
+    const int per = dw_pairs_per_wg(K, stride, Ci, Co);
     return (stride + per - 1) / per;
   }
   if (Ci >= 1 && Ci <= 4 && has_bases && n_dout > 0) {
@@ -3290,12 +3306,7 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
               "scn_conv_dweight: column slices (ld_in / ld_dout) need planes that are multiples of 32 and < 4 GiB operands");
   if (Ci % 32 == 0 && Co % 32 == 0 && !huge) {
     const unsigned in_bytes = (unsigned)((n_in - 1) * ld_in * 4 + Ci * 4), do_bytes = (unsigned)((n_dout - 1) * ld_dout * 4 + Co * 4);
-    // slices per list: enough workgroups per (k, plane block) to fill the chip, few enough that the float atomics of
-    // the partial sums (one CIB x COB tile per workgroup) stay far below the ~1.3 TB/s atomic rate.  The longest list
-    // (the centre offset: one pair per site) gets ~2400 pairs per workgroup, an average one about half of that.
-    int per = (int)(((stride + g_dw_slices - 1) / g_dw_slices + 63) / 64 * 64);
-    if (per < 2048) per = 2048;
-    if (per > 16384) per = 16384;
+    const int per = dw_pairs_per_wg(K, stride, Ci, Co);  // slices per list
     const int gx = (int)((stride + per - 1) / per);
     if (Ci % 64 == 0 && Co % 64 == 0) {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 64) * (Co / 64));
