@@ -2021,7 +2021,10 @@ __device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], con
 // NB (round 3 experiment, tuning key 14): a wave owns NB consecutive blocks of 32 pairs and multiplies them with the SAME weight
 // fragments (with one block per wave a launch reads C_i x 64 weights, 16-32 KB from L2, for every 32 gathered rows, 8-16 KB
 // from HBM).  NB = 2 (240 VGPRs, two waves per SIMD) measures the same as NB = 1, NB = 4 (436 VGPRs) 20 % slower: the
-// weight traffic is not the limit.  NB = 1 stays.
+// weight traffic is not the limit.  NB = 1 stays.  Neither are cross-XCD re-reads of the input: giving the ncb plane blocks of
+// a pair block to ONE XCD back to back (they gather the same rows) changed no launch by more than 1.5 %.  What the launch
+// by launch times say instead: a wave is a chain of dependent latencies (pair indices -> rows -> MFMAs -> residual rows ->
+// stores, ~5 us for 1.8 us of MFMAs at C_i = 64) and three waves per SIMD do not cover it.
 template <int NB>
 __global__ void __launch_bounds__(64)
     k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
