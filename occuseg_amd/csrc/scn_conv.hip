@@ -2024,7 +2024,8 @@ __device__ __forceinline__ void fill_src_table(int (*src)[SCN_TILE_GRANULE], con
 // weight traffic is not the limit.  NB = 1 stays.  Neither are cross-XCD re-reads of the input: giving the ncb plane blocks of
 // a pair block to ONE XCD back to back (they gather the same rows) changed no launch by more than 1.5 %.  What the launch
 // by launch times say instead: a wave is a chain of dependent latencies (pair indices -> rows -> MFMAs -> residual rows ->
-// stores, ~5 us for 1.8 us of MFMAs at C_i = 64) and three waves per SIMD do not cover it.
+// stores, ~5 us for 1.8 us of MFMAs at C_i = 64) and three waves per SIMD do not cover it; 16-plane chunks (120 VGPRs, four
+// waves per SIMD) bought 3 % (1.818 -> 1.768 ms per step over the 20 launches) and were not kept either.
 template <int NB>
 __global__ void __launch_bounds__(64)
     k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
