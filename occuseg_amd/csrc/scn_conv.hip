@@ -2156,6 +2156,71 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// ------------------------------------------------ the stem on the matrix cores ---
+// C_i <= 4 (the 3 -> m stem over 27 offsets): for a granule of 32 output rows the gathered inputs ARE a dense
+// [32 x K C_i] matrix (zero where a neighbour is absent) and the layer is one small GEMM with W as [K C_i x C_o]:
+//   out[32 x C_o] = A[32 x 81] . W[81 x C_o]          (k_conv_generic did it with scalar FMAs: 11 TFLOP/s, 0.26 ms for 600k sites)
+// Four waves per workgroup: wave w owns the 16-row block w / 2 and two 16-plane blocks; its weight fragments (21 steps of
+// v_mfma_f32_16x16x4_f32 x 2 blocks = 42 registers) stay in registers while the workgroup walks granules g, g + gridDim.x, ...
+// The inverse table src[k][row] of the granule is built as in k_conv_generic, the A tile goes through LDS (row stride = 2
+// mod 32 floats: the 32 lanes of a half wave, (row li, step column lq), read 32 different banks).
+template <int CI>
+__global__ void __launch_bounds__(256)
+    k_conv_stem(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ W, const float *__restrict__ bias,
+                const int2 *__restrict__ rules, const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
+                int64_t n_out, int n_gran, int Co) {
+  constexpr int M = SCN_TILE_GRANULE;
+  constexpr int NS = (KMAX * CI + 3) / 4;  // MFMA steps over the reduction (K C_i padded to a multiple of 4)
+  constexpr int AS = (NS * 4 + 31) / 32 * 32 + 2;
+  __shared__ int src[KMAX][M];
+  __shared__ float a[M * AS];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int cb = blockIdx.y * 64;
+  const int rb = w >> 1, q0 = (w & 1) * 2;
+  const int kk_end = K * CI;
+  bool qlive[2];
+  float wf[NS][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    qlive[q] = cb + 16 * (q0 + q) < Co;  // (C_o is a multiple of 16)
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int kk = 4 * s_ + lq;  // = k C_i + c: W is [K][C_i][C_o]
+      wf[s_][q] = (qlive[q] && kk < kk_end) ? W[(int64_t)kk * Co + cb + 16 * (q0 + q) + li] : 0.f;
+    }
+  }
+  for (int g = blockIdx.x; g < n_gran; g += gridDim.x) {
+    const int64_t o0 = (int64_t)g * M;
+    __syncthreads();  // the previous granule is done with src[] and a[]
+    fill_src_table(src, rules, bases, K, stride, in_col, n_gran, g, o0);
+    for (int i = tid; i < KMAX * M; i += 256) {  // (offset k, row r): the C_i inputs of the neighbour, or zeros
+      const int k = i / M, r = i % M;
+      const int sidx = k < K ? src[k][r] : -1;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) a[r * AS + k * CI + c] = sidx >= 0 ? in[(int64_t)sidx * CI + c] : 0.f;
+    }
+    for (int i = tid; i < (NS * 4 - KMAX * CI) * M; i += 256) a[(i % M) * AS + KMAX * CI + i / M] = 0.f;
+    __syncthreads();
+    floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const float bv = a[(rb * 16 + li) * AS + 4 * s_ + lq];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s_][q], bv, acc[q], 0, 0, 0);
+    }
+    // D[i = plane][j = row]: lane (li, lq) holds planes 16 q + 4 lq .. + 3 of row li
+    const int64_t row = o0 + rb * 16 + li;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (qlive[q] && row < n_out) {
+        floatx4 v = acc[q];
+        if (bias) v += *(const floatx4 *)(bias + cb + 16 * (q0 + q) + 4 * lq);
+        *(floatx4 *)(out + row * Co + cb + 16 * (q0 + q) + 4 * lq) = v;
+      }
+  }
+}
+
 // generic fallback (any Ci, Co; scalar FMA; used by the 3 -> m stem): 32 output rows x 64 planes per
 // block.  The tile's segments of all K lists are first inverted into an LDS table src[k][row] (one
 // barrier), then thread (row, 8 planes) walks the offsets on its own: no per-offset barrier, the
@@ -2769,6 +2834,7 @@ SCN_KNOB g_dw_direct = 0;       // tuning key 12: 1 = k_dw_direct (no LDS stagin
                                 // step is 1.8 ms SLOWER with it (50.3 against 48.4 ms, tools/ab_step.py tune12=0,1): off
 SCN_KNOB g_conv_expand_nb = 1;  // tuning key 14: blocks of 32 pairs per wave of k_conv_expand (1, 2 or 4).  Measured (round 3, 20 launches
                                 // per step): 1.81 / 1.83 / 2.21 ms -- the weight re-reads are not what bounds the kernel
+SCN_KNOB g_conv_stem_mfma = 1;  // tuning key 15: 0 = the C_i <= 4 stem runs k_conv_generic (scalar FMAs) instead of k_conv_stem (A/B)
 SCN_KNOB g_conv_gtab = 1;       // tuning key 13: 0 = k_conv_tile4 keeps its pass table in LDS (A/B)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
@@ -3066,6 +3132,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 12) { g_dw_direct = value; return 0; }
   if (key == 13) { g_conv_gtab = value; return 0; }
   if (key == 14) { g_conv_expand_nb = value; return 0; }
+  if (key == 15) { g_conv_stem_mfma = value; return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
@@ -3220,6 +3287,17 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   dim3 grid((unsigned)(n_gran < 2048 ? n_gran : 2048), (unsigned)((Co + 63) / 64));  // persistent: weights staged once
+  if (g_conv_stem_mfma && Ci <= 4 && Co % 16 == 0 && !w_transposed && !w_reverse && residual == nullptr && colstats.out == nullptr) {
+    const int2 *r2 = (const int2 *)rules;
+    switch (Ci) {  // the stem as a GEMM on the matrix cores (k_conv_stem)
+      case 1: k_conv_stem<1><<<grid, 256, 0, stream>>>(in, out, W, bias, r2, bases, K, stride, in_col, n_out, n_gran, Co); break;
+      case 2: k_conv_stem<2><<<grid, 256, 0, stream>>>(in, out, W, bias, r2, bases, K, stride, in_col, n_out, n_gran, Co); break;
+      case 3: k_conv_stem<3><<<grid, 256, 0, stream>>>(in, out, W, bias, r2, bases, K, stride, in_col, n_out, n_gran, Co); break;
+      default: k_conv_stem<4><<<grid, 256, 0, stream>>>(in, out, W, bias, r2, bases, K, stride, in_col, n_out, n_gran, Co);
+    }
+    SCN_CHECK_LAUNCH();
+    return 0;
+  }
   const size_t wbytes = (size_t)K * Ci * 64 * 4;
   if (wbytes <= 40 * 1024)
     k_conv_generic<true><<<grid, 256, wbytes, stream>>>(in, out, W, bias, residual, colstats, (const int2 *)rules, bases, K, stride,
