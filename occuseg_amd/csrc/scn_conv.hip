@@ -2772,6 +2772,76 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// dW of the stem on the matrix cores: with the gathered inputs of a granule as the dense tile A[32 x K C_i] (k_conv_stem),
+//   dW[K C_i x C_o] += A^T[K C_i x 32] . dOut[32 x C_o]
+// is 8 steps of v_mfma_f32_16x16x4_f32 per (16 reduction rows of dW, 16 planes) block.  Wave w owns the planes 16 w .. 16 w + 15
+// and all six 16-row blocks of dW (96 >= K C_i rows): 24 accumulator registers that live over all granules of the
+// persistent workgroup; every (row of dW, plane) is owned by ONE lane, so the end is one float atomic (or one workspace
+// slot) per element and workgroup, no reduction across waves.  k_dw_rows did the same sums with v_readlane + scalar FMAs
+// (0.44 ms for 600k sites, 7 TFLOP/s).
+template <int CI>
+__global__ void __launch_bounds__(256)
+    k_dw_stem(const float *__restrict__ in, const float *__restrict__ dout, DwOut dwo, const int2 *__restrict__ rules,
+              const int32_t *__restrict__ bases, int K, int64_t stride, int in_col, int n_gran, int64_t n_dout, int Co) {
+  constexpr int M = SCN_TILE_GRANULE;
+  constexpr int NM = (KMAX * CI + 15) / 16;  // 16-row blocks of dW
+  // row stride of the A tile = 18 mod 32: the MFMA reads (rows lq, lq + 1 x 16 columns per half wave) hit 30 different banks,
+  // the gather's writes (32 rows, one column) 16
+  constexpr int AS = (NM * 16 + 31) / 32 * 32 + 18;
+  constexpr int DS = 80;  // row stride of the dOut tile (16 mod 32: rows lq and lq + 1 of a half wave on different banks)
+  __shared__ int src[KMAX][M];
+  __shared__ float a[M * AS];
+  __shared__ __attribute__((aligned(16))) float d[M * DS];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int cb = blockIdx.y * 64;
+  floatx4 acc[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int g = blockIdx.x; g < n_gran; g += gridDim.x) {
+    const int64_t o0 = (int64_t)g * M;
+    __syncthreads();  // the previous granule is done with src[], a[] and d[]
+    // the dOut rows of the granule, coalesced (requested before the dependent chain bases -> pairs -> inputs below)
+    floatx4 dv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = (tid + 256 * u) * 4, r = e / 64, c = e % 64;
+      dv[u] = (o0 + r < n_dout && cb + c < Co) ? *(const floatx4 *)(dout + (o0 + r) * Co + cb + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    fill_src_table(src, rules, bases, K, stride, in_col, n_gran, g, o0);
+    for (int i = tid; i < KMAX * M; i += 256) {
+      const int k = i / M, r = i % M;
+      const int sidx = k < K ? src[k][r] : -1;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) a[r * AS + k * CI + c] = sidx >= 0 ? in[(int64_t)sidx * CI + c] : 0.f;
+    }
+    for (int i = tid; i < (NM * 16 - KMAX * CI) * M; i += 256) a[(i % M) * AS + KMAX * CI + i / M] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = (tid + 256 * u) * 4, r = e / 64, c = e % 64;
+      *(floatx4 *)(d + r * DS + c) = dv[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < M / 4; ++t) {
+      const float bv = d[(4 * t + lq) * DS + 16 * w + li];  // B[k = row][j = plane]
+#pragma unroll
+      for (int m = 0; m < NM; ++m)  // A[i = row of dW][k = row]
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(4 * t + lq) * AS + 16 * m + li], bv, acc[m], 0, 0, 0);
+    }
+  }
+  // D[i = row of dW][j = plane]: lane (li, lq) holds rows 16 m + 4 lq .. + 3 of plane 16 w + li
+  const int co = cb + 16 * w + li;
+  if (co < Co)
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = 16 * m + 4 * lq + e;
+        if (kk < K * CI) dwo.add(blockIdx.x, (int64_t)kk * Co + co, acc[m][e]);
+      }
+}
+
 // generic dW (any Ci, Co): block = (pair chunk, k); threads stride over (ci, co)
 __global__ void __launch_bounds__(256)
     k_dw_generic(const float *__restrict__ in, const float *__restrict__ dout, DwOut dwo,
@@ -3420,6 +3490,17 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
   if (Ci >= 1 && Ci <= 4 && bases != nullptr && n_dout > 0) {
     const int n_gran = (int)((n_dout + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
     dim3 grid((unsigned)(n_gran < 1024 ? n_gran : 1024), (unsigned)((Co + 63) / 64));
+    if (g_conv_stem_mfma && Co % 16 == 0) {  // on the matrix cores (k_dw_stem)
+      const int2 *r2 = (const int2 *)rules;
+      switch (Ci) {
+        case 1: k_dw_stem<1><<<grid, 256, 0, stream>>>(in, dout, dwo, r2, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+        case 2: k_dw_stem<2><<<grid, 256, 0, stream>>>(in, dout, dwo, r2, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+        case 3: k_dw_stem<3><<<grid, 256, 0, stream>>>(in, dout, dwo, r2, bases, K, stride, in_col, n_gran, n_dout, Co); break;
+        default: k_dw_stem<4><<<grid, 256, 0, stream>>>(in, dout, dwo, r2, bases, K, stride, in_col, n_gran, n_dout, Co);
+      }
+      SCN_CHECK_LAUNCH();
+      return finish();
+    }
     switch (Ci) {
       case 1: k_dw_rows<1><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
       case 2: k_dw_rows<2><<<grid, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, bases, K, stride, in_col, n_gran, n_dout, Co); break;
