@@ -23,8 +23,10 @@ def _setup(gpu, seed=0, n=3000, batch=2, extent=24):
     return m, size, grid, table, coords
 
 
-# (Ci, Co): MFMA tile path (multiples of 16, NW = 4/3/2/1), Ci chunking (>64), generic path (3, 5, 20)
-PLANES = [(16, 16), (32, 64), (64, 64), (64, 48), (48, 32), (128, 64), (80, 16), (3, 32), (5, 7), (20, 24)]
+# (Ci, Co): MFMA tile path (multiples of 16, NW = 4/3/2/1), Ci chunking (>64), generic path (5, 20; 3 -> 8), the stem on the
+# matrix cores (k_conv_stem / k_dw_stem: Ci <= 4, Co % 16 == 0; one, two and one-and-a-half 64-plane blocks)
+PLANES = [(16, 16), (32, 64), (64, 64), (64, 48), (48, 32), (128, 64), (80, 16), (3, 32), (5, 7), (20, 24),
+          (1, 16), (2, 96), (3, 64), (4, 80), (4, 128), (3, 8)]
 
 
 @pytest.mark.parametrize("ci,co", PLANES)
@@ -57,7 +59,7 @@ def test_submanifold_fwd_bwd(gpu, ci, co):
 
 # the last two run on a grid large enough (>= 512 output tiles on both scales) for the two-wave kernel k_conv_tile4
 @pytest.mark.parametrize("ci,co,big", [(16, 32, 0), (64, 128, 0), (96, 64, 0), (32, 48, 0), (3, 8, 0), (128, 192, 0),
-                                       (64, 64, 1), (64, 128, 1)])
+                                       (3, 32, 0), (4, 96, 0), (64, 64, 1), (64, 128, 1)])
 def test_conv_deconv_fwd_bwd(gpu, ci, co, big):
     from occuseg_amd import SCN
     from oracle import arith as A, rules as R
