@@ -744,6 +744,8 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
         R = rb.total_pairs
         code = lib.scn_conv_plan(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
         name = _CONV_KERNELS.get(code // 100, "conv") + ("_split" if code % 100 > 1 else "")
+        if code // 100 == 0 and Ci <= 4 and Co % 16 == 0 and not w_transposed and residual is None:
+            name = "conv_stem"  # k_conv_stem: the narrow-input layer as a GEMM on the matrix cores
         _prof_end(ev, name, 2.0 * R * Ci * Co, 4.0 * (R * Ci + n_out * Co) + 8.0 * R + 4.0 * K * Ci * Co,
                   (K, n_out, Ci, Co, int(w_transposed), in_col))
 
@@ -890,7 +892,8 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
                                        ptr(rb.bases.get(out_col)), K, rb.stride, in_col, out_col, inp.size(0),
                                        d_out.size(0), Ci, Co, 0, ld_dout, ptr(ws), wsb, stream()))
             R = rb.total_pairs
-            _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else "dw_narrow", 2.0 * R * Ci * Co,
+            _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else
+                      ("dw_stem" if Ci <= 4 and Co % 16 == 0 and rb.bases.get(out_col) is not None else "dw_narrow"), 2.0 * R * Ci * Co,
                       4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
         if side is not None:
             _dw_side_end(side, d_out)

@@ -9,7 +9,7 @@ import sys
 d = sys.argv[1]
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-key = lambda n: next((k for k in ("k_conv_tile4", "k_conv_tile2", "k_conv_expand", "k_dw_tile", "k_bn_", "k_conv_generic", "k_dw_rows") if k in n), None)
+key = lambda n: next((k for k in ("k_conv_tile4", "k_conv_tile2", "k_conv_expand", "k_dw_tile", "k_bn_", "k_conv_generic", "k_conv_stem", "k_dw_stem", "k_dw_rows") if k in n), None)
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = key(r["Kernel_Name"])

@@ -14,7 +14,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KERNELS = (("k_conv_tile4", "conv_tile4"), ("k_conv_tile2", "conv_tile2"), ("k_conv_expand", "conv_expand"),
-           ("k_conv_tile<", "conv_tile_fallback"), ("k_conv_generic", "conv_generic"), ("k_dw_tile", "dw_tile"),
+           ("k_conv_tile<", "conv_tile_fallback"), ("k_conv_generic", "conv_generic"), ("k_conv_stem", "conv_stem"), ("k_dw_stem", "dw_stem"), ("k_dw_tile", "dw_tile"),
            ("k_bn_", "bn"), ("k_dw_narrow", "dw_narrow"))
 
 

@@ -13,7 +13,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
 iv.sort()
 mm = [(s, e, n) for s, e, n in iv if "k_conv_tile4" in n or "k_dw_tile" in n or "k_conv_expand" in n or "k_conv_tile2" in n]
 # steps: split the matrix launches at the k_conv_generic (stem forward) launches
-stems = [s for s, e, n in iv if "k_conv_generic" in n]
+stems = [s for s, e, n in iv if "k_conv_generic" in n or "k_conv_stem" in n]
 hist = collections.Counter()
 for s, e, n in iv:
     if "k_sub_probe" in n or "k_rules_fill" in n or "k_str_fill" in n or "k_hash_insert" in n:
