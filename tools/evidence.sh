@@ -52,6 +52,10 @@ GUARD_SYNC=stream timeout 600 python3 -X faulthandler tools/guard_run.py 2> $E/g
 GUARD_POISON=0xEF timeout 600 python3 -X faulthandler tools/guard_run.py 2> $E/guard_poison.err | grep guard_run > $E/guard_poison.txt
 python3 tools/check_scratch.py > $E/check_scratch.txt 2>&1
 bash tools/scratch_fault_repro.sh 4 > $E/scratch_fault_repro.txt 2>&1
+# the default bench line once more, now that the traffic of THESE kernel sources exists (bench.py refuses a traffic file
+# measured on other sources): this is the line that goes to profiles/rNN_bench.json
+cp $E/traffic.json profiles/r03_traffic.json
+python3 bench.py > $E/bench_final.json 2>> $E/bench.err
 # keep the merge small: raw traces stay on the box
 find $E -name "*.db" -delete
 find $E -name "*kernel_trace.csv" -size +2M -delete
