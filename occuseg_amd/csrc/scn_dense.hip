@@ -316,6 +316,8 @@ __global__ void __launch_bounds__(256)
   const bool live = c0 < C;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   if (live)
+    // (four rows in flight per thread: one dependent L2 round trip per row made a 1,774-row launch 29 us)
+#pragma unroll 4
     for (int64_t r = slot; r < N; r += 64) {
       const float4 v = *(const float4 *)(x + r * C + c0);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
@@ -344,6 +346,7 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   if (!live) return;
   const float4 w = *(const float4 *)&wb[0][cgl * 4], bb = *(const float4 *)&wb[1][cgl * 4];
+#pragma unroll 4
   for (int64_t r = slot; r < N; r += 64) {
     const float4 v = *(const float4 *)(x + r * C + c0);
     float4 o;
@@ -382,6 +385,8 @@ __global__ void __launch_bounds__(256)
   };
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   if (live)
+    // (four rows in flight per thread: one dependent L2 round trip per row made a 1,774-row launch 29 us)
+#pragma unroll 4
     for (int64_t r = slot; r < N; r += 64) {
       const float4 xv = *(const float4 *)(x + r * C + c0);
       const float4 d = masked(xv, *(const float4 *)(d_out + r * C + c0));
@@ -407,6 +412,7 @@ __global__ void __launch_bounds__(256)
   if (!live) return;
   const float4 gm = *(const float4 *)&coef[0][cgl * 4], kk = *(const float4 *)&coef[1][cgl * 4],
                sc = *(const float4 *)&coef[2][cgl * 4];
+#pragma unroll 4
   for (int64_t r = slot; r < N; r += 64) {
     const float4 xv = *(const float4 *)(x + r * C + c0);
     const float4 d = masked(xv, *(const float4 *)(d_out + r * C + c0));
