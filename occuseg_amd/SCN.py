@@ -806,19 +806,26 @@ def _dw_side_begin(*tensors):
     side = st[0]
     side.wait_stream(torch.cuda.current_stream(dev))  # dOut, the zeroed dW, the saved input: produced on the main stream
     for t in tensors:
-        t.record_stream(side)  # (the caching allocator must not hand their memory out before the side stream is done)
+        if t is not None:
+            t.record_stream(side)  # (the caching allocator must not hand their memory out before the side stream is done)
     held = st[2]
     while held and held[0][0].query():  # kernels that have finished no longer pin their dOut
         held.pop(0)
     return side
 
 
-def _dw_side_end(side, d_out):
+def _dw_side_end(side, d_out, rb=None):
+    """`rb`: the rulebook the kernel walks.  It is held like dOut: the LAST reference to a batch's Metadata_3 -- hence to
+    its rulebooks -- is dropped INSIDE the backward pass (InputLayer's backward clears it), before the main stream has
+    joined the side stream; with the rulebooks allocated on the prefetch stream (SCN.prefetch_input) their memory went
+    back to that stream's pool as soon as the MAIN stream had passed, and the next batch's rule build overwrote the pair
+    lists under the last dWeight kernels (round 3: GPU memory access faults in 5 of 30 runs of 42 steps on one box, first
+    seen under rocprofv3 only; never with the prefetch or the side stream off)."""
     st = _DW_STATE[side.device.index]
     ev = torch.cuda.Event()
     ev.record(side)
     st[1] = ev
-    st[2].append((ev, d_out))
+    st[2].append((ev, d_out, rb))
 
 
 def dw_join(device=None):
@@ -884,7 +891,8 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
     if not DW_FIRST:
         d_input()
     if d_weight is not None and d_weight.numel():
-        side = _dw_side_begin(inp, d_out, d_weight)
+        # (everything the kernel reads or writes: the rulebook's tensors too -- see _dw_side_end)
+        side = _dw_side_begin(inp, d_out, d_weight, rb.rules, rb.counts, rb.bases.get(out_col))
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             ev = _prof_begin()
             ws, wsb = _dw_workspace(rb, out_col, K, inp.size(0), d_out.size(0), Ci, Co, inp.device)
@@ -896,7 +904,7 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
                       ("dw_stem" if Ci <= 4 and Co % 16 == 0 and rb.bases.get(out_col) is not None else "dw_narrow"), 2.0 * R * Ci * Co,
                       4.0 * R * (Ci + Co) + 8.0 * R + 4.0 * K * Ci * Co, (K, inp.size(0), Ci, Co, 0, in_col))
         if side is not None:
-            _dw_side_end(side, d_out)
+            _dw_side_end(side, d_out, rb)
     if DW_FIRST:
         d_input()
     if d_bias is not None and d_bias.numel():
@@ -1146,7 +1154,7 @@ def _identity_rulebook(n, device):
         rb.bases[0] = rb.bases[1] = bases.reshape(1, n_gran + 1).contiguous()
         rb.total_pairs = n
         rb.unique_col = 2
-        while len(_IDENTITY_RB) >= 8:
+        while len(_IDENTITY_RB) >= 64:  # (two batches x five levels of the m64 UNet already are ten sizes)
             _IDENTITY_RB.pop(next(iter(_IDENTITY_RB)))
     _IDENTITY_RB[key] = rb
     return rb
