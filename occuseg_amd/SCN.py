@@ -849,6 +849,9 @@ def _dw_finish(idx):
     del st[2][:]
 
 
+DW_SIDE_TEST_DELAY_CYCLES = 0  # tests only: a spin kernel in front of every side-stream dWeight kernel, so that the side stream
+                               # lags the main stream by milliseconds and anything the kernel reads that is not pinned is gone
+                               # by the time it runs (tests/test_gpu_memory_safety.py)
 DETERMINISTIC_DW = False  # True: parameter gradients bitwise reproducible run to run (scn_conv_dweight's workspace: partial
                           # sums added in a fixed order instead of float atomics); costs a memset + a reduction per launch
 
@@ -894,6 +897,8 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
         # (everything the kernel reads or writes: the rulebook's tensors too -- see _dw_side_end)
         side = _dw_side_begin(inp, d_out, d_weight, rb.rules, rb.counts, rb.bases.get(out_col))
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if side is not None and DW_SIDE_TEST_DELAY_CYCLES:
+                torch.cuda._sleep(int(DW_SIDE_TEST_DELAY_CYCLES))
             ev = _prof_begin()
             ws, wsb = _dw_workspace(rb, out_col, K, inp.size(0), d_out.size(0), Ci, Co, inp.device)
             check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts),

@@ -14,8 +14,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("env", [{"GUARD_MODE": "end"}, {"GUARD_MODE": "start"},
                                  {"GUARD_MODE": "end", "GUARD_POISON": "0xEF"},
-                                 {"GUARD_MODE": "end", "GUARD_SYNC": "stream"}],
-                         ids=["past_the_end", "before_the_start", "poisoned_fresh_memory", "per_stream_frees"])
+                                 {"GUARD_MODE": "end", "GUARD_SYNC": "stream"},
+                                 # the dWeight side stream made to lag by ~1 ms per kernel: whatever its kernels read must
+                                 # be pinned until they ran (round 3: the rulebooks were not -- the last reference to a
+                                 # batch's Metadata goes inside the backward pass, before the streams are joined)
+                                 {"GUARD_MODE": "end", "GUARD_SYNC": "stream", "GUARD_DW_DELAY": "2000000"}],
+                         ids=["past_the_end", "before_the_start", "poisoned_fresh_memory", "per_stream_frees",
+                              "lagging_dweight_stream"])
 def test_train_steps_touch_no_byte_outside_their_tensors(env):
     e = dict(os.environ)
     e.update(env)

@@ -47,6 +47,9 @@ def main():
             if self.numel() and glib.guard_record(self.untyped_storage().data_ptr(), stream.cuda_stream):
                 raise RuntimeError("record_stream: tensor not from the guard allocator")
         torch.Tensor.record_stream = record_stream
+    if os.environ.get("GUARD_DW_DELAY"):  # (tests: the dWeight side stream lags the main stream, see SCN.DW_SIDE_TEST_DELAY_CYCLES)
+        from occuseg_amd import SCN
+        SCN.DW_SIDE_TEST_DELAY_CYCLES = int(os.environ["GUARD_DW_DELAY"])
     import bench
     sys.argv = [os.path.join(ROOT, "bench.py")] + (sys.argv[1:] or ["--no-cpu-baseline", "--steps", "2", "--warmup", "2"])
     bench.main()
