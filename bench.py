@@ -274,6 +274,8 @@ def main():
             trace("prefetch done")
         return out
 
+    if args.no_dw_side_stream:  # (the warm-up steps too)
+        SCN.DW_SIDE_STREAM = False
     for _ in range(args.warmup):
         step()
 

@@ -431,12 +431,12 @@ struct GridTemp {
   size_t keys_in, idx_in, blk_cnt, info, sort, total, sort_bytes;
 };
 // The 48-bit key sort.  rocPRIM's default Onesweep configuration for (u64, u32) on gfx950 compiles to a kernel with 80
-// bytes of SCRATCH (private memory) per lane -- the only kernel of this library that has any.  A queue's first dispatch
-// with scratch makes the runtime (re)size that queue's scratch buffer; with the rule build on its own high-priority
-// stream (SCN.prefetch_input) beside a deep main-stream queue, runs under rocprofv3 --kernel-trace died with "Memory
-// access fault by GPU" on some boxes (never without the profiler, never with the build on the main stream, never with
-// serialized launches; tools/guard_run.py finds no access outside a tensor).  8-bit digits, 256 x 12 keys per block: no
-// scratch, six passes over the 48 bits.  SCN_SORT_ROCPRIM_DEFAULT=1 selects rocPRIM's default again (A/B).
+// bytes of SCRATCH (private memory) per lane -- the only kernel of this library that had any.  8-bit digits, 256 x 12 keys
+// per block: no scratch, six passes over the 48 bits; the rule build of an m64 batch alone takes 2.5 instead of 2.3 ms
+// (tools/check_scratch.py keeps the library scratch-free).  History: for a day of round 3 this looked like the cure of GPU memory access faults seen under
+// rocprofv3 (default sort 4 of 4 runs, this one 0 of 8 on the same box); the faults were a lifetime race of the side-stream
+// dWeight kernels (SCN.py, _dw_side_end) and the sort's different workspace size merely moved which freed block the next
+// rule build overwrote first.  SCN_SORT_ROCPRIM_DEFAULT=1 selects rocPRIM's default (A/B).
 using SortNoScratch = rocprim::radix_sort_config<
     rocprim::default_config, rocprim::default_config,
     rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<256, 12>, 8>>;
