@@ -123,19 +123,30 @@ def test_dweight_side_stream_is_race_free(gpu):
     plain = [p.grad.clone() for p in net.parameters()]
     bucket = dp.FlatGradBucket(net.parameters())
     before = SCN.DW_SIDE_STREAM
+    input_layer = next(m for m in net.modules() if isinstance(m, scn.InputLayer))
     try:
-        for side in (True, False):
-            SCN.DW_SIDE_STREAM = side
-            for it in range(20 if side else 3):
+        # "lag": the side stream made to trail the main stream by a spin kernel in front of every dWeight kernel, and the
+        # next pass's rulebooks prefetched on a third stream in between (they recycle the memory of the rulebooks the
+        # lagging kernels still read unless those are pinned: round 3's race)
+        for side in (True, "lag", False):
+            SCN.DW_SIDE_STREAM = bool(side)
+            SCN.DW_SIDE_TEST_DELAY_CYCLES = 300000 if side == "lag" else 0
+            for it in range({True: 20, "lag": 6, False: 3}[side]):
                 bucket.zero()
                 net(batch).sum().backward()
+                if side == "lag":
+                    input_layer.prefetch(batch, wait_for_current_stream=False)
                 net(batch).sum().backward()
                 bucket.all_reduce_mean()
+                if side == "lag":
+                    input_layer.prefetch(batch, wait_for_current_stream=False)
                 for (name, p), ref in zip(net.named_parameters(), plain):
                     err = (p.grad - ref).abs().max().item()
                     assert err <= 1e-4 * ref.abs().max().item() + 1e-30, (side, it, name, err)
     finally:
         SCN.DW_SIDE_STREAM = before
+        SCN.DW_SIDE_TEST_DELAY_CYCLES = 0
+        SCN._PREFETCHED.clear()
         bucket.close()
 
 
