@@ -41,6 +41,21 @@ with torch.no_grad():
     md.inputLayer(torch.tensor([4096] * 3), inp[0], 0, 4, dev)
     n0 = md.nActive[md.inputSpatialSize]
 res["cfg2_m32_fwd_1scene"] = {"active_voxels": n0, "ms": ms, "voxels_per_s": n0 / ms * 1e3}
+# the same as a serving loop would run it: the NEXT scene's voxel hash and rulebooks built on a side stream while this scene's
+# kernels run (InputLayer.prefetch; here the next scene is the same tensor, built afresh every time)
+input_layer = next(m for m in net.modules() if isinstance(m, scn.InputLayer))
+
+
+def fwd_pipelined():
+    out = net(inp)
+    input_layer.prefetch(inp, wait_for_current_stream=False)
+    return out
+
+
+with torch.no_grad():
+    ms_p = timeit(fwd_pipelined, 10, 3)
+SCN._PREFETCHED.clear()
+res["cfg2_m32_fwd_1scene_rules_prefetched"] = {"active_voxels": n0, "ms": ms_p, "voxels_per_s": n0 / ms_p * 1e3}
 
 # cfg5
 f3 = torch.tensor([3, 3, 3])
