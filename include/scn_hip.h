@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 3
+#define SCN_ABI_VERSION 4
 #define SCN_TILE_GRANULE 32 /* output-row granule of the tile-base tables */
+#define SCN_SK_STATE_BYTES 65536 /* scn_conv_forward's sk_state */
 
 int scn_abi_version(void);
 const char *scn_last_error(void);
@@ -120,10 +121,13 @@ int scn_strided_rules(const int32_t *fine_coords, int64_t N, const int32_t *coar
 int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
                    int out_col, int64_t n_out, int32_t *bases, void *stream);
 
-/* order [ceil(n_out / 128)]: a dispatch order for scn_conv_forward's tile_order from the tile-base table of the output
- * column: the tiles with fewer pairs than light_permille / 1000 of the mean go last, the others keep their place
- * (a stable partition).  At most 16384 tiles. */
-int scn_tile_order(const int32_t *bases, int K, int64_t n_out, int light_permille, int32_t *order, void *stream);
+/* passes (scn_tile_passes_bytes(n_out) bytes) = int32 [ceil(n_out / 128) + 1]: prefix sums over the 128-row output tiles of max(1, sum_k ceil(pairs_k(tile) / 32)) -- the
+ * number of 32-pair passes the big gather-mm launches (k_conv_tile4) make over a tile per 64-plane input chunk -- from the
+ * tile-base table of the output column.  scn_conv_forward's `tile_passes`: with it those launches cut their whole pass
+ * sequence into equal slices for persistent workgroups (stream-K) instead of dealing whole tiles, which the reference's
+ * chunk kernels (sparseconvnet/SCN/CUDA/Convolution.cu:1059-1152) and round 3's launch both do. */
+size_t scn_tile_passes_bytes(int64_t n_out); /* bytes of `passes`: the prefix, then one slice table per column-block count */
+int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes, void *stream);
 
 /* ------------------------------------------------------- gather-mm-scatter ---
  * out[o,:] = (bias) + sum_k sum_{pairs of list k} in[pair.in_col,:] . Wk
@@ -158,10 +162,13 @@ int scn_tile_order(const int32_t *bases, int K, int64_t n_out, int light_permill
  *   writes its result straight into the right half of the joined tensor and its backward pass reads the right half of the
  *   joined gradient in place.  ld_in: planes that are multiples of 16 (the pipelined kernels); ld_out: out_unique launches with
  *   planes % 64 == 0 only (scn_conv_plan = 5xx).  residual / colstats / bn_bwd->x stay contiguous [n_out, Co].
- *   tile_order (may be NULL): int32 [ceil(n_out / 128)], a permutation of the 128-row output tiles = the order in which
- *   the big launches (k_conv_tile4) start them.  A caller that knows the pair count of every tile (from `bases`) puts the
- *   light tiles last, so that the last round of workgroups -- the tail in which the chip runs dry -- is short.  Results do
- *   not depend on it (every tile is computed by one workgroup in a fixed summation order).
+ *   tile_passes (may be NULL): scn_tile_passes(bases, K, n_out, ..).  With it -- and with sk_state -- the big launches
+ *   (k_conv_tile4) run as 4 persistent workgroups per CU that draw equal SLICES of the launch's pass sequence; a tile cut by a
+ *   slice boundary is continued, not summed: the workgroup that holds its first passes hands the 128 x 64 partial tile on
+ *   through the workspace and the next one goes on from it, so every output element is still accumulated in (offset, chunk,
+ *   pair) order: results are bit-identical with and without it.
+ *   sk_state (may be NULL): SCN_SK_STATE_BYTES bytes of device memory that hold ZERO when the launch starts; the launch leaves
+ *   them zero.  One such block per stream (launches that may overlap need different blocks).
  *   workspace: scn_conv_workspace_bytes(...) bytes.  Launches with few output tiles (the coarse UNet levels) split their
  *   offsets over several workgroups per tile; the partial tiles go to the workspace and are added in a fixed order, so
  *   every launch is bitwise reproducible run to run (the reference scatters with float atomics,
@@ -206,10 +213,10 @@ typedef struct scn_bn_bwd_stats {
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
                      const float *bias, const float *residual, float *colstats, const scn_bn_bwd_stats *bn_bwd,
                      const int32_t *rules,
-                     const int32_t *bases, const int32_t *tile_order, const int32_t *counts,
+                     const int32_t *bases, const int32_t *tile_passes, const int32_t *counts,
                      int K, int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in,
                      int64_t n_out, int Ci, int Co, int64_t ld_in, int64_t ld_out, void *wpack, int wpack_ready,
-                     void *workspace, size_t workspace_bytes, void *stream);
+                     void *workspace, size_t workspace_bytes, void *sk_state, void *stream);
 
 /* scn_set_tuning / scn_debug_stamps (kernel-variant selection, timing-only ablation builds, cycle stamps) are NOT
  * part of this ABI: they exist only in libscn_hip_tuning.so (same sources compiled with -DSCN_TUNING), which

@@ -88,10 +88,24 @@ def _need_cuda(t, what):
 _PLANS = {}
 _PLANS_USED = {}  # spatial size -> the request list of the most recent forward pass that really ran (tools, bench)
 PREBUILD = True
-# dispatch order of the 128-row tiles of the big launches: 0 = index order; 1 = the tiles lighter than TILE_ORDER_LIGHT x the
-# mean pair count last, in index order (scn_tile_order); 2 = longest first (see Metadata_3._tile_bases)
-TILE_ORDER = int(os.environ.get("SCN_TILE_ORDER", "0"))
-TILE_ORDER_LIGHT = float(os.environ.get("SCN_TILE_ORDER_LIGHT", "0.95"))
+# stream-K for the big gather-mm launches (k_conv_tile4): every rulebook carries the pass prefix of its 128-row tiles and the
+# slice tables (scn_tile_passes); handed those and a control block, a launch whose tiles would leave a tenth or more of the last
+# round of resident workgroups empty (2.70 rounds, say) runs as persistent workgroups that are dealt whole tiles first and equal
+# slices of the remaining pass sequence at the end -- bit-identical results.  The library decides per launch (the persistent
+# loop runs ~6 % behind hardware re-dispatch: launches of 2.83 or 4.59 rounds keep one workgroup per tile; DESIGN.md section 3.3,
+# profiles/r04_ab_stream_k.txt).  False: never (A/B: tools/ab_step.py STREAM_K=0,1)
+STREAM_K = os.environ.get("SCN_STREAM_K", "1") != "0"
+_SK_STATE = {}  # (device index, stream handle) -> the zeroed control block of that stream's stream-K launches
+
+
+def _sk_state(device):
+    """SCN_SK_STATE_BYTES of zeros per (device, stream): slice counters and slab flags of a stream-K launch.  Every launch
+    leaves the block as it found it; launches on ONE stream never overlap, so they can share one."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _SK_STATE.get(key)
+    if t is None:
+        t = _SK_STATE[key] = torch.zeros(_lib.SK_STATE_BYTES, dtype=torch.uint8, device=device)
+    return t
 KEEP_NBR = False  # tests only: keep each submanifold rulebook's neighbour table (`d_global_query_result`) alive
 _COORD_DTYPES = {torch.int32: 0, torch.int64: 1, torch.float32: 2}  # scn_grid_build coords_dtype
 
@@ -117,7 +131,7 @@ class _Grid(object):
 class _RuleBook(object):
     """Device rulebook: rules int32 [K, stride, 2], counts int32 [K] (device),
     tile-base tables per output column."""
-    __slots__ = ("K", "stride", "rules", "counts", "bases", "order", "n_rows", "total_pairs", "nbr", "unique_col", "ori",
+    __slots__ = ("K", "stride", "rules", "counts", "bases", "passes", "n_rows", "total_pairs", "nbr", "unique_col", "ori",
                  "class_books")
 
     def __init__(self, K, stride, rules, counts):
@@ -126,7 +140,7 @@ class _RuleBook(object):
         self.rules = rules
         self.counts = counts
         self.bases = {}      # out_col -> int32 [K, n_gran+1]
-        self.order = {}      # out_col -> int32 [tiles of 128 rows]: dispatch order of the big launches (may be absent)
+        self.passes = {}     # out_col -> int32 [tiles of 128 rows + 1]: pass prefix of the tiles for stream-K launches (may be absent)
         self.n_rows = {}     # out_col -> number of output rows
         self.total_pairs = None
         self.nbr = None
@@ -289,7 +303,7 @@ class Metadata_3(object):
                 if t is not None:
                     yield t
         for rb in list(self.submanifoldRuleBooks.values()) + list(self.ruleBooks.values()):
-            for t in [rb.rules, rb.counts, rb.nbr, rb.ori] + list(rb.bases.values()) + list(rb.order.values()):
+            for t in [rb.rules, rb.counts, rb.nbr, rb.ori] + list(rb.bases.values()) + list(rb.passes.values()):
                 if t is not None:
                     yield t
         for sn, ori in self.normals.values():
@@ -331,19 +345,12 @@ class Metadata_3(object):
                                  ptr(bases), stream()))
         rb.bases[out_col] = bases
         rb.n_rows[out_col] = n_out
-        # Dispatch order of the 128-row tiles of the big launches (scn_conv_forward's tile_order): heavy tiles keep their
-        # place (neighbouring tiles gather overlapping rows and share an L2), the lightest TILE_ORDER_TAIL of them move to
-        # the end, lightest last.
+        # pass prefix of the 128-row tiles (scn_conv_forward's tile_passes): what a stream-K launch cuts into equal slices
         n_tiles = (n_out + 127) // 128
-        if TILE_ORDER and rb.K > 1 and 128 <= n_tiles <= 16384:
-            if TILE_ORDER == 1:  # one small kernel: stable partition, tiles lighter than TILE_ORDER_LIGHT x the mean last
-                order = torch.empty(n_tiles, dtype=torch.int32, device=bases.device)
-                check(lib.scn_tile_order(ptr(bases), rb.K, n_out, int(1000 * TILE_ORDER_LIGHT), ptr(order), stream()))
-            else:  # 2: longest first (A/B)
-                lo = torch.arange(n_tiles, device=bases.device) * 4
-                work = (bases[:, torch.clamp(lo + 4, max=n_gran)] - bases[:, lo]).sum(0)
-                order = torch.argsort(work, descending=True, stable=True).to(torch.int32).contiguous()
-            rb.order[out_col] = order
+        if rb.K > 1 and n_tiles >= 128:
+            passes = torch.empty(lib.scn_tile_passes_bytes(n_out) // 4, dtype=torch.int32, device=bases.device)
+            check(lib.scn_tile_passes(ptr(bases), rb.K, n_out, ptr(passes), stream()))
+            rb.passes[out_col] = passes
 
     def getSubmanifoldRuleBook(self, spatialSize, filterSize, dilated_rate=1, _defer=False):
         """cache key (spatialSize, filterSize) as sparseconvnet/SCN/Metadata/Metadata.cpp:504-529"""
@@ -733,9 +740,11 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None, ptr(residual), ptr(cstats),
-                               ctypes.byref(bnb) if bnb is not None else None, ptr(rb.rules), ptr(rb.bases[out_col]), ptr(rb.order.get(out_col)), ptr(rb.counts), K, rb.stride,
+                               ctypes.byref(bnb) if bnb is not None else None, ptr(rb.rules), ptr(rb.bases[out_col]),
+                               ptr(rb.passes.get(out_col)) if STREAM_K else None, ptr(rb.counts), K, rb.stride,
                                in_col, out_col, uniq,
-                               inp.size(0), n_out, Ci, Co, ld_in, ld_out, ptr(wpack), ready, ptr(ws), ws_bytes, stream()))
+                               inp.size(0), n_out, Ci, Co, ld_in, ld_out, ptr(wpack), ready, ptr(ws), ws_bytes,
+                               ptr(_sk_state(inp.device)) if STREAM_K and kind == 4 else None, stream()))
     if bn_link is not None:
         bn_link.offer(out, cstats if bnb is not None else None)
     # algorithmic work of one launch: flops = 2 R Ci Co;

@@ -29,7 +29,8 @@ SIGNATURES = {
     "scn_submanifold_rules": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_size_t, _P, c_int, c_int, _P, _P]),
     "scn_strided_rules": (c_int, [_P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "scn_tile_bases": (c_int, [_P, _P, c_int, c_int64, c_int, c_int64, _P, _P]),
-    "scn_tile_order": (c_int, [_P, c_int, c_int64, c_int, _P, _P]),
+    "scn_tile_passes_bytes": (c_size_t, [c_int64]),
+    "scn_tile_passes": (c_int, [_P, c_int, c_int64, _P, _P]),
     "scn_conv_wpack_bytes": (c_size_t, [c_int, c_int, c_int]),
     "scn_conv_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_plan": (c_int, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
@@ -39,7 +40,7 @@ SIGNATURES = {
     "scn_weight_pack_batch": (c_int, [_P, c_int, c_int64, _P]),
     "scn_conv_stats_blocks": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int,
-                                 c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P, c_int, _P, c_size_t, _P]),
+                                 c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P, c_int, _P, c_size_t, _P, _P]),
     "scn_conv_dweight_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64,
                                  c_int64, _P, c_size_t, _P]),
@@ -74,7 +75,8 @@ TUNING_SIGNATURES = {
     "scn_peak_read": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
 }
 TUNING_LIB_PATH = os.path.join(_HERE, "libscn_hip_tuning.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
+SK_STATE_BYTES = 65536  # SCN_SK_STATE_BYTES
 
 _lib = None
 

@@ -31,6 +31,16 @@ inline int fail(int code, const char *fmt, const char *a = "", long b = 0, long 
 
 constexpr int WAVE = 64;
 
+// stream-K launches of k_conv_tile4 (scn_conv.hip) and the tables scn_tile_passes builds for them (scn_rules.hip): the LAST
+// 1 + fraction rounds of SCN_SK_SLICES (tile, column block) items are cut into SCN_SK_SLICES equal slices of passes, the
+// items in front of them are dealt whole
+constexpr int SCN_SK_SLICES = 1024;
+constexpr int SCN_SK_MAX_NCB = 6;  // column blocks (C_o / 64) a table exists for
+__host__ __device__ inline int64_t scn_sk_whole_items(int64_t items) {
+  const int64_t rounds = items / SCN_SK_SLICES;
+  return rounds < 2 ? 0 : (rounds - 1) * SCN_SK_SLICES;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // 31-bit voxel key of the reference: ((z<<21)|(y<<10)|x) & 0x7FFFFFFF

@@ -752,19 +752,60 @@ __global__ void __launch_bounds__(256)
 // GT = 1: the pass table lives in GLOBAL memory (a 64-byte aligned region per workgroup of the launcher's workspace) and is
 // read with scalar loads: an entry in LDS costs a v_mov (address) + ds_read + two v_readfirstlane per pass -- three
 // vector-ALU instructions at 8-12 matrix-pipe cycles each -- a scalar load none.
-template <int DBG = 0, int INCOL = -1, int GT = 0>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
+// SK = 1 (needs GT = 1): STREAM-K.  The launch is gridDim.x persistent workgroups (four per CU) and the unit that is dealt
+// out is not a tile but a SLICE: the passes of all (tile, column block) items, in item order, form one sequence of
+// T = nch * ncb * sum_tiles L(tile) passes (`tile_passes`: the prefix of L over the tiles, scn_tile_passes) that is cut into
+// n_slices equal parts.  Whole tiles dealt over 1,024 resident workgroups run ceil(n / 1024) rounds (2,766 tiles: three
+// rounds for 2.70 rounds of work; 4,688: five for 4.58): the last round is 8-10 % of every launch.  A slice begins and ends
+// anywhere inside a tile's pass table, so an item cut by a slice boundary is computed in two PIECES that are chained, not
+// summed: the piece that holds the item's first passes stores its 128 x 64 output tile to a slab (write-through, sc1),
+// the piece that holds the rest starts its LDS tile from that slab and goes on -- every output element still sees
+// its contributions in (offset, chunk, pair) order, so the result is bit-identical to the one-workgroup-per-tile launch
+// and to k_conv_tile2.  Within a slice the piece that FEEDS the next slice runs first and the piece that WAITS for the
+// previous slice last (a slice is >= 1 tile of work: the slab it waits for was published a tile ago).  Slices are drawn
+// from per-XCD counters (a counter hands out chunks of SK_CH consecutive slices, the chunks dealt round robin over the
+// XCDs: neighbouring tiles gather overlapping rows -> shared L2), a slice waits only for a lower one that was drawn
+// earlier or belongs to another XCD's sequence and the lowest unfinished slice never waits: no deadlock, whatever the
+// residency.  Only the END of the launch is cut that way: the first rounds deal whole items to the same persistent workgroups, in
+// the order the one-workgroup-per-tile launch starts them, and the last 1 + fraction rounds are the sliced sequence (slicing
+// everything measured 4-9 % SLOWER than one workgroup per tile: every slice costs a search, a tile set-up and a slab round trip, and
+// workgroups that walk 4.6 consecutive tiles each no longer share gathered rows in the XCD's L2 the way 64 neighbouring tiles in
+// flight do).  `sk_state` (zero when the launch starts and when it ends): [0..7] whole-item counters, [8] exit ticket,
+// [9] set if a wait for a slab gave up (never, unless the launch is broken), [10] slices drawn so far, [16..23] slice counters, [32 + s] "slab s is
+// published".
+constexpr int SK_CH = 16;          // slices per chunk of one XCD
+constexpr int SK_ITEM_CH = 64;     // whole items per chunk of one XCD (the first rounds)
+constexpr int SK_STATE_WORDS = 32; // counters + ticket in front of the flags
+constexpr bool SK_DRAIN = true;
+constexpr int SK_SLICES = SCN_SK_SLICES;  // slices of the sliced part of a launch (= the entries of scn_tile_passes' slice tables)
+template <int DBG = 0, int INCOL = -1, int GT = 0, int SK = 0>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (<= 256 registers: hipcc then keeps the accumulators in VGPRs, no v_accvgpr_read)
-    k_conv_tile4(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
-                 const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
-                 const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
-                 int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb,
-                 unsigned in_bytes, unsigned wp_bytes, int ksplit, const int32_t *__restrict__ tile_order,
-                 unsigned long long *__restrict__ gtab = nullptr, int gstride = 0) {
+    k_conv_tile4(const float *__restrict__ in, float *__restrict__ out_a, const float *__restrict__ Wp,
+                 const float *__restrict__ bias_a, const float *__restrict__ residual_a, StatsArg colstats_a, const int2 *__restrict__ rules,
+                 const int32_t *__restrict__ bases_a, int K_a, int64_t stride_a, int in_col,
+                 int64_t n_out_a, int n_gran_a, int Ci, int Co, int ntiles_a, int ncb_a,
+                 unsigned in_bytes, unsigned wp_bytes, int ksplit_a,
+                 unsigned long long *__restrict__ gtab_a = nullptr, int gstride_a = 0,
+                 const int32_t *__restrict__ tile_passes_a = nullptr, unsigned *sk_state_a = nullptr, float *slabs_a = nullptr,
+                 int na_items_a = 0) {
+  // (mutable copies of everything the set-up and the epilogue of a piece use: a stream-K launch parks them in the lanes of
+  //  one VGPR while the pass loop runs, see `park_all` below)
+  float *out = out_a;
+  const float *bias = bias_a, *residual = residual_a;
+  StatsArg colstats = colstats_a;
+  const int32_t *bases = bases_a, *tile_passes = tile_passes_a;
+  int K = K_a, n_gran = n_gran_a, ntiles = ntiles_a, ncb = ncb_a, gstride = gstride_a, na_items = na_items_a < 0 ? -na_items_a : na_items_a;
+  const int ksplit = SK ? 1 : ksplit_a;
+  int64_t stride = stride_a, n_out = n_out_a;
+  unsigned long long *gtab = gtab_a;
+  unsigned *sk_state = sk_state_a;
+  float *slabs = slabs_a;
   constexpr int M = 128, COB = 64, OS = COB + 4, CK = 64, NS16 = 4, COS = 2;
   constexpr int TMAX = KMAX * 4 * SCN_TILE4_MAX_CHUNKS + 8;  // passes per tile: <= 4 per (offset, chunk); + sentinels
   __shared__ __attribute__((aligned(16))) float o_tile[(M + 1) * OS];  // row M: sink for padded pairs
   __shared__ __attribute__((aligned(8))) unsigned ptab[GT ? 1 : TMAX][2];  // {byte offset of the pass's first pair in `rules`,
                                                                   //  pairs left in the list | chunk<<8 | k<<12 | first<<20}
+  static_assert(!SK || GT, "stream-K keeps its pass tables in global memory");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -776,14 +817,25 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a_), "s"(b_), "v"(c_));
     return r;
   };
-  const unsigned row_bytes = (unsigned)((colstats.ldi ? colstats.ldi : Ci) * 4), lq16 = (unsigned)(lq * 16), os_u = (unsigned)(OS * 4);
+  const unsigned row_bytes = (unsigned)((colstats.ldi ? colstats.ldi : Ci) * 4), os_u = (unsigned)(OS * 4);
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ru_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)rules, 0, (int)(K * stride * 8), 0x00020000);
 
-  int lin;
-  {
+  const int nch = Ci / CK;
+  auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+  // (a pointer that IS uniform, said so: hipcc otherwise wraps buffer accesses through a resource made from it in a waterfall loop)
+  auto uni_ptr = [](const void *q) __attribute__((always_inline)) {
+    const unsigned long long a = (unsigned long long)(size_t)q;
+    return (void *)(size_t)((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32);
+  };
+  // ---- what this workgroup computes: ONE item = (tile, column block), all of its passes -- or (SK) a sequence of PIECES:
+  // passes [p_lo, p_hi) of an item's table, starting from bias + residual or from slab `seed_slab`, ending in `out` (with the
+  // column statistics) or in slab `out_slab`
+  int item = 0, p_lo = 0, p_hi = 0x7fffffff, seed_slab = -1, out_slab = -1;
+  if (!SK) {
     // Workgroup b runs on XCD b % 8.  Each XCD takes CHUNKS of consecutive tiles (neighbouring tiles gather
     // overlapping rows: shared L2), dealt round robin so that density differences along the row order (whole scenes)
     // do not leave some XCDs with more work than others; the ragged end falls back to one contiguous range each.
@@ -792,22 +844,187 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int CH = 64 * ncb;
     const int full = (DBG & 512) ? 0 : (total / (8 * CH)) * (8 * CH);  // part that divides into rounds of 8 chunks
     if (bid < full) {
-      lin = ((j / CH) * 8 + xcd) * CH + j % CH;
+      item = ((j / CH) * 8 + xcd) * CH + j % CH;
     } else {
       const int rest = total - full, b2 = bid - full, x2 = b2 & 7, j2 = b2 >> 3;
       const int q = rest >> 3, r = rest & 7;
-      lin = full + (x2 < r ? x2 * (q + 1) : r * (q + 1) + (x2 - r) * q) + j2;
+      item = full + (x2 < r ? x2 * (q + 1) : r * (q + 1) + (x2 - r) * q) + j2;
     }
   }
-  // tile_order (may be NULL): position in the dispatch order -> tile.  Workgroups start in blockIdx order; a list that ends
-  // with the LIGHT tiles (few pairs) keeps the last round of the launch short -- the tail in which the chip runs dry
-  // was ~10 % of a launch with tiles of arbitrary weight at the end (4.6 rounds of 1024 resident workgroups).
-  const int tile = tile_order ? __builtin_amdgcn_readfirstlane(tile_order[lin / ncb]) : lin / ncb;
-  const int co0 = (lin % ncb) * COB;
+  // ---- stream-K bookkeeping (scalar; both waves compute the same values)
+  int sk_phase = 0, sk_par = 0, sk_steal = 0, sk_steal_a = 0, sk_s = 0, sk_ia = 0, sk_pa = 0, sk_ib = 0, sk_pb = 0, sk_cur = 0, gpar = 0,
+      sk_pf = 0;
+#ifdef SCN_TUNING
+  if (na_items_a < 0) sk_steal = 8;  // (A/B: whole items only, no sliced part; the item count must be a multiple of SCN_SK_SLICES / 2)
+#endif
+  unsigned *sk_flags = sk_state + SK_STATE_WORDS;
+  // ---- SK: the scalars that only the set-up and the epilogue of a piece need -- kernel arguments and the slice bookkeeping,
+  // some fifty of them -- would all be live across the pass loop of a persistent kernel, and hipcc, short of scalar registers,
+  // spills by loop DEPTH: the search loops of the set-up are nested deeper than the pass loop, so it was the pass loop's scalars
+  // that went to VGPR lanes (27 v_readlane per three passes, each 8-12 matrix-pipe cycles).  They are parked by hand instead:
+  // lane i of ONE VGPR holds value i from just before the pass loop to just behind it, where everything is read back.
+  int park = 0;
+  int tile_parked = 0;
+  auto park_all = [&](bool store) __attribute__((always_inline)) {
+    // (the lane is an immediate: v_writelane takes ONE scalar register operand)
+#define SCN_P32(I, V)                                                                                                      \
+  do {                                                                                                                     \
+    if (store) asm volatile("v_writelane_b32 %0, %1, " #I : "+v"(park) : "s"(__builtin_amdgcn_readfirstlane((int)(V)))); \
+    else V = (decltype(V))__builtin_amdgcn_readlane(park, I);                                                              \
+  } while (0)
+#define SCN_P64(I, J, V)                                                                                                   \
+  do {                                                                                                                     \
+    unsigned long long v64_ = (unsigned long long)(V);                                                                     \
+    int lo_ = (int)(unsigned)v64_, hi_ = (int)(unsigned)(v64_ >> 32);                                                      \
+    SCN_P32(I, lo_);                                                                                                       \
+    SCN_P32(J, hi_);                                                                                                       \
+    if (!store) V = (decltype(V))((unsigned long long)(unsigned)lo_ | (unsigned long long)(unsigned)hi_ << 32);            \
+  } while (0)
+    if (!store) asm volatile("" : "+v"(park));
+    SCN_P64(0, 1, out); SCN_P64(2, 3, bias); SCN_P64(4, 5, residual);
+    SCN_P64(6, 7, colstats.out); SCN_P64(8, 9, colstats.x); SCN_P64(10, 11, colstats.mean); SCN_P64(12, 13, colstats.invstd);
+    SCN_P64(14, 15, colstats.gamma); SCN_P64(16, 17, colstats.beta);
+    int leak_bits = (int)__float_as_uint(colstats.leak);
+    SCN_P32(18, leak_bits);
+    if (!store) colstats.leak = __uint_as_float((unsigned)leak_bits);
+    SCN_P64(19, 20, bases); SCN_P64(21, 22, tile_passes); SCN_P64(23, 24, gtab); SCN_P64(25, 26, sk_state); SCN_P64(27, 28, slabs);
+    SCN_P32(29, K); SCN_P32(30, n_gran); SCN_P32(31, ntiles); SCN_P32(32, ncb); SCN_P32(33, gstride); SCN_P32(34, sk_pf);
+    SCN_P64(36, 37, stride); SCN_P64(38, 39, n_out);
+    SCN_P32(40, sk_phase); SCN_P32(41, sk_par); SCN_P32(42, sk_steal); SCN_P32(43, sk_s); SCN_P32(44, sk_ia); SCN_P32(45, sk_pa);
+    SCN_P32(46, sk_ib); SCN_P32(47, sk_pb); SCN_P32(48, sk_cur); SCN_P32(49, gpar);
+    SCN_P32(50, item); SCN_P32(51, out_slab); SCN_P32(52, tile_parked); SCN_P32(53, sk_steal_a); SCN_P32(54, na_items);
+#undef SCN_P64
+#undef SCN_P32
+    if (store) asm volatile("" : "+v"(park));
+    else sk_flags = sk_state + SK_STATE_WORDS;
+  };
+  // LDS words for the workgroup's two waves to agree on what was drawn: the row behind the output tile (the sink row of older
+  // builds), two alternating sets
+  int *const sk_slot = (int *)(o_tile + M * OS);
+  // where slice s begins: entry s of the slice table scn_tile_passes left behind the pass prefix for this column-block count
+  // (item, pass inside the item's table in units of nch passes).  One scalar load for both ends of a slice.
+  auto sk_bounds = [&](int s_) __attribute__((always_inline)) {
+    const int4 *tab = (const int4 *)(tile_passes + ((ntiles + 2) & ~1) + (size_t)(ncb - 1) * (2 * (SK_SLICES + 1)));
+    const int2 *e = (const int2 *)tab + s_;
+    const int2 a = e[0], b = e[1];
+    sk_ia = uni(a.x); sk_pa = uni(a.y) * nch;
+    sk_ib = uni(b.x); sk_pb = uni(b.y) * nch;
+  };
+  // One draw from this XCD's whole-item counter (which = 1: the first rounds of the launch deal WHOLE items, in the order the
+  // one-workgroup-per-tile launch starts them -- chunks of consecutive items per XCD: no slab, no table) or from its slice
+  // counter (which = 2).  Almost every draw was made ahead of time, while the previous piece's first loads were in flight
+  // (sk_pf: see the prologue of the pass loop), and all that is left of it here is a barrier: a draw made HERE is a round
+  // trip through a memory path that a CU's eight gathering waves keep full, 2-3 us -- the first version also tried the other
+  // seven XCDs' counters when its own ran out, fifteen such round trips at the end of every workgroup: 8 % of a launch.
+  // (Every XCD holds the same number of workgroups and is dealt the same number of items and equal slices: nothing to steal.)
+  auto sk_draw = [&](int which) __attribute__((always_inline)) {
+    if (sk_pf == which) {
+      sk_pf = 0;
+      lds_barrier();
+    } else {
+      sk_pf = 0;  // (a draw of the other kind made ahead is dropped: that counter has run out)
+      if (tid == 0)
+        sk_slot[sk_par] = (int)__hip_atomic_fetch_add(sk_state + (which == 1 ? 0 : 16) + ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+      lds_barrier();
+    }
+    const int t = uni(sk_slot[sk_par]);
+    sk_par ^= 1;
+    return t;
+  };
+  // the next piece: of the current slice -- the item its END cuts first (that piece feeds the next slice), the whole items,
+  // the item its BEGINNING cuts last (that piece waits for the previous slice) -- or of a new slice
+  auto sk_next = [&]() __attribute__((always_inline)) {
+    for (;;) {
+      if (sk_phase == 0) {
+        if (!sk_steal_a) {
+          const int t = sk_draw(1);
+          if (t < (na_items >> 3)) {
+            item = ((t / SK_ITEM_CH) * 8 + ((int)blockIdx.x & 7)) * SK_ITEM_CH + t % SK_ITEM_CH;
+            p_lo = 0; p_hi = 0x7fffffff; seed_slab = -1; out_slab = -1;
+            return true;
+          }
+          sk_steal_a = 1;  // (the whole items of this XCD are dealt)
+        }
+        if (sk_steal >= 8) return false;
+        {
+          // a slice of this XCD's sequence; when that has run out, of another XCD's -- workgroups enter the sliced part when their
+          // last whole item ends, up to an item's time apart, and equal slices alone would carry that spread to the end of the
+          // launch: the early ones take a second slice.  Word 10 counts the slices drawn by the whole launch, so that the
+          // workgroups that finish last see with ONE load that nothing is left, not with seven more draws.
+          int t = sk_steal == 0 ? sk_draw(2) : (SK_SLICES >> 3);
+          while (t >= (SK_SLICES >> 3)) {
+            if (sk_steal == 0) {
+              if (tid == 0) sk_slot[sk_par] = (int)__hip_atomic_load(sk_state + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              lds_barrier();
+              const int taken = uni(sk_slot[sk_par]);
+              sk_par ^= 1;
+              if (taken >= SK_SLICES) { sk_steal = 8; return false; }
+            }
+            if (++sk_steal >= 8) return false;
+            const int xc = ((int)blockIdx.x + sk_steal) & 7;
+            if (tid == 0) sk_slot[sk_par] = (int)__hip_atomic_fetch_add(sk_state + 16 + xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds_barrier();
+            t = uni(sk_slot[sk_par]);
+            sk_par ^= 1;
+          }
+          if (tid == 0) __hip_atomic_fetch_add(sk_state + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sk_s = ((t / SK_CH) * 8 + (((int)blockIdx.x + sk_steal) & 7)) * SK_CH + t % SK_CH;
+        }
+        sk_bounds(sk_s);
+        if (sk_ia == sk_ib) {  // inside one item (a slice shorter than the item)
+          if (sk_pa == sk_pb) continue;
+          item = sk_ia; p_lo = sk_pa; p_hi = sk_pb;
+          seed_slab = sk_pa > 0 ? sk_s - 1 : -1;
+          out_slab = sk_s;
+          return true;
+        }
+        sk_phase = 1;
+      }
+      if (sk_phase == 1) {
+        sk_phase = 2;
+        sk_cur = sk_pa > 0 ? sk_ia + 1 : sk_ia;
+        if (sk_pb > 0) {
+          item = sk_ib; p_lo = 0; p_hi = sk_pb; seed_slab = -1; out_slab = sk_s;
+          return true;
+        }
+      }
+      if (sk_phase == 2) {
+        if (sk_cur < sk_ib) {
+          item = sk_cur++; p_lo = 0; p_hi = 0x7fffffff; seed_slab = -1; out_slab = -1;
+          return true;
+        }
+        sk_phase = 3;
+      }
+      sk_phase = 0;
+      if (sk_pa > 0) {
+        item = sk_ia; p_lo = sk_pa; p_hi = 0x7fffffff; seed_slab = sk_s - 1; out_slab = -1;
+        return true;
+      }
+    }
+  };
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+  int tid_opaque = (int)threadIdx.x;
+  for (;;) {  // SK: pieces; otherwise once
+  if (SK && !sk_next()) break;
+  // (SK: everything per-lane below is derived afresh in every piece -- left loop-invariant, hipcc hoists a dozen per-lane
+  //  addresses of the set-up and the epilogue out of the piece loop, finds no registers for them beside the pass loop's 220
+  //  and spills them to scratch)
+  if (SK) asm volatile("" : "+v"(tid_opaque));
+  const int tid = SK ? tid_opaque : (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int li = lane & 15, lq = lane >> 4;
+  const unsigned lq16 = (unsigned)(lq * 16);
+  const int tile = item / ncb;
+  const int co0 = (item % ncb) * COB;
   const int64_t o0 = (int64_t)tile * M;
   const int g0 = tile * (M / SCN_TILE_GRANULE);
   const int g1 = min(g0 + M / SCN_TILE_GRANULE, n_gran);
-  const int nch = Ci / CK;
+  // this piece's region of the global pass table (SK: two per workgroup, alternating: wave 0 may write the next piece's table
+  // while wave 1 still walks this one; the set-up barrier keeps it from getting two ahead)
+  unsigned long long *const gt_region =
+      GT ? gtab + (SK ? (size_t)(blockIdx.x * 2 + gpar) : (size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * (size_t)gstride : nullptr;
+  gpar ^= 1;
   // output-tile BYTE address of (row dst, this lane's first plane) = dst * (OS * 4) + tile0, modulo 2^32: dst - o0 is what
   // counts (kept in a VGPR: a VOP3 instruction takes one scalar operand)
   typedef __attribute__((address_space(3))) floatx4 lds_floatx4;
@@ -824,21 +1041,46 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int NIT = M * 8 / 64;  // row pieces per lane; i = lane + 64 j: the plane quad (i & 7) is the lane's own
     const int c4 = (lane & 7) * 4;
     floatx4 bv = {0.f, 0.f, 0.f, 0.f}, rv[NIT];
+    if (SK && seed_slab >= 0) {
+      // the item's first passes were computed by the workgroup that holds the previous slice: start from its tile.  That
+      // piece ran FIRST in its slice and this one runs LAST in ours, so the flag is up long before it is looked at.  The slab
+      // was stored write-through (sc1) and is read with sc1 loads: the L2 caches of two XCDs are not coherent.
+      if (tid == 0) {
+        unsigned spins = 0;  // (bounded, ~1 s: a launch that can never finish takes the whole GPU down; word 9 says it gave up)
+        while (__hip_atomic_load(sk_flags + seed_slab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 23))
+          __builtin_amdgcn_s_sleep(4);
+        if (spins >= (1u << 23)) __hip_atomic_store(sk_state + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sk_flags + seed_slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (one reader per flag)
+      }
+      __syncthreads();
+      asm volatile("" ::: "memory");
+      const __amdgpu_buffer_rsrc_t sl_rsrc = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(slabs + (size_t)seed_slab * (size_t)(M * COB)), 0, M * COB * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sl_rsrc, ((w * NIT + j) * 64 + lane) * 16, 0, 16 /* sc1 */);
+        rv[j] = floatx4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+      }
+    } else {
     if (bias && blockIdx.y == 0) bv = *(const floatx4 *)(bias + co0 + 32 * w + c4);
     if (residual && blockIdx.y == 0) {
 #pragma unroll
       for (int j = 0; j < NIT; ++j) {
-        const int r = (lane >> 3) + 8 * j;
-        rv[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (o0 + r < n_out) rv[j] = *(const floatx4 *)(residual + (o0 + r) * Co + co0 + 32 * w + c4);
+        // (rows past the end of the tensor repeat its last row: they are never stored, and sixteen loads behind sixteen
+        //  branches are 2^16 paths for tools/check_asm_loads.py)
+        const int64_t r = min(o0 + (lane >> 3) + 8 * j, n_out - 1);
+        rv[j] = *(const floatx4 *)(residual + r * Co + co0 + 32 * w + c4);
       }
+      // (SK: hipcc lays this arm out in front of the seeded one and skips that through a scalar flag; the checker, which
+      //  follows every branch, would see these loads in flight under the slab loads.  The tile writes below need them anyway.)
+      if (SK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
 #pragma unroll
       for (int j = 0; j < NIT; ++j) rv[j] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
+    }
 #pragma unroll
     for (int j = 0; j < NIT; ++j) *(floatx4 *)(o_tile + ((lane >> 3) + 8 * j) * OS + 32 * w + c4) = rv[j] + bv;
-    if (lane < 8) *(floatx4 *)(o_tile + M * OS + 32 * w + c4) = floatx4{0.f, 0.f, 0.f, 0.f};  // (row M: unused sink of older builds)
+    if (!SK && lane < 8) *(floatx4 *)(o_tile + M * OS + 32 * w + c4) = floatx4{0.f, 0.f, 0.f, 0.f};  // (row M: unused sink of older builds)
   }
   if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
     int s = 0, c = 0;
@@ -855,15 +1097,18 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int y = __shfl_up(pos, o);
       if (lane >= o) pos += y;
     }
-    const int total = __shfl(pos, 63);
+    const int total_item = __shfl(pos, 63);
     pos -= npl * nch;
+    // (SK: the piece holds the entries [p_lo, p_hi) of the item's table, stored from index 0)
+    const int t_lo = SK ? min(p_lo, total_item) : 0, t_hi = SK ? min(p_hi, total_item) : total_item;
+    const int total = t_hi - t_lo;
     const unsigned first = (unsigned)(((int64_t)tid * stride + s) * 8);
-    uint2 *gt = GT ? (uint2 *)(gtab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (size_t)gstride) : nullptr;
+    uint2 *gt = (uint2 *)gt_region;
     for (int chn = 0; chn < nch; ++chn)
       for (int j = 0; j < npl; ++j) {
         const unsigned e0 = first + (unsigned)j * 256u;
         const unsigned e1 = (unsigned)(c - 32 * j) | (unsigned)chn << 8 | (unsigned)tid << 12 | (j == 0 ? 1u << 20 : 0u);
-        if (GT) gt[pos] = make_uint2(e0, e1);
+        if (GT) { if (!SK || (pos >= t_lo && pos < t_hi)) gt[pos - t_lo] = make_uint2(e0, e1); }
         else { ptab[pos][0] = e0; ptab[pos][1] = e1; }
         ++pos;
       }
@@ -879,11 +1124,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (GT) asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   unsigned long long gt_s = 0;  // this workgroup's region, in a scalar register pair
   if (GT) {
-    const unsigned long long a = (unsigned long long)(gtab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (size_t)gstride);
+    const unsigned long long a = (unsigned long long)gt_region;
     gt_s = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32;
   }
-  auto uni = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   // offset of the loads a pass does not need (absent second group, passes past the end): the first bytes of the buffer
   // (always valid; what they fetch is multiplied by nothing or lands in the sink row).  Pointing them past the end of the
   // buffer instead (DBG & 8192: the range check returns 0 without touching memory) is 0.5-2 % SLOWER.
@@ -1000,9 +1244,21 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         : [a] "v"(addr), [m] "s"(mask), [d0] "v"(d0), [d1] "v"(d1)
         : "memory");
   };
-  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 
+  // SK, whole items: the NEXT item is drawn here -- the returning atomic travels with this piece's first index loads and the
+  // wait behind them covers it (drawn at the top of the next piece it cost every item a round trip through a memory path
+  // that a CU's eight gathering waves keep full: 2-3 us per dependent access)
+  // (sk_phase == 0: the next call of sk_next begins with a draw.  Only draws of WHOLE items are made ahead: a slice drawn while
+  //  its workgroup still has a piece to finish sits undone, and the slice behind it waits for its first piece -- measured:
+  //  launches 7-12 % slower)
+  const bool pf_now = SK && sk_phase == 0 && !sk_steal_a && na_items > 0;
+  const int pf_slot = sk_par, pf_which = 1;
+  unsigned pf_val = 0;
+  if (pf_now && tid == 0)
+    pf_val = __hip_atomic_fetch_add(sk_state + (pf_which == 1 ? 0 : 16) + ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (SK) { sk_pf = pf_now ? pf_which : 0; tile_parked = tile; park_all(true); }
   Ent E0 = entry(0);
+  if (SK && pf_now && !(rem(E0) > 0) && tid == 0) sk_slot[pf_slot] = (int)pf_val;  // (an item without passes: no prologue)
   if (rem(E0) > 0) {
     // ---- pipeline state at the top of pass p: rows(p) in rc, rows(p+1) in rm (arrived), weights(p) in wc, indices of
     // pass p+2 in pr (arrived); E0..E3 = table entries p..p+3; `ioff` = index-load offsets of pass p+3; acc[1] / op1 =
@@ -1028,6 +1284,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       load_idx(E0, ioff, pr);
       asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr[0]), "v"(pr[1]) : "memory");
       __builtin_amdgcn_sched_barrier(0);
+      if (SK && pf_now) {  // (the draw made above has returned)
+        if (tid == 0) sk_slot[pf_slot] = (int)pf_val;
+        __builtin_amdgcn_sched_barrier(0);
+      }
       addr(E0, pr, off, oA);
       weight_scalars(E0, so, voff, fresh);
 #pragma unroll
@@ -1200,10 +1460,27 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   }
 #undef SCN_ROWS
-  if ((DBG & 256) && lane == 0)
-    for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
+  if (SK) park_all(false);
+  const int tile_e = SK ? tile_parked : tile;  // (SK: `tile` and `o0_e` are not kept across the pass loop)
+  const int64_t o0_e = (int64_t)tile_e * M;
+  if (SK && out_slab >= 0) {
+    // the item goes on in the next slice: publish the tile (each wave its 32 planes, in the order the seeded set-up reads
+    // them back: piece j of lane l = row (l >> 3) + 8 j, plane quad l & 7).  Write-through stores, every storing wave drains
+    // them, the barrier, then ONE lane raises the flag (sc1 store): the hand-off form the other XCDs' L2s require.
+    const __amdgpu_buffer_rsrc_t sl_rsrc = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(slabs + (size_t)out_slab * (size_t)(M * COB)), 0, M * COB * 4, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < M * 8 / 64; ++j) {
+      const floatx4 v = *(const floatx4 *)(o_tile + ((lane >> 3) + 8 * j) * OS + 32 * w + (lane & 7) * 4);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
+                                             sl_rsrc, ((w * (M * 8 / 64) + j) * 64 + lane) * 16, 0, 16 /* sc1 */);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(sk_flags + out_slab, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    continue;
+  }
   // each wave stores its own 32 planes: no barrier needed
-  const int rows = (int)min((int64_t)M, n_out - o0);
+  const int rows = (int)min((int64_t)M, n_out - o0_e);
   float *dst = out + (int64_t)blockIdx.y * n_out * Co;
   // ... and the column statistics of these 32 planes over the tile's rows come from the SAME 16-byte reads: lane (row
   // octet lane >> 3, plane quad lane & 7) sums its 16 rows, a butterfly over the eight lanes of a plane quad finishes.  (The
@@ -1217,8 +1494,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   for (int i = lane; i < rows * 8; i += 64) {
     const int r = i >> 3, c4 = (i & 7) * 4;
     const floatx4 v = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
-    *(floatx4 *)(dst + (o0 + r) * Co + co0 + 32 * w + c4) = v;
-    sc.add(v, colstats.x + (o0 + r) * Co + co0 + 32 * w + c4, cs, css);
+    *(floatx4 *)(dst + (o0_e + r) * Co + co0 + 32 * w + c4) = v;
+    sc.add(v, colstats.x + (o0_e + r) * Co + co0 + 32 * w + c4, cs, css);
   }
   if (stats) {
 #pragma unroll
@@ -1229,8 +1506,24 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         css[e] += __shfl_xor(css[e], o);
       }
     if (lane < 8) {
-      *(floatx4 *)(colstats.out + ((int64_t)tile * 2 + 0) * Co + co0 + 32 * w + lane * 4) = cs;
-      *(floatx4 *)(colstats.out + ((int64_t)tile * 2 + 1) * Co + co0 + 32 * w + lane * 4) = css;
+      *(floatx4 *)(colstats.out + ((int64_t)tile_e * 2 + 0) * Co + co0 + 32 * w + lane * 4) = cs;
+      *(floatx4 *)(colstats.out + ((int64_t)tile_e * 2 + 1) * Co + co0 + 32 * w + lane * 4) = css;
+    }
+  }
+  if (!SK) break;
+  // (the set-up that follows waits for its first loads, hence -- vmcnt counts in order -- for these stores, within a
+  //  microsecond anyway; said here, tools/check_asm_loads.py sees an empty queue at the top of every piece)
+  if (SK_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }  // pieces
+  if ((DBG & 256) && lane == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
+  if (SK && tid == 0) {  // the last workgroup out leaves the counters as it found them (every flag was reset by its reader)
+    if (__hip_atomic_fetch_add(sk_state + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+#pragma unroll
+      for (int i = 0; i < 11; ++i)
+        if (i != 9) __hip_atomic_store(sk_state + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 16; i < 24; ++i) __hip_atomic_store(sk_state + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1802,8 +2095,8 @@ __global__ void __launch_bounds__(64)
         //  ds_read2_b32 / ds_write2_b32 per fragment instead of one ds_read_b128 / ds_write_b128)
         if (!(DBG & 1)) old[i][q] = *(const floatx4 *)__builtin_assume_aligned(o_tile + orow[i] + 32 * w + 16 * q + 4 * lq, 16);
   };
-  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
   Ent E0 = entry(0);
   if (rem(E0) > 0) {
     // ---- pipeline state at the top of pass p: rows(p) in rc, rows(p+1) in rm (arrived), weights(p) in wc, indices of
@@ -2906,6 +3199,12 @@ SCN_KNOB g_conv_expand_nb = 1;  // tuning key 14: blocks of 32 pairs per wave of
                                 // per step): 1.81 / 1.83 / 2.21 ms -- the weight re-reads are not what bounds the kernel
 SCN_KNOB g_conv_stem_mfma = 1;  // tuning key 15: 0 = the C_i <= 4 stem runs k_conv_generic (scalar FMAs) instead of k_conv_stem (A/B)
 SCN_KNOB g_conv_gtab = 1;       // tuning key 13: 0 = k_conv_tile4 keeps its pass table in LDS (A/B)
+SCN_KNOB g_conv_sk = 1;         // tuning key 16: stream-K for the unsplit k_conv_tile4 launches (0 = one workgroup per tile, the round-3 launch)
+SCN_KNOB g_conv_sk_min_loss = 90;   // tuning key 18: ... and only where one workgroup per tile would leave at least this many permille of the last
+                                    // round of resident workgroups empty (2.70 rounds: 100; 2.83: 57; 4.59: 82).  Measured (tools/ab_stream_k.py,
+                                    // profiles/r04_ab_stream_k.txt): the persistent loop runs ~6 % behind hardware re-dispatch, so stream-K gains
+                                    // 6 % at 2.70 rounds, breaks even at 2.83 and loses 8 % at 4.59.  0: every eligible launch (A/B)
+SCN_KNOB g_conv_sk_min_items = 1024;  // tuning key 17: ... for launches with at least this many (tile, column block) items
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 // Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.
@@ -3044,9 +3343,55 @@ static int tile4_gtab_stride(int K, int Ci) { return (K * 4 * (Ci / 64) + 8 + 7)
 static int expand_nb() { return g_conv_expand_nb >= 4 ? 4 : g_conv_expand_nb >= 2 ? 2 : 1; }
 static int64_t expand_waves(int64_t n_out, int K) { return (n_out + 32 * expand_nb() - 1) / (32 * expand_nb()) + K; }
 
+// stream-K geometry of an unsplit k_conv_tile4 launch: persistent workgroups (four per CU), slices (a power of two, a multiple of
+// 8 XCDs x SK_CH), and where the pass tables (two per workgroup) and the slabs (one 128 x 64 tile per slice) sit in the workspace
+struct SkPlan {
+  int groups, slices, shift, na_items;
+  size_t gtab_bytes, slab_bytes;
+};
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  return cus;
+}
+static bool tile4_sk_plan(int K, int64_t n_out, int Ci, int Co, SkPlan &sp) {
+  if (g_conv_sk <= 0) return false;
+  const int64_t items = ((n_out + 127) / 128) * (Co / 64);
+  if (items < g_conv_sk_min_items) return false;
+  if (Co / 64 > SCN_SK_MAX_NCB) return false;
+  sp.groups = 4 * device_cus();
+  {
+    const int64_t rounds_up = (items + sp.groups - 1) / sp.groups;
+    if ((rounds_up * sp.groups - items) * 1000 < (int64_t)g_conv_sk_min_loss * rounds_up * sp.groups) return false;
+  }
+  sp.slices = SK_SLICES;
+  sp.shift = 0;
+  // whole items first: all but the last 1 + fraction rounds of SK_SLICES items (the rule k_sk_slices built the table for)
+  sp.na_items = (int)scn_sk_whole_items(items);
+#ifdef SCN_TUNING
+  if (g_conv_sk == 2) sp.na_items = -(int)(items / 512 * 512);
+#endif
+  if (sp.slices + SK_STATE_WORDS > (int)(SCN_SK_STATE_BYTES / 4)) return false;
+  sp.gtab_bytes = (size_t)sp.groups * 2 * (size_t)tile4_gtab_stride(K, Ci) * 8;
+  sp.slab_bytes = (size_t)sp.slices * 128 * 64 * 4;
+  return true;
+}
+
+// workspace of an unsplit k_conv_tile4 launch: the pass tables, one region per workgroup; stream-K: + one slab per slice
+static size_t tile4_workspace_bytes(int K, int64_t n_out, int Ci, int Co) {
+  const size_t plain = (size_t)((n_out + 127) / 128) * (size_t)(Co / 64) * (size_t)tile4_gtab_stride(K, Ci) * 8;
+  SkPlan sp;
+  if (!tile4_sk_plan(K, n_out, Ci, Co, sp)) return plain;
+  return plain > sp.gtab_bytes + sp.slab_bytes ? plain : sp.gtab_bytes + sp.slab_bytes;
+}
+
 static int launch_tile4(const float *in, float *out, const float *Wp, const float *bias, const float *residual, StatsArg colstats, const int32_t *rules,
                         const int32_t *bases, int K, int64_t stride, int in_col, int64_t n_out, int64_t n_in,
-                        int Ci, int Co, int ksplit, float *part, const int32_t *tile_order, hipStream_t stream) {
+                        int Ci, int Co, int ksplit, float *part, const int32_t *tile_passes, unsigned *sk_state, hipStream_t stream) {
   const int M = tile4_rows(ksplit);
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
@@ -3101,7 +3446,7 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
 #define SCN_LAUNCH_TILE4(D)                                                                                         \
   k_conv_tile4<D><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,                     \
                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb,                    \
-                                             in_bytes, wp_bytes, ksplit, tile_order)
+                                             in_bytes, wp_bytes, ksplit)
 #ifdef SCN_TUNING
   if (g_conv_tile5 != 0) {  // one wave per tile, all 64 planes (k_conv_tile5): A/B only, measured slower
     k_conv_tile5<0><<<grid4, 64, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out,
@@ -3121,33 +3466,53 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 4097: SCN_LAUNCH_TILE4(4096 + 11); break;  // ... and no weight loads
     case 8192: SCN_LAUNCH_TILE4(8192); break;  // A/B: unneeded loads point out of range instead of reading offset 0
     default:
+      SkPlan sp;
+      if (gtab != nullptr && tile_passes != nullptr && sk_state != nullptr && tile4_sk_plan(K, n_out, Ci, Co, sp)) {
+        float *slabs = (float *)((char *)part + sp.gtab_bytes);
+        if (in_col)
+          k_conv_tile4<0, 1, 1, 1><<<sp.groups, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
+                                                                  ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items);
+        else
+          k_conv_tile4<0, 0, 1, 1><<<sp.groups, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
+                                                                  ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items);
+      } else
       if (gtab != nullptr && in_col)
         k_conv_tile4<0, 1, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order, gtab, gstride);
+                                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride);
       else if (gtab != nullptr)
         k_conv_tile4<0, 0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order, gtab, gstride);
+                                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride);
       else if (in_col)
         k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
+                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
       else
         k_conv_tile4<0, 0><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
+                                                                              stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
   }
 #else
-  if (gtab != nullptr) {  // pass table in global memory, read with scalar loads (see k_conv_tile4's GT)
+  SkPlan sp;
+  if (gtab != nullptr && tile_passes != nullptr && sk_state != nullptr && tile4_sk_plan(K, n_out, Ci, Co, sp)) {
+    // stream-K: persistent workgroups, equal slices of the pass sequence (see k_conv_tile4's SK)
+    float *slabs = (float *)((char *)part + sp.gtab_bytes);
+    if (in_col)
+      k_conv_tile4<0, 1, 1, 1><<<sp.groups, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
+                                                              ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items);
+    else
+      k_conv_tile4<0, 0, 1, 1><<<sp.groups, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
+                                                              ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items);
+  } else if (gtab != nullptr) {  // pass table in global memory, read with scalar loads (see k_conv_tile4's GT)
     if (in_col)
       k_conv_tile4<0, 1, 1><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                       stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order, gtab, gstride);
+                                                       stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride);
     else
       k_conv_tile4<0, 0, 1><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                       stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order, gtab, gstride);
+                                                       stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride);
   } else if (in_col)
     k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
+                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
   else
     k_conv_tile4<0, 0><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, tile_order);
+                                                                          stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
 #endif
   }
 #undef SCN_LAUNCH_TILE4
@@ -3203,6 +3568,9 @@ int scn_set_tuning(int key, int value) {
   if (key == 13) { g_conv_gtab = value; return 0; }
   if (key == 14) { g_conv_expand_nb = value; return 0; }
   if (key == 15) { g_conv_stem_mfma = value; return 0; }
+  if (key == 16 && value >= 0 && value <= 2) { g_conv_sk = value; return 0; }
+  if (key == 17 && value >= 1) { g_conv_sk_min_items = value; return 0; }
+  if (key == 18 && value >= 0 && value <= 1000) { g_conv_sk_min_loss = value; return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
@@ -3213,8 +3581,7 @@ size_t scn_conv_wpack_bytes(int K, int Ci, int Co) { return (size_t)K * Ci * Co 
 size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_out, int Ci, int Co, int out_unique) {
   if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
   const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
-  if (p.kind == 4 && p.ksplit == 1)  // k_conv_tile4's pass tables, one region per workgroup
-    return (size_t)((n_out + 127) / 128) * (size_t)(Co / 64) * (size_t)tile4_gtab_stride(K, Ci) * 8;
+  if (p.kind == 4 && p.ksplit == 1) return tile4_workspace_bytes(K, n_out, Ci, Co);
   return p.ksplit > 1 ? (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4 : 0;
 }
 
@@ -3274,10 +3641,10 @@ int scn_weight_pack_batch(const void *descs, int n, int64_t total_blocks, void *
 int scn_conv_forward(const float *in, float *out, const float *W, int w_transposed, int w_reverse,
                      const float *bias, const float *residual, float *colstats_out, const scn_bn_bwd_stats *bn_bwd,
                      const int32_t *rules, const int32_t *bases,
-                     const int32_t *tile_order, const int32_t *counts, int K,
+                     const int32_t *tile_passes, const int32_t *counts, int K,
                      int64_t stride, int in_col, int out_col, int out_unique, int64_t n_in, int64_t n_out, int Ci,
                      int Co, int64_t ld_in, int64_t ld_out, void *wpack, int wpack_ready, void *workspace,
-                     size_t workspace_bytes, void *stream_) {
+                     size_t workspace_bytes, void *sk_state, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE((ld_in == 0 || (ld_in >= Ci && ld_in % 4 == 0 && ld_in < (1 << 20))) &&
               (ld_out == 0 || (ld_out >= Co && ld_out % 4 == 0 && ld_out < (1 << 20))), "scn_conv_forward: bad leading dimensions");
@@ -3343,11 +3710,11 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     float *part = (float *)workspace;
     if (p.kind == 4 && p.ksplit == 1 && workspace != nullptr)
-      SCN_REQUIRE(workspace_bytes >= (size_t)((n_out + 127) / 128) * (size_t)(Co / 64) * (size_t)tile4_gtab_stride(K, Ci) * 8,
+      SCN_REQUIRE(workspace_bytes >= tile4_workspace_bytes(K, n_out, Ci, Co),
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     if (p.kind == 4)
       return launch_tile4(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part,
-                          p.ksplit == 1 ? tile_order : nullptr, stream);
+                          p.ksplit == 1 ? tile_passes : nullptr, (unsigned *)sk_state, stream);
     switch (p.nw) {
       case 4: return launch_tile2_ck<4>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
       case 3: return launch_tile2_ck<3>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);

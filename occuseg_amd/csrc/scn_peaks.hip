@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(256) k_mfma_probe(float *sink, const float *sr
   __shared__ float lds[4096];
   asm volatile("" ::: "a255");  // (mode 10 reads it)
   floatx4 acc[8];
-  float a[32], b[16], f[4] = {0.f, 0.f, 0.f, 0.f};
+  float a[32], b[16], f[4] = {0.f, 0.f, 0.f, 0.f}, g[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { g[i] = (float)(threadIdx.x * 3 + i) * 1e-9f; asm volatile("" : "+v"(g[i])); }
   floatx4 junk = {0.f, 0.f, 0.f, 0.f};
   int sc = never;
 #pragma unroll
@@ -123,6 +125,21 @@ __global__ void __launch_bounds__(256) k_mfma_probe(float *sink, const float *sr
         for (int u = 0; u < 16; ++u) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(double *)&f[(u & 1) * 2]) : "v"(*(double *)&a[(u & 15) * 2]), "v"(*(double *)&b[(u & 7) * 2]));
       }
       if (MODE == 19 && (m & 3) == 3) asm volatile("ds_write_b128 %0, %1" ::"v"(voff), "v"(acc[0]) : "memory");
+      // 34-45 (round 4): what made row 3 (compiler-emitted f += 1.0f: 143 TF) so much cheaper than every inline-asm row (111 TF)?
+      // the asm statement itself, the encoding (VOP2 / VOP3), the operand count, or that the asm rows all READ a register that
+      // the MFMAs around them read too (a[], b[]).  g[] are registers no MFMA touches.
+      if (MODE == 34) asm volatile("v_add_f32_e32 %0, 1.0, %0" : "+v"(f[m & 3]));                                 // row 3 as asm
+      if (MODE == 35) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(f[m & 3]) : "v"(a[m & 31]));                 // + reads an MFMA operand
+      if (MODE == 36) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(f[m & 3]) : "v"(g[m & 3]));                  // + reads a free register
+      if (MODE == 37) asm volatile("v_add_f32_e64 %0, %1, %0" : "+v"(f[m & 3]) : "v"(g[m & 3]));                  // VOP3 encoding of 36
+      if (MODE == 38) asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(f[m & 3]) : "v"(g[m & 3]));                  // integer add
+      if (MODE == 39) asm volatile("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(f[m & 3]) : "v"(g[m & 3]));              // VOP3 address form
+      if (MODE == 40) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(*(double *)&f[(m & 1) * 2]) : "v"(*(double *)&g[(m & 1) * 2]));  // packed, free registers
+      if (MODE == 41) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(f[m & 3]) : "v"(g[m & 3]), "v"(g[(m + 1) & 3]));            // three free sources
+      if (MODE == 42) f[m & 3] += a[m & 31];                                                                       // compiler-emitted, reads an MFMA operand
+      if (MODE == 43) { f[(m & 1) * 2] += g[(m & 1) * 2]; f[(m & 1) * 2 + 1] += g[(m & 1) * 2 + 1]; }              // compiler-emitted pair (v_pk_add_f32?)
+      if (MODE == 44) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(f[m & 3]) : "v"(g[m & 3]));                       // plain move, free registers
+      if (MODE == 45) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(double *)&f[(m & 1) * 2]) : "v"(*(double *)&acc[2 + (m & 1)]), "v"(*(double *)&g[(m & 1) * 2]));  // packed, reads an idle accumulator tuple
       __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(junk) : "memory");
@@ -132,7 +149,7 @@ __global__ void __launch_bounds__(256) k_mfma_probe(float *sink, const float *sr
 #pragma unroll
   for (int i = 1; i < 8; ++i) s += acc[i];
   s += junk;
-  if (s.x + f[0] + f[1] + f[2] + f[3] + (float)sc == 123.456f) sink[0] = s.x + s.y + s.z + s.w;
+  if (s.x + f[0] + f[1] + f[2] + f[3] + g[0] + g[1] + g[2] + g[3] + (float)sc == 123.456f) sink[0] = s.x + s.y + s.z + s.w;
 }
 }  // namespace scn
 using namespace scn;
@@ -182,7 +199,7 @@ int scn_mfma_probe(float *scratch_dev, const float *src_dev, int mode, int waves
     const int n = rep == 0 ? 50 : iters;
     if (rep == 1) SCN_CHECK_HIP(hipEventRecord(e0, stream));
     switch (mode) {
-      SCN_PROBE(0); SCN_PROBE(1); SCN_PROBE(2); SCN_PROBE(3); SCN_PROBE(4); SCN_PROBE(5); SCN_PROBE(6); SCN_PROBE(7); SCN_PROBE(8); SCN_PROBE(9); SCN_PROBE(10); SCN_PROBE(11); SCN_PROBE(12); SCN_PROBE(13); SCN_PROBE(14); SCN_PROBE(15); SCN_PROBE(16); SCN_PROBE(17); SCN_PROBE(18); SCN_PROBE(19); SCN_PROBE(20); SCN_PROBE(21); SCN_PROBE(22); SCN_PROBE(23); SCN_PROBE(24); SCN_PROBE(25); SCN_PROBE(26); SCN_PROBE(27); SCN_PROBE(28); SCN_PROBE(29); SCN_PROBE(30); SCN_PROBE(31); SCN_PROBE(32); SCN_PROBE(33);
+      SCN_PROBE(0); SCN_PROBE(1); SCN_PROBE(2); SCN_PROBE(3); SCN_PROBE(4); SCN_PROBE(5); SCN_PROBE(6); SCN_PROBE(7); SCN_PROBE(8); SCN_PROBE(9); SCN_PROBE(10); SCN_PROBE(11); SCN_PROBE(12); SCN_PROBE(13); SCN_PROBE(14); SCN_PROBE(15); SCN_PROBE(16); SCN_PROBE(17); SCN_PROBE(18); SCN_PROBE(19); SCN_PROBE(20); SCN_PROBE(21); SCN_PROBE(22); SCN_PROBE(23); SCN_PROBE(24); SCN_PROBE(25); SCN_PROBE(26); SCN_PROBE(27); SCN_PROBE(28); SCN_PROBE(29); SCN_PROBE(30); SCN_PROBE(31); SCN_PROBE(32); SCN_PROBE(33); SCN_PROBE(34); SCN_PROBE(35); SCN_PROBE(36); SCN_PROBE(37); SCN_PROBE(38); SCN_PROBE(39); SCN_PROBE(40); SCN_PROBE(41); SCN_PROBE(42); SCN_PROBE(43); SCN_PROBE(44); SCN_PROBE(45);
       default: return fail(2, "scn_mfma_probe: unknown mode%s", "");
     }
   }

@@ -312,68 +312,76 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// Dispatch order of the 128-row tiles of one output column (scn_conv_forward's tile_order): the tiles whose pair count is
-// below light_permille / 1000 of the mean move to the end, everything else keeps its place -- a stable partition, so
-// neighbouring tiles (which gather overlapping rows) stay neighbours in both parts.  One workgroup: <= 16 tiles per thread.
-constexpr int TILE_ORDER_MAX = 16384;
+// Pass prefix of the 128-row output tiles of one output column (scn_conv_forward's tile_passes): k_conv_tile4 walks the pairs
+// of (tile, offset k) in passes of 32, so tile t costs L(t) = sum_k ceil(pairs_k(t) / 32) passes per 64-plane input chunk and
+// output column block (an empty tile still costs its set-up: weight 1).  passes[t] = sum_{t' < t} max(1, L(t')): with it a
+// persistent launch cuts the whole pass sequence into equal slices (stream-K) instead of dealing whole tiles.  One workgroup.
 __global__ void __launch_bounds__(1024)
-    k_tile_order(const int32_t *__restrict__ bases, int K, int n_gran, int n_tiles, int light_permille, int32_t *__restrict__ order) {
-  constexpr int PER = TILE_ORDER_MAX / 1024;
-  __shared__ unsigned long long total_s;
-  __shared__ int wsum[16], heavy_s;
+    k_tile_passes(const int32_t *__restrict__ bases, int K, int n_gran, int n_tiles, int32_t *__restrict__ passes) {
+  __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int work[PER];
-  unsigned long long mine = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {  // thread t owns the CONSECUTIVE tiles t * PER + j (keeps the partition stable)
-    const int t = tid * PER + j;
+  int carry = 0;
+  for (int base = 0; base < n_tiles; base += 1024) {
+    const int t = base + tid;
     int wk = 0;
     if (t < n_tiles) {
       const int g0 = t * 4, g1 = min(g0 + 4, n_gran);
-      for (int k = 0; k < K; ++k) wk += bases[(int64_t)k * (n_gran + 1) + g1] - bases[(int64_t)k * (n_gran + 1) + g0];
+      for (int k = 0; k < K; ++k)
+        wk += (bases[(int64_t)k * (n_gran + 1) + g1] - bases[(int64_t)k * (n_gran + 1) + g0] + 31) >> 5;
+      wk = max(wk, 1);
     }
-    work[j] = wk;
-    mine += (unsigned long long)wk;
-  }
-  if (tid == 0) total_s = 0;
-  __syncthreads();
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-  if (lane == 0) atomicAdd(&total_s, mine);
-  __syncthreads();
-  // light: work * 1000 * n_tiles < light_permille * total
-  const unsigned long long rhs = (unsigned long long)light_permille * total_s;
-  int nh = 0;
-  bool heavy[PER];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int t = tid * PER + j;
-    heavy[j] = t < n_tiles && (unsigned long long)work[j] * 1000ull * (unsigned long long)n_tiles >= rhs;
-    nh += heavy[j];
-  }
-  // exclusive scan of the per-thread heavy counts over the workgroup
-  int incl = nh;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(incl, o);
-    if (lane >= o) incl += y;
-  }
-  if (lane == 63) wsum[wv] = incl;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int i = 0; i < 16; ++i) { const int v = wsum[i]; wsum[i] = run; run += v; }
-    heavy_s = run;
-  }
-  __syncthreads();
-  int hpos = wsum[wv] + incl - nh;                                   // heavy tiles before this thread's first tile
-  int lpos = heavy_s + min(tid * PER, n_tiles) - hpos;               // light tiles before it, behind all heavy ones
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int t = tid * PER + j;
-    if (t < n_tiles) {
-      if (heavy[j]) order[hpos++] = t;
-      else order[lpos++] = t;
+    int incl = wk;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
     }
+    __syncthreads();  // (wsum of the previous round has been read)
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int v = wsum[i];
+      before += i < wv ? v : 0;
+      total += v;
+    }
+    if (t < n_tiles) passes[t] = carry + before + incl - wk;
+    carry += total;
   }
+  if (tid == 0) passes[n_tiles] = carry;
+}
+
+// Slice tables behind the prefix (one per column-block count ncb = 1 .. SCN_SK_MAX_NCB): entry s = where slice s of the sliced
+// part of a launch begins, as (item = tile * ncb + column block, pass inside the item in units of one pass per input chunk).
+// The sequence: items in order, item (tile, cb) holding L(tile) = passes[tile + 1] - passes[tile] units; the whole items
+// [0, scn_sk_whole_items) are left out.  Boundaries within 4 units of an item's ends move there (a piece of a few passes costs a
+// tile set-up and a slab round trip).
+__global__ void __launch_bounds__(256)
+    k_sk_slices(const int32_t *__restrict__ passes, int n_tiles, int2 *__restrict__ tab) {
+  const int ncb = blockIdx.y + 1;
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s > SCN_SK_SLICES) return;
+  int2 *out = tab + (size_t)(ncb - 1) * (SCN_SK_SLICES + 1);
+  const int64_t items = (int64_t)n_tiles * ncb, na = scn_sk_whole_items(items);
+  if (s == SCN_SK_SLICES) { out[s] = make_int2((int)items, 0); return; }
+  if (s == 0) { out[s] = make_int2((int)na, 0); return; }
+  const int t_a = (int)(na / ncb), cb_a = (int)(na % ncb);
+  const int64_t X0 = (int64_t)passes[t_a] * ncb + (int64_t)cb_a * (passes[t_a + 1] - passes[t_a]);
+  const int64_t T = (int64_t)passes[n_tiles] * ncb;
+  const int64_t x = X0 + (T - X0) * s / SCN_SK_SLICES;
+  const int64_t y = x / ncb;
+  int lo = 0, hi = n_tiles;  // largest t in [0, n_tiles) with passes[t] <= y
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (passes[mid] <= y) lo = mid; else hi = mid;
+  }
+  const int64_t l0 = passes[lo], L = passes[lo + 1] - l0;
+  const int64_t r = x - l0 * ncb;
+  int64_t cb = r / L, ps = r - cb * L;
+  const int64_t d = L / 2 < 4 ? L / 2 : 4;
+  if (ps < d) ps = 0;
+  else if (L - ps <= d) { ps = 0; ++cb; }
+  out[s] = make_int2((int)(lo * (int64_t)ncb + cb), (int)ps);
 }
 
 // ------------------------------------------------------------ tile bases ---
@@ -647,15 +655,22 @@ int scn_strided_rules(const int32_t *fine_coords, int64_t N, const int32_t *coar
   return 0;
 }
 
-int scn_tile_order(const int32_t *bases, int K, int64_t n_out, int light_permille, int32_t *order, void *stream_) {
+int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
-  const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
-  const int n_tiles = (int)((n_out + 127) / 128);
-  SCN_REQUIRE(K >= 1 && n_tiles >= 1 && n_tiles <= TILE_ORDER_MAX && light_permille >= 0 && light_permille <= 1000,
-              "scn_tile_order: bad arguments (at most 16384 tiles)");
-  k_tile_order<<<1, 1024, 0, stream>>>(bases, K, n_gran, n_tiles, light_permille, order);
+  const int64_t n_gran = (n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE, n_tiles = (n_out + 127) / 128;
+  SCN_REQUIRE(bases != nullptr && passes != nullptr && K >= 1 && K <= 27 && n_out > 0 && n_tiles < (1 << 24),
+              "scn_tile_passes: bad arguments");
+  k_tile_passes<<<1, 1024, 0, stream>>>(bases, K, (int)n_gran, (int)n_tiles, passes);
+  SCN_CHECK_LAUNCH();
+  // (8-byte aligned behind the n_tiles + 1 prefix entries)
+  k_sk_slices<<<dim3((SCN_SK_SLICES + 256) / 256, SCN_SK_MAX_NCB), 256, 0, stream>>>(passes, (int)n_tiles, (int2 *)(passes + ((n_tiles + 2) & ~(int64_t)1)));
   SCN_CHECK_LAUNCH();
   return 0;
+}
+
+size_t scn_tile_passes_bytes(int64_t n_out) {
+  const int64_t n_tiles = (n_out + 127) / 128;
+  return (size_t)(((n_tiles + 2) & ~(int64_t)1) * 4 + (int64_t)SCN_SK_MAX_NCB * (SCN_SK_SLICES + 1) * 8);
 }
 
 int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,

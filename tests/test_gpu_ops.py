@@ -317,6 +317,79 @@ def test_tile4_residual_and_column_statistics_at_384_192(gpu):
     assert_close(part[1], (want * want).sum(0), "column sums of squares")
 
 
+@pytest.mark.parametrize("ci,co,leak", [(128, 128, 0.0), (64, 256, 0.3)])
+def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
+    """k_conv_tile4 as a stream-K launch (scn_conv_forward's tile_passes + sk_state): 637 tiles x 2 column blocks = 1.24 rounds of
+    the 1,024 persistent workgroups -- every slice boundary cuts a tile, whose second piece starts from the slab the first
+    piece published -- and x 4 column blocks = 2.49 rounds (whole tiles first, then the sliced part).  Forward with bias,
+    shortcut and column statistics, then the dInput launch with the batch-norm-backward sums: against the float64 oracle, and
+    BITWISE against the one-workgroup-per-tile launch and against k_conv_tile2 (same summation order in all three); the control
+    block is zero again after every launch."""
+    from occuseg_amd import SCN, _lib
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu, seed=21, n=45000, batch=2, extent=60)
+    N = grid.n
+    lib0 = _lib.load()
+    tiles = (N + 127) // 128
+    assert lib0.scn_conv_plan(27, N, N, N, ci, co, 0) == 401 and tiles == 637  # x 2 = 1.24 rounds, x 4 = 2.49 rounds
+    # the product library's own rule picks stream-K for this launch (half of the last round of workgroups would be empty)
+    gstride = (27 * 4 * (ci // 64) + 8 + 7) // 8 * 8
+    assert lib0.scn_conv_workspace_bytes(27, N, N, N, ci, co, 0) == 1024 * 2 * gstride * 8 + 1024 * 128 * 64 * 4
+    rules, _ = R.submanifold_rules(grid)
+    rng = np.random.default_rng(ci + co)
+    x = (rng.normal(size=(N, ci)) * 2 + rng.normal(size=ci)).astype(np.float32)
+    w = (rng.normal(size=(27, ci, co)) * (2.0 / ci / 27) ** 0.5).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    res = rng.normal(size=(N, co)).astype(np.float32)
+    dy = rng.normal(size=(N, co)).astype(np.float32)
+    gamma, beta = rng.normal(size=ci).astype(np.float32), rng.normal(size=ci).astype(np.float32)
+    xt, wt, bt, rt, dyt, gt, bet = [_t(a, gpu) for a in (x, w, b, res, dy, gamma, beta)]
+    e = torch.empty(0, device=gpu)
+    # y = BN(x): the convolution's input, so that its dInput launch can take the batch norm's backward sums
+    y, sm, si = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+    SCN.BatchNormalization_updateOutput(xt, y, sm, si, torch.zeros(ci, device=gpu), torch.ones(ci, device=gpu), gt, bet, 1e-4, 0.9, True, leak)
+
+    def run():
+        out, sink = torch.empty(0, device=gpu), []
+        SCN.SubmanifoldConvolution_updateOutput(size, F3, m, y, out, wt, bt, 1, residual=rt, stats_out=sink)
+        link = SCN.BnLink(xt, sm, si, gt, bet, leak)
+        d_in = torch.empty(0, device=gpu)
+        SCN.SubmanifoldConvolution_backward(size, F3, m, y, d_in, dyt, wt, torch.zeros(27, ci, co, device=gpu), e, 1, _bn_link=link)
+        part = link.take(d_in)
+        assert part is not None and int(SCN._sk_state(gpu).view(torch.int32).abs().sum().item()) == 0
+        return out, sink[0], d_in, part
+
+    got = {"product": run()}
+    before = SCN.STREAM_K
+    try:
+        lib = _lib.use_tuning_build()
+        lib.scn_set_tuning(18, 0)
+        got["stream-K, every launch"] = run()
+        lib.scn_set_tuning(16, 0)
+        got["one workgroup per tile"] = run()
+        lib.scn_set_tuning(0, 2)
+        got["k_conv_tile2"] = run()
+        lib.scn_set_tuning(0, 4)
+        lib.scn_set_tuning(16, 1)
+        lib.scn_set_tuning(18, 90)
+    finally:
+        _lib.use_product_build()
+        SCN.STREAM_K = before
+    ref = got["one workgroup per tile"]
+    for name, g in got.items():
+        for i, what in enumerate(("forward", "column statistics", "dInput", "batch-norm-backward sums")):
+            if name == "k_conv_tile2" and i in (1, 3):
+                continue  # (its statistics come per 128-row tile as well, but are not the subject here)
+            assert torch.equal(g[i], ref[i]), (name, what)
+    yn = y.cpu().numpy()
+    want, _ = A.conv_forward(yn, w, rules, N, b, dtype=np.float64)
+    assert_close(ref[0].cpu().numpy(), want + res, "stream-K forward %d->%d" % (ci, co))
+    d_in_o, _, _ = A.conv_backward(yn, dy, w, rules, dtype=np.float64)
+    assert_close(ref[2].cpu().numpy(), d_in_o, "stream-K dInput")
+    part = ref[1].double().sum(0).cpu().numpy()
+    assert_close(part[0], (want + res).sum(0), "column sums", scale=np.abs(want + res).sum(0).max())
+
+
 def test_tile4_equals_tile2_bitwise_sweep(gpu):
     """300 randomised launches (clouds of varying density / extent / batch, C_i 64..384, C_o 64..256, submanifold and
     strided rulebooks in both directions, plain / transposed / reversed weights, with and without bias) through

@@ -136,42 +136,39 @@ def test_rulebooks_against_hand_derived_literal_vectors(gpu):
         assert np.array_equal(rb.host_lists()[k], want), k
 
 
-def test_tile_order_is_a_stable_partition_and_changes_nothing(gpu):
-    """scn_tile_order: a permutation of the 128-row tiles -- heavy ones first in index order, the tiles with fewer pairs than
-    0.95 x the mean last in index order -- and scn_conv_forward's result does not depend on it (bitwise)."""
+def test_tile_passes_prefix_and_stream_k_changes_nothing(gpu):
+    """scn_tile_passes: prefix sums over the 128-row tiles of max(1, sum_k ceil(pairs_k(tile) / 32)) -- and scn_conv_forward's
+    result does not depend on whether the launch draws slices of that sequence (stream-K) or whole tiles (bitwise), and
+    the stream-K control block is all zero again after every launch."""
     from occuseg_amd import SCN, _lib
     from occuseg_amd import scenes
     coords, _ = scenes.batch([1000, 1001], 70000)
     size = torch.tensor([4096] * 3)
     f3 = torch.tensor([3, 3, 3])
     outs = []
-    before = SCN.TILE_ORDER
+    before = SCN.STREAM_K
     try:
-        for mode in (0, 1):
-            SCN.TILE_ORDER = mode
+        for mode in (False, True):
+            SCN.STREAM_K = mode
             md = SCN.Metadata_3()
             md.inputLayer(size, torch.from_numpy(coords), 0, 4, gpu)
             rb = md.getSubmanifoldRuleBook(size, f3)
             n = md.getNActive(size)
-            if mode == 1:
-                order = rb.order[1].cpu().numpy()
-                n_tiles = (n + 127) // 128
-                assert sorted(order.tolist()) == list(range(n_tiles))
-                bases = rb.bases[1].cpu().numpy().astype(np.int64)
-                g = np.minimum(np.arange(n_tiles + 1) * 4, bases.shape[1] - 1)
-                work = (bases[:, g[1:]] - bases[:, g[:-1]]).sum(0)
-                heavy = work * 1000 * n_tiles >= 950 * work.sum()
-                want = np.concatenate([np.nonzero(heavy)[0], np.nonzero(~heavy)[0]])
-                assert np.array_equal(order, want) and 0 < heavy.sum() < n_tiles
-            else:
-                assert 1 not in rb.order
+            n_tiles = (n + 127) // 128
+            passes = rb.passes[1].cpu().numpy().astype(np.int64)[:n_tiles + 1]
+            bases = rb.bases[1].cpu().numpy().astype(np.int64)
+            g = np.minimum(np.arange(n_tiles + 1) * 4, bases.shape[1] - 1)
+            per_tile = np.maximum(((bases[:, g[1:]] - bases[:, g[:-1]] + 31) // 32).sum(0), 1)
+            assert np.array_equal(passes, np.concatenate([[0], np.cumsum(per_tile)]))
             torch.manual_seed(0)
             x = torch.randn(n, 64, device=gpu)
             w = torch.randn(27, 64, 64, device=gpu) * 0.05
             out = torch.empty(0, device=gpu)
             assert _lib.load().scn_conv_plan(27, n, n, n, 64, 64, 0) == 401
-            SCN.SubmanifoldConvolution_updateOutput(size, f3, md, x, out, w, torch.empty(0, device=gpu), 1)
+            for _ in range(3):
+                SCN.SubmanifoldConvolution_updateOutput(size, f3, md, x, out, w, torch.empty(0, device=gpu), 1)
+                assert int(SCN._sk_state(gpu).view(torch.int32).abs().sum().item()) == 0
             outs.append(out)
     finally:
-        SCN.TILE_ORDER = before
+        SCN.STREAM_K = before
     assert torch.equal(outs[0], outs[1])

@@ -42,7 +42,7 @@ python3 tools/ab_step.py conv.JOIN_IN_PLACE=0,1 > $E/ab_join_in_place.txt 2>&1
 python3 tools/ab_step.py tune13=0,1 > $E/ab_tile4_global_pass_table.txt 2>&1
 python3 tools/ab_step.py DETERMINISTIC_DW=0,1 > $E/ab_deterministic_dw.txt 2>&1
 python3 tools/ab_step.py tune12=0,1 > $E/ab_dw_direct.txt 2>&1
-python3 tools/ab_tile_order.py > $E/ab_tile_order_layers.txt 2>&1
+python3 tools/ab_stream_k.py > $E/ab_stream_k_layers.txt 2>&1
 python3 tools/cold_cache.py > $E/cold_cache.txt 2>&1
 python3 tools/run_configs.py > $E/configs_cfg2_cfg5.json 2> $E/configs.err
 for mode in end start; do

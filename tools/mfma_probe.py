@@ -19,7 +19,12 @@ MODES = ["2 accumulators, back to back", "8 accumulators", "2 acc, operands from
          "32 per 64: 1 after every 2nd", "16 per 64: 1 after every 4th", "16 per 64: 16 after the 64th", "16 v_pk_add_f32 per 64, after the 64th",
          "asm MFMA, accumulators in VGPRs", "asm MFMA, accumulators in AGPRs",
          "acc in VGPRs + buffer_load_dwordx4 per 4 MFMAs", "acc in AGPRs + buffer_load_dwordx4 per 4 MFMAs",
-         "acc in VGPRs + buffer_load_dwordx4 per 2 MFMAs", "acc in AGPRs + buffer_load_dwordx4 per 2 MFMAs"]
+         "acc in VGPRs + buffer_load_dwordx4 per 2 MFMAs", "acc in AGPRs + buffer_load_dwordx4 per 2 MFMAs",
+         "asm v_add_f32_e32 f, 1.0, f (row 3 as asm)", "asm v_add_f32_e32 f, a[], f (reads an MFMA operand)",
+         "asm v_add_f32_e32 f, g, f (free registers)", "asm v_add_f32_e64 f, g, f (VOP3)", "asm v_add_u32_e32 f, g, f",
+         "asm v_lshl_add_u32 f, g, 2, f (VOP3)", "asm v_pk_add_f32, free registers", "asm v_mad_u32_u24, free registers",
+         "compiler f += a[] (reads an MFMA operand)", "compiler pair f += g", "asm v_mov_b32 f, g (free registers)",
+         "asm v_pk_add_f32 reading an idle accumulator"]
 ONLY = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else None
 
 if __name__ == "__main__":
