@@ -33,7 +33,7 @@ import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 
 
 def build_net(scn, m):
@@ -234,6 +234,7 @@ def main():
     bucket = dp.FlatGradBucket(net.parameters())
     if world > 1:
         bucket.enable_overlap()  # bucketed all-reduce launched from backward as each bucket completes
+        bucket.record_exposed = True
     # torch's fused Adam kernel (same arithmetic as the default foreach implementation: 53.5 -> 51.9 ms per step)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=bool(int(os.environ.get("SCN_BENCH_FUSED_ADAM", "1"))))
 
@@ -328,13 +329,25 @@ def main():
     SCN.PROFILE_KINDS = ("mm", "bn", "rules", "io")
     barrier()
 
+    # N > 1: per rank, the time the main stream stood still for the gradient exchange (end of the backward kernels -> last
+    # bucket complete; the buckets launched from inside backward overlap it) and the active voxels it processed
+    exposed_ms = sorted(e0.elapsed_time(e1) for e0, e1 in bucket.exposed[-(args.steps + 1):-1]) if bucket.exposed else []
+    exposed_med = exposed_ms[len(exposed_ms) // 2] if exposed_ms else 0.0
     t = torch.tensor([dt, float(sites_done)], dtype=torch.float64, device=dev)
+    per_rank = None
     if world > 1:
         tcpu = t.cpu() if backend == "gloo" else t
         tmax = tcpu.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tcpu.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        mine = torch.tensor([exposed_med, float(sites_done), dt], dtype=torch.float64, device=dev)
+        mine = mine.cpu() if backend == "gloo" else mine
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = {"allreduce_exposed_ms": [float(g[0]) for g in gathered],
+                    "active_voxels": [float(g[1]) for g in gathered],
+                    "seconds": [float(g[2]) for g in gathered]}
         dt, total_sites = float(tmax[0]), float(tsum[1])
     else:
         total_sites = float(sites_done)
@@ -357,15 +370,42 @@ def main():
                 launches.append((kernel, shape, ms * per, flops * per, nbytes * per, per))
         peaks = measured_peaks(dev) if world == 1 else None
         hbm_meas = max(peaks["hbm_copy_GBs"], peaks["hbm_read_GBs"]) if peaks else None
+        # HBM bytes per launch of every kernel: rocprofv3 PMC counters cannot be read from inside this process; they are
+        # collected by running THIS command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) and
+        # summarised by tools/pmc_traffic.py, which stamps the file with the hash of the kernel sources it measured.  A file
+        # measured on other sources is refused.
+        counted, traffic_note = {}, None
+        if os.path.exists(TRAFFIC_FILE) and args.m == 64 and args.scenes_per_gpu == 4 and args.sites == 150000:
+            try:
+                tj = json.load(open(TRAFFIC_FILE))
+                if tj.get("source_hash") == source_hash():
+                    counted = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+                    traffic_note = ("profiles/r04_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
+                                    "separate passes; FETCH_SIZE x2 per the gfx950 note), same kernel sources")
+                else:
+                    traffic_note = "profiles/r04_traffic.json was measured on other kernel sources: refused"
+            except (OSError, ValueError, KeyError):
+                counted = {}
         kernels = {}
         for kname, (cnt, flops, nbytes, secs) in sorted(agg.items(), key=lambda kv: -kv[1][3]):
+            # `hbm_frac`: share of the 8 TB/s the launch's HBM traffic amounts to.  The bytes are the SMALLER of the algorithmic
+            # count (SURVEY 8d's formula, which charges e.g. one dOut row per RULE to dWeight although a row that several rules
+            # of a workgroup name is fetched once) and the bytes the counters saw -- a fraction above 1 (round 3: dw_stem 1.66)
+            # only said that the formula over-counts.  `hbm_bytes`: which of the two it is.
+            cb = counted.get(kname, counted.get(kname.replace("_split", "")))
+            algo_pl = nbytes / cnt
+            use = min(algo_pl, cb) if cb else algo_pl
             k = {"launches_per_step": cnt / sampled, "ms_per_step": 1e3 * secs / sampled, "avg_ms": 1e3 * secs / cnt,
-                 "algo_GBs": nbytes / secs / 1e9, "hbm_frac": nbytes / secs / 1e9 / HBM_PEAK_GBS}
+                 "algo_GBs": nbytes / secs / 1e9, "algo_bytes_per_launch": algo_pl,
+                 "counted_bytes_per_launch": cb, "counted_over_algorithmic": (cb / algo_pl) if cb else None,
+                 "hbm_bytes": "counted" if (cb and cb < algo_pl) else "algorithmic",
+                 "hbm_frac": use * cnt / secs / 1e9 / HBM_PEAK_GBS}
             if flops > 0:
                 k["tflops"] = flops / secs / 1e12
                 k["mfma_frac"] = flops / secs / 1e12 / F32_MFMA_PEAK_TFLOPS
+                k["bound"] = "mfma" if flops / max(use * cnt, 1.0) > F32_MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"
             if hbm_meas:
-                k["hbm_frac_of_measured"] = nbytes / secs / 1e9 / hbm_meas
+                k["hbm_frac_of_measured"] = use * cnt / secs / 1e9 / hbm_meas
             kernels[kname] = k
         groups = {"bn": ("bn_fwd", "bn_bwd"), "rules": ("grid_build", "sub_rules", "strided_rules"), "io": ("io",)}
         for g, names in groups.items():  # the HBM-bound parts of the step, summed
@@ -402,22 +442,7 @@ def main():
                                         "kernels; alone_*: the same build on an idle GPU, incl. its ~7 host syncs")
         mm = [k for k in agg if k.startswith(("conv_", "dw_"))]
         dom = max(mm, key=lambda k: agg[k][3]) if mm else None
-        # HBM bytes per launch of the dominant kernel: rocprofv3 PMC counters cannot be read from inside this process;
-        # they are collected by running THIS command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
-        # (separate passes) and summarised by tools/pmc_traffic.py, which stamps the file with the hash of the kernel
-        # sources it measured.  A file measured on other sources is refused.
-        traffic, traffic_note = None, None
-        if os.path.exists(TRAFFIC_FILE) and args.m == 64 and args.scenes_per_gpu == 4 and args.sites == 150000:
-            try:
-                tj = json.load(open(TRAFFIC_FILE))
-                if tj.get("source_hash") == source_hash():
-                    traffic = tj.get(dom or "", {}).get("hbm_bytes_per_launch")
-                    traffic_note = ("profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
-                                    "separate passes; FETCH_SIZE x2 per the gfx950 note), same kernel sources")
-                else:
-                    traffic_note = "profiles/r03_traffic.json was measured on other kernel sources: refused"
-            except (OSError, ValueError):
-                traffic = None
+        traffic = counted.get(dom or "")
         roof = None
         if dom:
             cnt, flops, nbytes, secs = agg[dom]
@@ -440,6 +465,10 @@ def main():
             fl, se = sum(agg[k][1] for k in mm), sum(agg[k][3] for k in mm)
             roof["all_matrix_kernels"] = {"tflops": fl / se / 1e12, "frac": fl / se / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                           "ms_per_step": 1e3 * se / sampled}
+            # the matrix work of a step over the WHOLE step time (rule build, batch norm, optimizer, gaps included)
+            step_s = dt / args.steps
+            roof["whole_step"] = {"tflop_per_step": fl / sampled / 1e12, "tflops": fl / sampled / step_s / 1e12,
+                                  "frac": fl / sampled / step_s / 1e12 / F32_MFMA_PEAK_TFLOPS}
         res = {
             "metric": "active-voxels/s fwd+bwd, ScanNet m64 UNet, 1/2/4/8 MI355X",
             "value": total_sites / dt, "unit": "active-voxels/s", "n_gpus": world,
@@ -467,6 +496,11 @@ def main():
                        "source_hash": source_hash()},
             "roofline": roof, "kernels": kernels, "peaks_measured": peaks,
         }
+        if per_rank is not None:
+            # what the first multi-GPU run has to explain about itself: how long each rank's main stream waited for the
+            # gradient exchange per step (median), and how evenly the voxels fell (scenes differ by +-5 % in sites)
+            res["allreduce_exposed_ms"] = max(per_rank["allreduce_exposed_ms"])
+            res["per_rank"] = per_rank
         # active sites and measured nu (pairs per site of the 3x3x3 rulebook) per UNet level, of the
         # batch of the extra step; the ten matrix launches (kernel, shape) that take the most time
         if seen_md:

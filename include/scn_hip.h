@@ -168,7 +168,10 @@ int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes,
  *   through the workspace and the next one goes on from it, so every output element is still accumulated in (offset, chunk,
  *   pair) order: results are bit-identical with and without it.
  *   sk_state (may be NULL): SCN_SK_STATE_BYTES bytes of device memory that hold ZERO when the launch starts; the launch leaves
- *   them zero.  One such block per stream (launches that may overlap need different blocks).
+ *   them zero.  One such block per stream (launches that may overlap need different blocks).  Launches that split their offsets
+ *   (the coarse levels) use it too: the last of a tile's workgroups to finish adds the partial tiles itself, in the same fixed
+ *   order as the second launch it replaces, and emits the column statistics from the finished tile (scn_conv_stats_blocks
+ *   counts on it: pass colstats to such a launch only together with sk_state).
  *   workspace: scn_conv_workspace_bytes(...) bytes.  Launches with few output tiles (the coarse UNet levels) split their
  *   offsets over several workgroups per tile; the partial tiles go to the workspace and are added in a fixed order, so
  *   every launch is bitwise reproducible run to run (the reference scatters with float atomics,

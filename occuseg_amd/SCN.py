@@ -12,6 +12,7 @@ the C ABI of include/scn_hip.h.  CPU tensors are refused: there is no CPU path.
 import contextlib
 import os
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -95,6 +96,10 @@ PREBUILD = True
 # loop runs ~6 % behind hardware re-dispatch: launches of 2.83 or 4.59 rounds keep one workgroup per tile; DESIGN.md section 3.3,
 # profiles/r04_ab_stream_k.txt).  False: never (A/B: tools/ab_step.py STREAM_K=0,1)
 STREAM_K = os.environ.get("SCN_STREAM_K", "1") != "0"
+# launches that split their offsets over several workgroups per tile (the coarse levels): the last workgroup of a tile adds the
+# partial tiles itself (scn_conv_forward's sk_state) instead of a second launch, and emits the batch norm's statistics.
+# False: k_split_reduce as in round 3 (A/B: tools/ab_step.py SPLIT_FUSED=0,1)
+SPLIT_FUSED = os.environ.get("SCN_SPLIT_FUSED", "1") != "0"
 _SK_STATE = {}  # (device index, stream handle) -> the zeroed control block of that stream's stream-K launches
 
 
@@ -545,6 +550,7 @@ _WPACK = {}          # key -> _PackedWeight
 _WEPOCH = [1]
 _BWD_SEEN = [False]
 _WTABLE = {}         # device index -> (signature, descriptor tensor, total blocks)
+_REPACK_EVENT = {}   # device index -> event recorded behind the last batched re-pack (for readers on other streams)
 WPACK_CACHE = True
 WPACK_STATS = {"single": 0, "batch": 0, "batch_entries": 0}  # launches since import (tests, bench)
 
@@ -603,6 +609,14 @@ def _repack_all(device):
         dev_desc = torch.from_numpy(desc.view(np.uint8).copy()).to(device)
         tab = _WTABLE[device.index] = (sig, dev_desc, first)
     check(lib.scn_weight_pack_batch(ptr(tab[1]), len(live), tab[2], stream()))
+    # (the packed copies are re-made on the CURRENT stream; a reader on another stream -- DataParallel-style threads -- must
+    #  wait for this: _REPACK_EVENT[device index] is recorded behind every batched re-pack)
+    ev = _REPACK_EVENT.get(device.index)
+    if ev is None:
+        ev = _REPACK_EVENT[device.index] = [torch.cuda.Event(), 0]
+    cur = torch.cuda.current_stream(device)
+    ev[0].record(cur)
+    ev[1] = cur.cuda_stream
     WPACK_STATS["batch"] += 1
     WPACK_STATS["batch_entries"] += len(live)
     for ent, base in live:
@@ -626,6 +640,9 @@ def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
         _repack_all(weight.device)  # stamps every live entry, this one included (unless it was dropped)
         ent = _WPACK.get(key)
     if ent is not None and ent.epoch == _WEPOCH[0] and ent.version == weight._version:
+        ev = _REPACK_EVENT.get(weight.device.index)
+        if ev is not None and ev[1] != stream():  # re-packed on ANOTHER stream: this one waits for that launch
+            torch.cuda.current_stream(weight.device).wait_event(ev[0])
         return ent.wpack, 1
     lib = _lib_()
     if ent is None:
@@ -669,13 +686,14 @@ class BnLink(object):
 
     def offer(self, grad, partials):
         self.partials = partials
-        self.grad_key = (grad.data_ptr(), grad._version, tuple(grad.shape)) if partials is not None else None
+        # (a weak reference, not the address: a hook that clones and frees the gradient can put another tensor at that address)
+        self.grad_key = (weakref.ref(grad), grad._version) if partials is not None else None
 
     def take(self, grad):
         """the partial sums, if `grad` is exactly the tensor they were taken from (nothing was added into it since)"""
         p, key = self.partials, self.grad_key
         self.partials, self.grad_key = None, None
-        if p is not None and grad.is_contiguous() and key == (grad.data_ptr(), grad._version, tuple(grad.shape)):
+        if p is not None and grad.is_contiguous() and key[0]() is grad and key[1] == grad._version:
             return p
         return None
 
@@ -701,16 +719,21 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     assert K == rb.K, (K, rb.K)
     assert weight.is_contiguous() and inp.size(1) == Ci
     uniq = int(rb.unique_col is not None and (rb.unique_col == out_col or rb.unique_col == 2))
-    kind = lib.scn_conv_plan(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq) // 100
     # `inp` may be a column slice of a wider row-major tensor (the right half of a joined gradient): the pipelined kernels
     # read it in place through its leading dimension; `out_view`: a preallocated slice the result is written into (the
-    # right half of a joined tensor; the one-contribution-per-row kernel only)
+    # right half of a joined tensor; the one-contribution-per-row kernel only).  The library plans a strided input by the
+    # rows its span WOULD hold at C_i planes (scn_conv_forward): the plan, workspace and statistics queries below are asked
+    # with the same number, and where that plan cannot read a slice the input is copied (round-3 advisor).
     ld_in = 0
+    n_plan = inp.size(0)
     if not inp.is_contiguous():
-        if _row_slice(inp) and kind in (2, 4, 5):
-            ld_in = inp.stride(0)
-        else:
+        if _row_slice(inp):
+            n_eff = (inp.size(0) * inp.stride(0) + Ci - 1) // Ci
+            if lib.scn_conv_plan(K, rb.stride, n_eff, n_out, Ci, Co, uniq) // 100 in (2, 4, 5):
+                ld_in, n_plan = inp.stride(0), n_eff
+        if not ld_in:
             inp = inp.contiguous()
+    kind = lib.scn_conv_plan(K, rb.stride, n_plan, n_out, Ci, Co, uniq) // 100
     ld_out = 0
     if out_view is not None:
         assert kind == 5 and _row_slice(out_view) and tuple(out_view.shape) == (n_out, Co), (kind, out_view.shape)
@@ -721,7 +744,7 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
         assert residual.is_contiguous() and tuple(residual.shape) == (n_out, Co) and residual.data_ptr() != out.data_ptr()
     wpack, ready = _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co)
     # launches with few output tiles split their offsets over workgroups; partial tiles go through this workspace
-    ws_bytes = lib.scn_conv_workspace_bytes(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
+    ws_bytes = lib.scn_conv_workspace_bytes(K, rb.stride, n_plan, n_out, Ci, Co, uniq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=inp.device) if ws_bytes else None
     # column statistics of the result for the batch norm that consumes it (stats_out: a list that receives the tensor)
     cstats = None
@@ -730,7 +753,9 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                                     and bn_link.x.is_contiguous()):
         bn_link = None
     if stats_out is not None or bn_link is not None:
-        nblk = lib.scn_conv_stats_blocks(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
+        nblk = lib.scn_conv_stats_blocks(K, rb.stride, n_plan, n_out, Ci, Co, uniq)
+        if kind == 2 and not SPLIT_FUSED and lib.scn_conv_plan(K, rb.stride, n_plan, n_out, Ci, Co, uniq) % 100 > 1:
+            nblk = 0  # (a split launch emits statistics only when it adds its partial tiles itself: sk_state)
         if nblk > 0:
             cstats = torch.empty((nblk, 2, Co), dtype=torch.float32, device=inp.device)
             if bn_link is not None:
@@ -744,14 +769,14 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                                ptr(rb.passes.get(out_col)) if STREAM_K else None, ptr(rb.counts), K, rb.stride,
                                in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ld_in, ld_out, ptr(wpack), ready, ptr(ws), ws_bytes,
-                               ptr(_sk_state(inp.device)) if STREAM_K and kind == 4 else None, stream()))
+                               ptr(_sk_state(inp.device)) if (STREAM_K and kind == 4) or (SPLIT_FUSED and kind == 2) else None, stream()))
     if bn_link is not None:
         bn_link.offer(out, cstats if bnb is not None else None)
     # algorithmic work of one launch: flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
     if ev is not None:
         R = rb.total_pairs
-        code = lib.scn_conv_plan(K, rb.stride, inp.size(0), n_out, Ci, Co, uniq)
+        code = lib.scn_conv_plan(K, rb.stride, n_plan, n_out, Ci, Co, uniq)
         name = _CONV_KERNELS.get(code // 100, "conv") + ("_split" if code % 100 > 1 else "")
         if code // 100 == 0 and Ci <= 4 and Co % 16 == 0 and not w_transposed and residual is None:
             name = "conv_stem"  # k_conv_stem: the narrow-input layer as a GEMM on the matrix cores
@@ -1301,3 +1326,60 @@ for _n in ("ActivePooling_updateOutput", "ActivePooling_updateGradInput",
            "AffineReluTrivialConvolution_backward", "BatchwiseMultiplicativeDropout_updateOutput",
            "BatchwiseMultiplicativeDropout_updateGradInput", "LeakyReLU_updateOutput", "LeakyReLU_updateGradInput"):
     globals()[_n] = _not_in_scope(_n)
+
+
+# ---- tracing: a roctx range around every boundary function, as the reference's EASY_FUNCTION / EASY_BLOCK ranges
+# (sparseconvnet/SCN/CUDA/Convolution.cpp:112-154, easy_profiler) -- so that `rocprofv3 --kernel-trace --marker-trace` attributes
+# the kernels of a step to layers.  Off unless SCN_ROCTX=1 (or SCN.enable_roctx()): then every call costs two ctypes calls.
+_ROCTX = [None]
+_TRACED = ("InputLayer_updateOutput", "InputLayer_updateGradInput", "OutputLayer_updateOutput", "OutputLayer_updateGradInput",
+           "SubmanifoldConvolution_updateOutput", "SubmanifoldConvolution_backward", "Convolution_updateOutput",
+           "Convolution_backward", "Deconvolution_updateOutput", "Deconvolution_backward", "BatchNormalization_updateOutput",
+           "BatchNormalization_backward", "NetworkInNetwork_updateOutput", "NetworkInNetwork_updateGradInput",
+           "NetworkInNetwork_backward")
+
+
+def _traced(name, fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        lib = _ROCTX[0]
+        if lib is None:
+            return fn(*args, **kwargs)
+        # the range's label: the function and the shapes of its feature / weight tensors, e.g.
+        # "SubmanifoldConvolution_updateOutput [601674x64] [27x64x64]"
+        shapes = " ".join("[" + "x".join(str(d) for d in a.shape) + "]" for a in args
+                          if torch.is_tensor(a) and a.dim() >= 2 and a.numel() and a.is_floating_point())
+        lib.roctxRangePushA((name + " " + shapes).encode())
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            lib.roctxRangePop()
+    wrapper.untraced = fn
+    return wrapper
+
+
+def enable_roctx(on=True):
+    """roctx ranges around the boundary functions on / off; returns whether they are on (False: libroctx64.so not found)"""
+    if not on:
+        _ROCTX[0] = None
+        return False
+    if _ROCTX[0] is None:
+        for cand in ("libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so"):
+            try:
+                lib = ctypes.CDLL(cand)
+                lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                lib.roctxRangePushA.restype = ctypes.c_int
+                lib.roctxRangePop.restype = ctypes.c_int
+                _ROCTX[0] = lib
+                break
+            except (OSError, AttributeError):
+                continue
+    return _ROCTX[0] is not None
+
+
+for _n in _TRACED:
+    globals()[_n] = _traced(_n, globals()[_n])
+if os.environ.get("SCN_ROCTX", "0") == "1":
+    enable_roctx()

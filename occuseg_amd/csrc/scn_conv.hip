@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per
                  const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
                  const int32_t *__restrict__ bases, int K, int64_t stride, int in_col,
                  int64_t n_out, int n_gran, int Ci, int Co, int ntiles, int ncb, int ksplit,
-                 unsigned in_bytes, unsigned wp_bytes) {
+                 unsigned in_bytes, unsigned wp_bytes, float *__restrict__ final_out = nullptr, unsigned *tickets = nullptr) {
   // requires Ci % CK == 0 (the launcher picks CK as the largest of 64/32/16 dividing Ci)
   constexpr int M = M_ ? M_ : 32 * NW;
   constexpr int COB = NW * COS * 16;
@@ -666,6 +666,73 @@ __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per
   // owns no offset here) goes to slab blockIdx.y and k_split_reduce adds the slabs in a FIXED order: no float
   // atomics, the result does not depend on which workgroup finishes first.
   float *dst = out + (int64_t)blockIdx.y * n_out * Co;
+  bool finished = ksplit == 1;  // this workgroup holds the finished tile in LDS (statistics below)
+  if (ksplit > 1 && tickets != nullptr) {
+    // ... and (round 4) the LAST of a tile's ksplit workgroups to get here does that addition itself, in the same fixed order,
+    // instead of a second launch: 26 launches of k_split_reduce per train step and their gaps are gone, and the complete tile
+    // is in LDS once more, so the column statistics / batch-norm-backward sums below are taken from it as in an unsplit launch
+    // (the coarse levels' batch norms had to make their own statistics pass).  The hand-off that the L2 caches of eight XCDs
+    // require: write-through (sc1) stores of the partial tile, every wave drains them, the barrier, ONE lane draws the tile's
+    // ticket; the workgroup that draws the last one reads all slabs with sc1 loads.  The ticket word goes back to 0.
+    const size_t slab_bytes = (size_t)n_out * (size_t)Co * 4;
+    const unsigned row_b = (unsigned)Co * 4u;
+    const unsigned tile_b = (unsigned)(((size_t)o0 * (size_t)Co + (size_t)co0) * 4);  // (< 4 GiB: the slabs of a split launch are a few MB)
+    {
+      const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, (int)slab_bytes, 0x00020000);
+      for (int i = tid; i < rows * (COB / 4); i += NT) {
+        const int r = i / (COB / 4), c4 = i % (COB / 4);
+        const floatx4 v = *(const floatx4 *)(o_tile + r * OS + c4 * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ds,
+                                               tile_b + (unsigned)r * row_b + (unsigned)c4 * 16u, 0, 16 /* sc1 */);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) nk_s = (int)__hip_atomic_fetch_add(tickets + lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(nk_s) != ksplit - 1) return;
+    if (tid == 0) __hip_atomic_store(tickets + lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory");
+    // (slab 0 first -- it holds bias and shortcut --, then 1, 2, ...: k_split_reduce's order.  The split is 3-, 9- or 27-fold:
+    //  three slabs' worth of loads are in flight at a time, eight 16-byte pieces per thread each)
+    constexpr int NE = M * (COB / 4) / NT;
+    floatx4 acc[NE];
+    unsigned off[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = tid + e * NT, r = i / (COB / 4), c4 = i % (COB / 4);
+      off[e] = r < rows ? tile_b + (unsigned)r * row_b + (unsigned)c4 * 16u : 0x80000000u;  // (out of range: reads zeros)
+    }
+    for (int j0 = 0; j0 < ksplit; j0 += 3) {
+      u32x4 b[3][NE];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const __amdgpu_buffer_rsrc_t ps = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)min(j0 + u, ksplit - 1) * (size_t)n_out * (size_t)Co), 0,
+                                                                            (int)slab_bytes, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) b[u][e] = __builtin_amdgcn_raw_buffer_load_b128(ps, off[e], 0, 16 /* sc1 */);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (j0 + u < ksplit) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const floatx4 bf = floatx4{__uint_as_float(b[u][e].x), __uint_as_float(b[u][e].y), __uint_as_float(b[u][e].z), __uint_as_float(b[u][e].w)};
+            acc[e] = (j0 + u == 0) ? bf : acc[e] + bf;
+          }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = tid + e * NT, r = i / (COB / 4), c4 = i % (COB / 4);
+      if (r < rows) {
+        *(floatx4 *)(o_tile + r * OS + c4 * 4) = acc[e];
+        *(floatx4 *)(final_out + (o0 + r) * Co + co0 + c4 * 4) = acc[e];
+      }
+    }
+    __syncthreads();
+    finished = true;
+  } else
   for (int i = tid; i < rows * (COB / 4); i += NT) {
     const int r = i / (COB / 4), c4 = i % (COB / 4);
     *(float4 *)(dst + (o0 + r) * Co + co0 + c4 * 4) = *(const float4 *)(o_tile + r * OS + c4 * 4);
@@ -673,7 +740,7 @@ __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per
   // Column statistics of the finished tile (sum, sum of squares per output plane over the tile's rows) while it is still
   // in LDS: the batch norm that consumes this tensor takes them instead of reading the tensor once more
   // (colstats [ntiles][2][Co], one deterministic partial per tile; the fp64 finalize of scn_bn_forward adds them up).
-  if (colstats.out != nullptr && ksplit == 1) {
+  if (colstats.out != nullptr && finished) {
     constexpr int G = NT / COB;  // threads per column
     const int c = tid % COB, g = tid / COB;
     float cs = 0.f, css = 0.f;
@@ -3205,6 +3272,8 @@ SCN_KNOB g_conv_sk_min_loss = 90;   // tuning key 18: ... and only where one wor
                                     // profiles/r04_ab_stream_k.txt): the persistent loop runs ~6 % behind hardware re-dispatch, so stream-K gains
                                     // 6 % at 2.70 rounds, breaks even at 2.83 and loses 8 % at 4.59.  0: every eligible launch (A/B)
 SCN_KNOB g_conv_sk_min_items = 1024;  // tuning key 17: ... for launches with at least this many (tile, column block) items
+SCN_KNOB g_conv_split_fused = 1;  // tuning key 19: 0 = the partial tiles of a split launch are added by a second launch (k_split_reduce) even
+                                  // when the caller hands in a control block (A/B)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
 
 // Which kernel a gather-mm launch gets.  One function decides for the launcher AND for scn_conv_workspace_bytes.
@@ -3289,7 +3358,7 @@ template <int NW, int COS, int CK, int NWM = 1, int M_ = 0>
 static int launch_tile2(const float *in, float *out, const float *Wp, const float *bias, const float *residual, StatsArg colstats,
                         const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                         int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
-                        hipStream_t stream) {
+                        hipStream_t stream, unsigned *tickets = nullptr) {
   constexpr int M = M_ ? M_ : 32 * NW;
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
   const int ntiles = (int)((n_out + M - 1) / M);
@@ -3297,10 +3366,14 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   const unsigned in_bytes = (unsigned)((n_in - 1) * (colstats.ldi ? colstats.ldi : Ci) * 4 + Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
   float *dst = ksplit > 1 ? part : out;
   const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
+  // split launches: with a control block the last workgroup of a tile adds the partial tiles itself (one ticket word per
+  // (tile, plane block) behind the stream-K words; slabs < 4 GiB: 32-bit buffer offsets)
+  const bool fused = ksplit > 1 && tickets != nullptr && g_conv_split_fused && ksplit % 3 == 0 &&
+                     (int64_t)ntiles * ncb + SK_STATE_WORDS <= (int64_t)(SCN_SK_STATE_BYTES / 4) && n_out * Co * 4 < ((int64_t)1 << 31);
 #define SCN_LAUNCH_T2(D)                                                                                   \
   k_conv_tile2<NW, COS, CK, D, NWM, M_><<<grid2, 64 * NW * NWM, 0, stream>>>(                             \
       in, dst, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, ksplit, \
-      in_bytes, wp_bytes)
+      in_bytes, wp_bytes, out, fused ? tickets + SK_STATE_WORDS : nullptr)
 #ifdef SCN_TUNING
   if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 1) SCN_LAUNCH_T2(1);
   else if (NW == 4 && CK == 64 && NWM == 1 && g_conv_dbg == 9) SCN_LAUNCH_T2(9);
@@ -3320,7 +3393,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
     SCN_LAUNCH_T2(0);
 #undef SCN_LAUNCH_T2
   SCN_CHECK_LAUNCH();
-  if (ksplit > 1) {
+  if (ksplit > 1 && !fused) {
     const int64_t total4 = n_out * Co / 4;
     int64_t g = (total4 + 255) / 256;
     if (g > 2048) g = 2048;
@@ -3531,14 +3604,14 @@ template <int NW>
 static int launch_tile2_ck(const float *in, float *out, const float *Wp, const float *bias, const float *residual, StatsArg colstats,
                            const int32_t *rules, const int32_t *bases, int K, int64_t stride,
                            int in_col, int64_t n_out, int64_t n_in, int Ci, int Co, int ksplit, float *part,
-                           hipStream_t stream) {
+                           hipStream_t stream, unsigned *tickets) {
 #ifdef SCN_TUNING
   if (NW == 4 && g_conv_wide && Ci % 64 == 0 && Co % 128 == 0 && ksplit == 1)
     return launch_tile2<4, 2, 64, 2, 128>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, 1, part, stream);
 #endif
-  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
-  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
-  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream);
+  if (Ci % 64 == 0) return launch_tile2<NW, 1, 64>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream, tickets);
+  if (Ci % 32 == 0) return launch_tile2<NW, 1, 32>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream, tickets);
+  return launch_tile2<NW, 1, 16>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, ksplit, part, stream, tickets);
 }
 
 extern "C" {
@@ -3571,6 +3644,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 16 && value >= 0 && value <= 2) { g_conv_sk = value; return 0; }
   if (key == 17 && value >= 1) { g_conv_sk_min_items = value; return 0; }
   if (key == 18 && value >= 0 && value <= 1000) { g_conv_sk_min_loss = value; return 0; }
+  if (key == 19) { g_conv_split_fused = value; return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }
@@ -3590,9 +3664,17 @@ int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out
   const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
   if (p.kind == 5) return expand_waves(n_out, K);
   if (p.kind != 2 && p.kind != 4) return 0;  // generic / fallback kernels do not emit statistics
-  if (p.ksplit > 1) return 0;  // coarse levels: the batch norm's own statistics pass over a few thousand rows is cheaper
-                               // than a reduction kernel that also reduces columns (A/B: +0.2 ms per step)
   const int M = p.kind == 4 ? tile4_rows(p.ksplit) : 32 * p.nw;
+  if (p.ksplit > 1) {
+    // split launches (coarse levels): the workgroup that adds a tile's partial tiles (k_conv_tile2 with a control block) has
+    // the finished tile in LDS and emits its sums like an unsplit launch.  Tensors of <= 2048 rows: none -- their batch norms
+    // run as ONE launch (k_bn_small_fwd / _bwd), which a hand-over would turn into two.  (A reduction kernel that also
+    // reduced columns cost +0.2 ms per step in round 2.)
+    const int64_t items = ((n_out + M - 1) / M) * (Co / (16 * p.nw));
+    const bool fused = p.kind == 2 && g_conv_split_fused && p.ksplit % 3 == 0 && items + 32 <= (int64_t)(SCN_SK_STATE_BYTES / 4) &&
+                       n_out * Co * 4 < ((int64_t)1 << 31);
+    return fused && n_out > 2048 ? (n_out + M - 1) / M : 0;
+  }
   return (n_out + M - 1) / M;
 }
 
@@ -3708,6 +3790,8 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
     if (p.ksplit > 1)
       SCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4,
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
+    SCN_REQUIRE(p.ksplit == 1 || colstats_out == nullptr || sk_state != nullptr,
+                "scn_conv_forward: a launch that splits its offsets emits column statistics only with sk_state");
     float *part = (float *)workspace;
     if (p.kind == 4 && p.ksplit == 1 && workspace != nullptr)
       SCN_REQUIRE(workspace_bytes >= tile4_workspace_bytes(K, n_out, Ci, Co),
@@ -3716,10 +3800,10 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
       return launch_tile4(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part,
                           p.ksplit == 1 ? tile_passes : nullptr, (unsigned *)sk_state, stream);
     switch (p.nw) {
-      case 4: return launch_tile2_ck<4>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      case 3: return launch_tile2_ck<3>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      case 2: return launch_tile2_ck<2>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
-      default: return launch_tile2_ck<1>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream);
+      case 4: return launch_tile2_ck<4>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream, (unsigned *)sk_state);
+      case 3: return launch_tile2_ck<3>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream, (unsigned *)sk_state);
+      case 2: return launch_tile2_ck<2>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream, (unsigned *)sk_state);
+      default: return launch_tile2_ck<1>(in, out, Wp, bias, residual, colstats, rules, bases, K, stride, in_col, n_out, n_in, Ci, Co, p.ksplit, part, stream, (unsigned *)sk_state);
     }
   }
   const int n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);

@@ -55,6 +55,8 @@ class FlatGradBucket(object):
                 self.buckets.append((start, end, first, i + 1))
                 start, first = end, i + 1
         self._work = []
+        self.record_exposed = False  # bench: time the main stream waits for the exchange at the end of every step
+        self.exposed = []            # ... as (start event, end event) pairs
         self._hooks = []
         self._launched = set()
         self._overlap = False
@@ -185,11 +187,18 @@ class FlatGradBucket(object):
             warnings.warn("FlatGradBucket: some .grad tensors were not views of the flat buffer at all_reduce time "
                           "-- their values were copied in; use bucket.zero() instead of zero_grad()")
         SCN.dw_join()  # single process too: the optimizer reads what the side stream accumulates
+        timed = self.record_exposed and self._distributed()
+        if timed:  # how long the main stream stands still for the exchange: from the end of the backward pass' kernels ...
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for b in range(len(self.buckets)):
             self._launch(b)
         for w in self._work:
             w.wait()
         self._work = []
+        if timed:  # ... to the completion of the last bucket (the buckets launched from backward overlap it: not counted)
+            e1.record()
+            self.exposed.append((e0, e1))
         if self._distributed():
             self.flat.div_(dist.get_world_size())
 

@@ -100,6 +100,7 @@ class JoinConcatTable(ConcatTable):
                 and self.training and not hooked and torch.is_grad_enabled()):
             return ConcatTable.forward(self, input)
         join = GradJoin(armed=False)
+        join.left = input.features
         x = path[0](input, join=join)
         for mod in path[1:]:
             x = mod(x)
@@ -149,6 +150,8 @@ class JoinTable(torch.nn.Sequential):
                                          base.data_ptr() + 4 * left.size(1) and left.dtype == base.dtype):
                 base = None
             join = getattr(input[1], "left_join", None)
+            if join is not None and join.left is not left:
+                join = None  # (the table's left entry is not the tensor the batch norm at the head of the path received)
             if join is not None:
                 join.armed = True
             out = _like(input[0], _JoinFunction.apply(left, right, base, join))

@@ -142,6 +142,16 @@ class _RuleConv(Module):
     def output_spatial_size(self, in_size):
         raise NotImplementedError
 
+    # weights that change without an optimizer step or a backward pass in between: a new weight epoch (round-3 advisor)
+    def _load_from_state_dict(self, *args, **kwargs):
+        Module._load_from_state_dict(self, *args, **kwargs)
+        SCN.weights_changed()
+
+    def _apply(self, fn, *args, **kwargs):
+        res = Module._apply(self, fn, *args, **kwargs)
+        SCN.weights_changed()
+        return res
+
     def forward(self, input, residual=None, join=None):
         """``residual`` (submanifold only; used by the residual blocks of scn.UNet): features added to the output
         inside the convolution kernel; ``join``: see tensor.GradJoin (the residual is the block's input)"""

@@ -22,19 +22,28 @@ class GradJoin(object):
     to autograd; the second adds it INSIDE its own kernel (batch norm backward's apply pass, the NiN dInput's output
     tile) and returns the sum: the elementwise add kernel autograd would launch at x disappears.  Whichever order the
     engine runs the two in, the sum is the same.  One object per forward pass: nothing survives a failed backward."""
-    __slots__ = ("pending", "armed")
+    __slots__ = ("pending", "armed", "left", "task")
 
     def __init__(self, armed=True):
         self.pending = None
+        self.task = None
         self.armed = armed  # False: created by one side only (JoinConcatTable); the other side (JoinTable) arms it in forward
+        self.left = None    # JoinConcatTable: the features tensor whose two gradients meet here (JoinTable checks it is its left entry)
+
+    @staticmethod
+    def _task():
+        try:  # the backward pass that is running (a retried or second backward over a retained graph is another one)
+            return torch._C._current_graph_task_id()
+        except AttributeError:
+            return None
 
     def put(self, grad):
-        assert self.pending is None
-        self.pending = grad
+        # (a gradient left by a backward pass that raised before the other side took it is replaced, not added twice)
+        self.pending, self.task = grad, self._task()
 
     def take(self):
         g, self.pending = self.pending, None
-        return g
+        return g if self.task == self._task() else None
 
 
 class SparseConvNetTensor(object):
@@ -60,6 +69,7 @@ class SparseConvNetTensor(object):
         self._colstats = None
         self._bn_link = None
         self.join_base = None
+        self.left_join = None
 
     def set_colstats(self, segments):
         """Column statistics of ``features`` emitted by the kernel(s) that produced it (not in the reference).  They

@@ -27,12 +27,21 @@ def _free_port():
 def pytest_collection_finish(session):
     """tests/test_gpu_dp.py needs child processes that use the GPU.  They are started HERE, before any test (and so
     before any HIP call in this process): a process that has initialised the GPU must not fork+exec on this pool."""
+    jobs = session.config._scn_jobs
+    # tests/test_gpu_memory_safety.py: the five guard-allocator runs of the train step, one after the other in a chain that is
+    # started here too (round-3 verdict: the test itself started them from a process that had long since initialised the GPU)
+    guard = [item.callspec.id for item in session.items
+             if item.fspath.basename == "test_gpu_memory_safety.py" and hasattr(item, "callspec")]
+    if guard and os.path.exists("/dev/kfd"):
+        gdir = tempfile.mkdtemp(prefix="scn_guard_")
+        jobs["guard"] = {"dir": gdir, "proc": subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "guard_chain.py"), gdir] + guard,
+            stdout=open(os.path.join(gdir, "chain.log"), "w"), stderr=subprocess.STDOUT, cwd=ROOT)}
     names = {item.name for item in session.items if item.fspath.basename == "test_gpu_dp.py"}
     if not names or not os.path.exists("/dev/kfd"):
         return
     tmp = tempfile.mkdtemp(prefix="scn_dp_")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    jobs = session.config._scn_jobs
     if "test_real_unet_under_process_group_world2" in names:
         port = str(_free_port())
         out = os.path.join(tmp, "dp_verdict.json")

@@ -140,3 +140,39 @@ def test_no_kernel_uses_scratch():
     assert len(ks) > 100
     bad = [(n, s) for n, s, _, _ in ks if s > 0 and not mod.ALLOWED.search(n)]
     assert not bad, bad
+
+
+def test_roctx_ranges_wrap_the_boundary_functions():
+    """SCN.enable_roctx(): a roctx range around every boundary function (the reference's EASY_FUNCTION ranges,
+    sparseconvnet/SCN/CUDA/Convolution.cpp:112-154), labelled with the function and its tensor shapes; balanced when the call
+    raises; nothing at all when off."""
+    from occuseg_amd import SCN
+
+    class Fake(object):
+        def __init__(self):
+            self.log = []
+
+        def roctxRangePushA(self, label):
+            self.log.append(label.decode())
+            return 0
+
+        def roctxRangePop(self):
+            self.log.append("pop")
+            return 0
+
+    fake = Fake()
+    x = torch.zeros(5, 16)
+    before = SCN._ROCTX[0]
+    try:
+        SCN._ROCTX[0] = fake
+        e, v = torch.empty(0), torch.zeros(16)
+        with pytest.raises(RuntimeError):  # CPU tensors are refused -- inside the range
+            SCN.BatchNormalization_updateOutput(x, e, e, e, v, v, v, v, 1e-4, 0.9, True, 0.0)
+        assert fake.log == ["BatchNormalization_updateOutput [5x16]", "pop"]
+        SCN._ROCTX[0] = None
+        with pytest.raises(RuntimeError):
+            SCN.BatchNormalization_updateOutput(x, e, e, e, v, v, v, v, 1e-4, 0.9, True, 0.0)
+        assert len(fake.log) == 2
+    finally:
+        SCN._ROCTX[0] = before
+    assert all(hasattr(getattr(SCN, n), "untraced") for n in SCN._TRACED)

@@ -76,6 +76,35 @@ def test_checker_follows_branches(tmp_path, capsys):
     assert "still in flight" in capsys.readouterr().out
 
 
+SCALAR = """
+_ZN3scn12k_conv_tile6ILi128ELb0ELi0EEEvPKf:
+	s_load_dwordx2 s[0:1], s[4:5], 0x0
+.LBB0_1:
+	;;#ASMSTART
+	s_load_dwordx2 s[60:61], s[40:41], s7
+	;;#ASMEND
+	v_mfma_f32_16x16x4_f32 a[0:3], v20, v21, a[0:3]
+%s
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	s_mov_b64 s[62:63], s[60:61]
+	;;#ASMEND
+	s_lshr_b32 s8, s63, 12
+	s_cbranch_vccnz .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_checker_tracks_scalar_loads_issued_from_inline_asm(tmp_path, capsys):
+    """round-3 advisor: k_conv_tile4 requests its pass-table entry with an s_load in one asm statement and picks it up ~430
+    instructions later in another; nothing proved that hipcc leaves the destination pair alone in between"""
+    assert _run(SCALAR % "\ts_add_u32 s9, s9, 1", tmp_path) == 0
+    assert _run(SCALAR % "\ts_mov_b32 s9, s61", tmp_path) == 1            # reads the pair before the wait
+    assert "scalar load still in flight" in capsys.readouterr().out
+    assert _run(SCALAR % "\ts_mov_b32 s60, 0", tmp_path) == 1             # re-homes something into it
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 def test_current_kernel_source_is_clean():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py")], capture_output=True,

@@ -567,10 +567,11 @@ def test_network_with_and_without_statistics_handover(gpu):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), "statistics hand-over: grads", rel=2e-4)
 
 
-# dInput launches: 64->64 and 128->64 on k_conv_tile4, 96->64 on the unsplit k_conv_tile2; the last one (a small grid) is
-# an offset-split launch, which emits no sums: the batch norm then runs its own statistics pass
+# dInput launches: 64->64 and 128->64 on k_conv_tile4, 96->64 on the unsplit k_conv_tile2; the fourth (a small grid) is an
+# offset-split launch whose last workgroup per tile adds the partial tiles and emits the sums (round 4); the fifth (<= 2048
+# rows) emits none: the batch norm then runs its own one-launch pass
 @pytest.mark.parametrize("ci,co,n,extent,leak", [(64, 64, 72000, 60, 0.0), (64, 96, 72000, 60, 0.2), (128, 64, 20000, 40, 1.0),
-                                                 (64, 64, 3000, 20, 0.0)])
+                                                 (64, 64, 3000, 20, 0.0), (64, 64, 900, 12, 0.0)])
 def test_bn_backward_reductions_from_the_dinput_launch(gpu, ci, co, n, extent, leak):
     """scn_conv_forward(bn_bwd): the dInput launch of a convolution whose input was y = BN(x) leaves sum d' and
     sum (x - mean) d' per block of rows; scn_bn_backward_ext finishes the batch norm's backward pass from them, with another
@@ -597,7 +598,10 @@ def test_bn_backward_reductions_from_the_dinput_launch(gpu, ci, co, n, extent, l
     d_in, gw = torch.empty(0, device=gpu), torch.zeros(27, ci, co, device=gpu)
     SCN.SubmanifoldConvolution_backward(size, F3, m, y, d_in, _t(dy, gpu), _t(w, gpu), gw, e, 1, _bn_link=link)
     partials = link.take(d_in)
-    assert (partials is None) == (n == 3000)
+    from occuseg_amd import _lib
+    code = _lib.load().scn_conv_plan(27, N, N, N, co, ci, 0)
+    assert (n > 3000) == (code % 100 == 1) and (n == 900) == (N <= 2048)
+    assert (partials is None) == (N <= 2048)
     assert partials is None or partials.shape[1:] == (2, ci)
     dgam, dbet = torch.zeros(ci, device=gpu), torch.zeros(ci, device=gpu)
     dx = torch.empty(0, device=gpu)

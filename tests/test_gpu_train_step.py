@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close
+from helpers import assert_close, device_masks
 
 pytestmark = pytest.mark.gpu
 
@@ -63,14 +63,15 @@ def test_forward_and_dinput_follow_the_optimizer(gpu, fused):
     # dInput after the update: the whole backward pass against the float64 oracle on the updated parameters
     from oracle import torch_ref
     opt.zero_grad()
-    out = net(batch)
+    out, masks = device_masks(net, scn, lambda: net(batch))
     gsel = torch.from_numpy(np.random.default_rng(0).normal(size=tuple(out.shape)))
     (out * gsel.to(gpu, torch.float32)).sum().backward()
-    ref_out, stats = torch_ref.ref_forward(net, coords, feats, torch.float64)
+    # (the oracle differentiates over the device's own activation masks: every gradient at 1e-4, not the 1e-2 of round 3)
+    ref_out, stats = torch_ref.ref_forward(net, coords, feats, torch.float64, masks=masks)
     (ref_out * gsel).sum().backward()
     for mod in net.modules():
         for name, leaf in (stats["params"].get(id(mod)) or {}).items():
-            assert_close(getattr(mod, name).grad.cpu().numpy(), leaf.grad.numpy(), "grad %s.%s" % (mod, name), rel=1e-2)
+            assert_close(getattr(mod, name).grad.cpu().numpy(), leaf.grad.numpy(), "grad %s.%s" % (mod, name), rel=1e-4)
     # a write through .data (no version bump, no optimizer): the next forward pass starts with an InputLayer call
     with torch.no_grad():
         for p in net.parameters():
