@@ -95,6 +95,13 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 __device__ unsigned long long g_stamps[8];
+#ifdef SCN_TUNING
+__device__ int g_sk_prio_dev = 1;  // tuning key 20: 0 = stream-K launches without the alternating wave priority (A/B)
+constexpr bool SK_TUNING_PRIO = true;
+#else
+constexpr int g_sk_prio_dev = 1;
+constexpr bool SK_TUNING_PRIO = false;
+#endif
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
@@ -1002,6 +1009,21 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // the next piece: of the current slice -- the item its END cuts first (that piece feeds the next slice), the whole items,
   // the item its BEGINNING cuts last (that piece waits for the previous slice) -- or of a new slice
   auto sk_next = [&]() __attribute__((always_inline)) {
+#ifdef SCN_TUNING
+    if (na_items_a == (int)0x80000000) {  // (A/B: this binary, but ONE whole item per workgroup as the hardware deals them)
+      if (sk_cur) return false;
+      sk_cur = 1;
+      const int total = ntiles * ncb, bid = blockIdx.x, xcd = bid & 7, j = bid >> 3, CH = 64 * ncb;
+      const int full = (total / (8 * CH)) * (8 * CH);
+      if (bid < full) item = ((j / CH) * 8 + xcd) * CH + j % CH;
+      else {
+        const int rest = total - full, b2 = bid - full, x2 = b2 & 7, j2 = b2 >> 3, q = rest >> 3, r = rest & 7;
+        item = full + (x2 < r ? x2 * (q + 1) : r * (q + 1) + (x2 - r) * q) + j2;
+      }
+      p_lo = 0; p_hi = 0x7fffffff; seed_slab = -1; out_slab = -1;
+      return true;
+    }
+#endif
     for (;;) {
       if (sk_phase == 0) {
         if (!sk_steal_a) {
@@ -1078,6 +1100,15 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   //  addresses of the set-up and the epilogue out of the piece loop, finds no registers for them beside the pass loop's 220
   //  and spills them to scratch)
   if (SK) asm volatile("" : "+v"(tid_opaque));
+  // SK: the two waves that share a SIMD take turns at the higher issue priority, piece by piece.  Waves that the hardware deals
+  // come and go, so which of a SIMD's two is the older one (the one its arbiter prefers) alternates by itself; persistent waves
+  // are all the same age for the whole launch, one of each pair is preferred throughout -- and the same pass loop ran 5 %
+  // slower (4096 whole tiles on 1024 persistent workgroups: +7 % against hardware dispatch without this, +1.4 % with it;
+  // profiles/r04_ab_stream_k.txt).  Which workgroups share SIMDs: those 2 x 256 apart in launch order (four per CU).
+  if (SK && (!SK_TUNING_PRIO || g_sk_prio_dev)) {
+    if ((((int)blockIdx.x >> 9) + gpar) & 1) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   const int tid = SK ? tid_opaque : (int)threadIdx.x;
   const int lane = tid & 63;
   const int li = lane & 15, lq = lane >> 4;
@@ -1318,7 +1349,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // (sk_phase == 0: the next call of sk_next begins with a draw.  Only draws of WHOLE items are made ahead: a slice drawn while
   //  its workgroup still has a piece to finish sits undone, and the slice behind it waits for its first piece -- measured:
   //  launches 7-12 % slower)
-  const bool pf_now = SK && sk_phase == 0 && !sk_steal_a && na_items > 0;
+  const bool pf_now = SK && sk_phase == 0 && !sk_steal_a && na_items > 0 && na_items_a != (int)0x80000000;
   const int pf_slot = sk_par, pf_which = 1;
   unsigned pf_val = 0;
   if (pf_now && tid == 0)
@@ -1584,7 +1615,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   }  // pieces
   if ((DBG & 256) && lane == 0)
     for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
-  if (SK && tid == 0) {  // the last workgroup out leaves the counters as it found them (every flag was reset by its reader)
+  if (SK && tid == 0 && na_items_a != (int)0x80000000) {  // the last workgroup out leaves the counters as it found them (every flag was reset by its reader)
     if (__hip_atomic_fetch_add(sk_state + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
 #pragma unroll
       for (int i = 0; i < 11; ++i)
@@ -3447,6 +3478,7 @@ static bool tile4_sk_plan(int K, int64_t n_out, int Ci, int Co, SkPlan &sp) {
   sp.na_items = (int)scn_sk_whole_items(items);
 #ifdef SCN_TUNING
   if (g_conv_sk == 2) sp.na_items = -(int)(items / 512 * 512);
+  if (g_conv_sk == 3) { sp.na_items = (int)0x80000000; sp.groups = (int)items; }
 #endif
   if (sp.slices + SK_STATE_WORDS > (int)(SCN_SK_STATE_BYTES / 4)) return false;
   sp.gtab_bytes = (size_t)sp.groups * 2 * (size_t)tile4_gtab_stride(K, Ci) * 8;
@@ -3641,10 +3673,11 @@ int scn_set_tuning(int key, int value) {
   if (key == 13) { g_conv_gtab = value; return 0; }
   if (key == 14) { g_conv_expand_nb = value; return 0; }
   if (key == 15) { g_conv_stem_mfma = value; return 0; }
-  if (key == 16 && value >= 0 && value <= 2) { g_conv_sk = value; return 0; }
+  if (key == 16 && value >= 0 && value <= 3) { g_conv_sk = value; return 0; }
   if (key == 17 && value >= 1) { g_conv_sk_min_items = value; return 0; }
   if (key == 18 && value >= 0 && value <= 1000) { g_conv_sk_min_loss = value; return 0; }
   if (key == 19) { g_conv_split_fused = value; return 0; }
+  if (key == 20) { SCN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_prio_dev), &value, sizeof(int))); return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
 }

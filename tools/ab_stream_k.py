@@ -35,12 +35,14 @@ def main():
     ap.add_argument("--m", type=int, default=64)
     ap.add_argument("--min-items", type=int, default=512)
     ap.add_argument("--residual", action="store_true")
+    ap.add_argument("--prio", type=int, default=1, help="0: stream-K launches without the alternating wave priority")
     ap.add_argument("--trunc", type=int, default=0, help="compute only the first TRUNC (tile, column block) items' worth of output rows")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.use_tuning_build()
     lib.scn_set_tuning(17, args.min_items)
     lib.scn_set_tuning(18, 0)  # (every eligible launch, whatever its round count)
+    lib.scn_set_tuning(20, args.prio)
     SCN.STREAM_K = True  # (hand tile_passes and sk_state to every launch: tuning key 16 then decides)
     coords, _ = scenes.batch([args.first_scene + i for i in range(args.scenes)], args.sites)
     md = SCN.Metadata_3()
