@@ -2547,6 +2547,166 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// The same arithmetic as k_conv_expand<1>, one wave per block of 32 pairs x 64 planes -- but the waves are PERSISTENT (two per
+// SIMD) and walk the blocks wave, wave + G, wave + 2 G, ..., and the walk is software-pipelined ACROSS blocks: the pair indices
+// of the next block are requested before this block's first multiply, and its first chunk of rows and weight fragments while
+// this block's last chunk multiplies.  k_conv_expand's wave was a chain of dependent round trips -- list position -> pair
+// indices -> rows -> MFMAs -> shortcut rows -> stores -- of which only the MFMAs do work: 59 TFLOP/s and 1.8 TB/s, on neither
+// roofline (round 3).  Bit-identical to it (same products, same order).  Tuning library only: 0-17 % faster per launch alone (the
+// 600k-row launches not at all: they move 460 MB at 3.3 TB/s), but the train step is 0.3 ms slower with it -- waves that hold
+// their slots for a whole launch and no LDS share CUs with the dWeight kernels of the side stream instead of leaving them room.
+#ifdef SCN_TUNING
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+    k_conv_expand_p(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
+                    const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules,
+                    const int32_t *__restrict__ counts, int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes,
+                    unsigned wp_bytes, int n_items) {
+  constexpr int CK = 32, NS16 = 2, COS = 4, PB = 32, NG = 2;
+  const int lane = threadIdx.x;
+  const int li = lane & 15, lq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)wp_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)((colstats.ldi ? colstats.ldi : Ci) * 4);
+  const int nch = Ci / CK;
+  const int64_t ldo = colstats.ldo ? colstats.ldo : Co;
+  struct Blk {  // one block of the walk: list k, its pairs [p0, p0 + 32), plane block co0; k < 0: past the end of the lists
+    int k, cnt, co0, pb;
+    unsigned roff0, roff1;  // (named members, not arrays: hipcc kept arrays of a struct that is copied in the loop in scratch)
+    int orow0, orow1;
+    bool live0, live1;
+  };
+  static_assert(NG == 2, "two groups of 16 pairs per block");
+  // (list, block of 32 pairs, plane block) of item t: blocks are numbered list after list (scalar: `counts` sits in the
+  //  scalar cache after the first look)
+  auto locate = [&](int t, Blk &b) __attribute__((always_inline)) {
+    int blk = t / ncb;
+    b.pb = blk;
+    b.co0 = (t % ncb) * 64;
+    int k = 0, cnt = 0;
+    for (; k < K; ++k) {
+      cnt = counts[k];
+      const int nb = (cnt + PB - 1) / PB;
+      if (blk < nb) break;
+      blk -= nb;
+    }
+    b.k = k < K ? k : -1;
+    b.cnt = cnt;
+    if (b.k >= 0) {
+      const int2 *rk = rules + (int64_t)k * stride;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int p = blk * PB + 16 * g + li;
+        const int2 pr = rk[min(p, cnt - 1)];
+        const unsigned ro = (unsigned)(in_col ? pr.y : pr.x) * row_bytes + (unsigned)(lq * 16);
+        const int orw = in_col ? pr.x : pr.y;
+        if (g == 0) { b.live0 = p < cnt; b.roff0 = ro; b.orow0 = orw; }
+        else { b.live1 = p < cnt; b.roff1 = ro; b.orow1 = orw; }
+      }
+    }
+  };
+  floatx4 acc[NG][COS];
+  floatx4 rA[NG][NS16], wA[COS][NS16], rB[NG][NS16], wB[COS][NS16];
+  auto load = [&](const Blk &b, int c, floatx4 (&r)[NG][NS16], floatx4 (&w)[COS][NS16]) __attribute__((always_inline)) {
+    const int blk0 = (b.k * (Ci / 16) + c * (CK / 16)) * (Co / 16) + b.co0 / 16;
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp)
+#pragma unroll
+      for (int q = 0; q < COS; ++q)
+        w[q][sp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+            wp_rsrc, (unsigned)lane * 16u, (blk0 + sp * (Co / 16) + q) * 1024, 0));
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int sp = 0; sp < NS16; ++sp)
+        r[g][sp] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+            in_rsrc, (g == 0 ? b.roff0 : b.roff1) + (unsigned)(sp * 64), c * (CK * 4), 0));
+  };
+  auto mma = [&](const floatx4 (&r)[NG][NS16], const floatx4 (&w)[COS][NS16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sp = 0; sp < NS16; ++sp)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < COS; ++q)
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q][sp][e], r[g][sp][e], acc[g][q], 0, 0, 0);
+  };
+  const int G = (int)gridDim.x;
+  Blk cur, nxt;
+  int t = (int)blockIdx.x;
+  locate(t, cur);
+  if (cur.k >= 0) load(cur, 0, rA, wA);
+  for (; t < n_items; t += G) {
+    const bool more = t + G < n_items;
+    if (more) locate(t + G, nxt);  // (its index loads travel with this block's loads)
+    else nxt.k = -1;
+    if (cur.k >= 0) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int q = 0; q < COS; ++q) acc[g][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nch; c += 2) {  // Ci % 64 == 0: an even number of 32-plane chunks
+        load(cur, c + 1, rB, wB);
+        mma(rA, wA);
+        if (c + 2 < nch) load(cur, c + 2, rA, wA);
+        else if (nxt.k >= 0) load(nxt, 0, rA, wA);  // the next block's first chunk, while this block's last one multiplies
+        mma(rB, wB);
+      }
+      // D[i = plane][j = pair]: lane (li, lq) holds planes 16 q + 4 lq .. + 3 of pair li
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (g == 0 ? cur.live0 : cur.live1) {
+          const int orw = g == 0 ? cur.orow0 : cur.orow1;
+#pragma unroll
+          for (int q = 0; q < COS; ++q) {
+            floatx4 v = acc[g][q];
+            if (bias) v += *(const floatx4 *)(bias + cur.co0 + 16 * q + 4 * lq);
+            if (residual) v += *(const floatx4 *)(residual + (int64_t)orw * Co + cur.co0 + 16 * q + 4 * lq);
+            *(floatx4 *)(out + (int64_t)orw * ldo + cur.co0 + 16 * q + 4 * lq) = v;
+            acc[g][q] = v;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < COS; ++q) acc[g][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else if (nxt.k >= 0) {
+      load(nxt, 0, rA, wA);  // (cannot happen: blocks past the end of the lists are the LAST ones; kept for the shape of the loop)
+    }
+    // column statistics of the block's 32 output rows (colstats [blocks][2][Co]; a block past the end of the lists: zeros)
+    if (colstats.out != nullptr) {
+      if (cur.k < 0) {
+        colstats.out[((int64_t)cur.pb * 2 + 0) * Co + cur.co0 + lane] = 0.f;
+        colstats.out[((int64_t)cur.pb * 2 + 1) * Co + cur.co0 + lane] = 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < COS; ++q) {
+          floatx4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
+          StatsCols sc;
+          sc.init(colstats, cur.co0 + 16 * q + 4 * lq);
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            if (!sc.bn || (g == 0 ? cur.live0 : cur.live1))
+              sc.add(acc[g][q], colstats.x + (int64_t)(g == 0 ? cur.orow0 : cur.orow1) * Co + cur.co0 + 16 * q + 4 * lq, cs, css);
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              cs[e] += __shfl_xor(cs[e], o);
+              css[e] += __shfl_xor(css[e], o);
+            }
+          if (li == 0) {
+            *(floatx4 *)(colstats.out + ((int64_t)cur.pb * 2 + 0) * Co + cur.co0 + 16 * q + 4 * lq) = cs;
+            *(floatx4 *)(colstats.out + ((int64_t)cur.pb * 2 + 1) * Co + cur.co0 + 16 * q + 4 * lq) = css;
+          }
+        }
+      }
+    }
+    cur = nxt;
+  }
+}
+#endif
+
 // ------------------------------------------------ the stem on the matrix cores ---
 // C_i <= 4 (the 3 -> m stem over 27 offsets): for a granule of 32 output rows the gathered inputs ARE a dense
 // [32 x K C_i] matrix (zero where a neighbour is absent) and the layer is one small GEMM with W as [K C_i x C_o]:
@@ -3295,6 +3455,9 @@ SCN_KNOB g_dw_direct = 0;       // tuning key 12: 1 = k_dw_direct (no LDS stagin
                                 // step is 1.8 ms SLOWER with it (50.3 against 48.4 ms, tools/ab_step.py tune12=0,1): off
 SCN_KNOB g_conv_expand_nb = 1;  // tuning key 14: blocks of 32 pairs per wave of k_conv_expand (1, 2 or 4).  Measured (round 3, 20 launches
                                 // per step): 1.81 / 1.83 / 2.21 ms -- the weight re-reads are not what bounds the kernel
+SCN_KNOB g_conv_expand_persist = 0;  // tuning key 21: 1 = k_conv_expand_p (persistent waves, pipelined across blocks; tuning library only).  Round 4:
+                                     // bit-identical, 0-17 % faster per launch in isolation (tools/ab_expand.py), 0.3 ms SLOWER per train step
+                                     // (46.73 against 46.40 ms, tools/ab_step.py tune21=0,1): off
 SCN_KNOB g_conv_stem_mfma = 1;  // tuning key 15: 0 = the C_i <= 4 stem runs k_conv_generic (scalar FMAs) instead of k_conv_stem (A/B)
 SCN_KNOB g_conv_gtab = 1;       // tuning key 13: 0 = k_conv_tile4 keeps its pass table in LDS (A/B)
 SCN_KNOB g_conv_sk = 1;         // tuning key 16: stream-K for the unsplit k_conv_tile4 launches (0 = one workgroup per tile, the round-3 launch)
@@ -3677,6 +3840,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 17 && value >= 1) { g_conv_sk_min_items = value; return 0; }
   if (key == 18 && value >= 0 && value <= 1000) { g_conv_sk_min_loss = value; return 0; }
   if (key == 19) { g_conv_split_fused = value; return 0; }
+  if (key == 21) { g_conv_expand_persist = value; return 0; }
   if (key == 20) { SCN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_prio_dev), &value, sizeof(int))); return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");
@@ -3811,6 +3975,15 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
 #define SCN_LAUNCH_EXPAND(NB_)                                                                                              \
   k_conv_expand<NB_><<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, \
                                                                stride, in_col, Ci, Co, ncb, in_bytes, wp_bytes)
+#ifdef SCN_TUNING
+      if (g_conv_expand_persist && expand_nb() == 1 && nblk * ncb < ((int64_t)1 << 30)) {
+        // persistent waves (two per SIMD: 237 registers), pipelined across blocks
+        const int64_t items = nblk * ncb;
+        const int64_t slots = (int64_t)device_cus() * 8;
+        k_conv_expand_p<<<(unsigned)(items < slots ? items : slots), 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K,
+                                                                                      stride, in_col, Ci, Co, ncb, in_bytes, wp_bytes, (int)items);
+      } else
+#endif
       switch (expand_nb()) {
         case 4: SCN_LAUNCH_EXPAND(4); break;
         case 2: SCN_LAUNCH_EXPAND(2); break;
