@@ -36,14 +36,13 @@ python3 tools/pmc_summary.py $E/pmc_tile4 k_dw_tile > $E/pmc_dw_tile.txt 2>&1
 python3 tools/mfma_probe.py > $E/mfma_probe.txt 2>&1
 python3 tools/bench_conv.py --levels 0,1 --variants 4 --extra-lds 0,2000,15200 > $E/occupancy_probe.txt 2>&1
 python3 tools/ab_step.py DW_SIDE_STREAM=0,1 > $E/ab_dw_side_stream.txt 2>&1
-python3 tools/ab_step.py BN_BWD_STATS_FROM_CONV=0,1 > $E/ab_bn_bwd_stats_from_conv.txt 2>&1
-python3 tools/ab_step.py containers.GRAD_JOIN=0,1 > $E/ab_grad_join.txt 2>&1
-python3 tools/ab_step.py conv.JOIN_IN_PLACE=0,1 > $E/ab_join_in_place.txt 2>&1
-python3 tools/ab_step.py tune13=0,1 > $E/ab_tile4_global_pass_table.txt 2>&1
 python3 tools/ab_step.py DETERMINISTIC_DW=0,1 > $E/ab_deterministic_dw.txt 2>&1
-python3 tools/ab_step.py tune12=0,1 > $E/ab_dw_direct.txt 2>&1
-python3 tools/ab_stream_k.py > $E/ab_stream_k_layers.txt 2>&1
-python3 tools/cold_cache.py > $E/cold_cache.txt 2>&1
+python3 tools/ab_step.py STREAM_K=0,1 > $E/ab_stream_k_step.txt 2>&1
+python3 tools/ab_step.py SPLIT_FUSED=0,1 > $E/ab_split_fused.txt 2>&1
+python3 tools/ab_step.py tune21=0,1 > $E/ab_expand_persistent_step.txt 2>&1
+python3 tools/ab_stream_k.py --levels 0,1 --sk 0,1,0,1 > $E/ab_stream_k_layers.txt 2>&1
+python3 tools/ab_stream_k.py --levels 0,1 --sk 0,1,0,1 --first-scene 1100 --residual >> $E/ab_stream_k_layers.txt 2>&1
+python3 tools/ab_expand.py > $E/ab_expand_layers.txt 2>&1
 python3 tools/run_configs.py > $E/configs_cfg2_cfg5.json 2> $E/configs.err
 for mode in end start; do
   GUARD_MODE=$mode timeout 600 python3 -X faulthandler tools/guard_run.py 2> $E/guard_$mode.err | grep guard_run > $E/guard_$mode.txt
@@ -51,7 +50,6 @@ done
 GUARD_SYNC=stream timeout 600 python3 -X faulthandler tools/guard_run.py 2> $E/guard_stream.err | grep guard_run > $E/guard_stream.txt
 GUARD_POISON=0xEF timeout 600 python3 -X faulthandler tools/guard_run.py 2> $E/guard_poison.err | grep guard_run > $E/guard_poison.txt
 python3 tools/check_scratch.py > $E/check_scratch.txt 2>&1
-bash tools/scratch_fault_repro.sh 4 > $E/scratch_fault_repro.txt 2>&1
 # the default bench line once more, now that the traffic of THESE kernel sources exists (bench.py refuses a traffic file
 # measured on other sources): this is the line that goes to profiles/rNN_bench.json
 cp $E/traffic.json profiles/r04_traffic.json
