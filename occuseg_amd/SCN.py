@@ -90,12 +90,14 @@ _PLANS = {}
 _PLANS_USED = {}  # spatial size -> the request list of the most recent forward pass that really ran (tools, bench)
 PREBUILD = True
 # stream-K for the big gather-mm launches (k_conv_tile4): every rulebook carries the pass prefix of its 128-row tiles and the
-# slice tables (scn_tile_passes); handed those and a control block, a launch whose tiles would leave a tenth or more of the last
-# round of resident workgroups empty (2.70 rounds, say) runs as persistent workgroups that are dealt whole tiles first and equal
-# slices of the remaining pass sequence at the end -- bit-identical results.  The library decides per launch (the persistent
-# loop runs ~6 % behind hardware re-dispatch: launches of 2.83 or 4.59 rounds keep one workgroup per tile; DESIGN.md section 3.3,
-# profiles/r04_ab_stream_k.txt).  False: never (A/B: tools/ab_step.py STREAM_K=0,1)
-STREAM_K = os.environ.get("SCN_STREAM_K", "1") != "0"
+# slice tables (scn_tile_passes); handed those and a control block, a launch whose tiles would leave 3 % or more of the last
+# round of resident workgroups empty runs as 1,024 persistent workgroups on a static schedule: whole tiles first, then one slice of
+# the remaining pass sequence each, cut to fit -- bit-identical results.  OFF by default: alone such a launch is 1-13 % faster
+# (tools/ab_stream_k.py), but inside the train step the same launches are SLOWER -- persistent workgroups hold every CU's LDS
+# for the whole launch, so the dWeight kernels of the side stream and the next batch's rule build, which plain launches
+# interleave with, delay the workgroups they displace and every slice waits for the slowest (43.5 -> 45.6 ms per step; with
+# drawn items and slices 44.0; DESIGN.md section 3.3e, profiles/r04_ab_stream_k.txt).  SCN_STREAM_K=1 / SCN.STREAM_K = True: on
+STREAM_K = os.environ.get("SCN_STREAM_K", "0") == "1"
 # launches that split their offsets over several workgroups per tile (the coarse levels): the last workgroup of a tile adds the
 # partial tiles itself (scn_conv_forward's sk_state) instead of a second launch, and emits the batch norm's statistics.
 # False: k_split_reduce as in round 3 (A/B: tools/ab_step.py SPLIT_FUSED=0,1)

@@ -32,14 +32,18 @@ inline int fail(int code, const char *fmt, const char *a = "", long b = 0, long 
 constexpr int WAVE = 64;
 
 // stream-K launches of k_conv_tile4 (scn_conv.hip) and the tables scn_tile_passes builds for them (scn_rules.hip): the LAST
-// 1 + fraction rounds of SCN_SK_SLICES (tile, column block) items are cut into SCN_SK_SLICES equal slices of passes, the
-// items in front of them are dealt whole
+// 1 + fraction rounds of SCN_SK_SLICES (tile, column block) items are cut into SCN_SK_SLICES equal slices of passes -- the tile
+// sequence into SCN_SK_SLICES / ncb parts, each walked once per column block --, the items in front of them are dealt whole
 constexpr int SCN_SK_SLICES = 1024;
 constexpr int SCN_SK_MAX_NCB = 6;  // column blocks (C_o / 64) a table exists for
-__host__ __device__ inline int64_t scn_sk_whole_items(int64_t items) {
-  const int64_t rounds = items / SCN_SK_SLICES;
-  return rounds < 2 ? 0 : (rounds - 1) * SCN_SK_SLICES;
+// (tiles whose ncb items are dealt whole: a multiple of 512, so that tiles x ncb items divide into the XCDs' chunks of 64)
+__host__ __device__ inline int64_t scn_sk_whole_tiles(int64_t tiles, int ncb, int static_schedule = 0) {
+  const int64_t rounds = tiles * ncb / SCN_SK_SLICES;
+  if (rounds < 2) return 0;
+  // (static schedule: whole rounds of 1024 items = 1024 / ncb tiles each)
+  return static_schedule ? (rounds - 1) * (SCN_SK_SLICES / ncb) : (rounds - 1) * SCN_SK_SLICES / ncb / 512 * 512;
 }
+constexpr int SCN_SK_CH = 64;  // slices per chunk of one XCD
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -847,10 +847,11 @@ __global__ void __launch_bounds__(256)
 // flight do).  `sk_state` (zero when the launch starts and when it ends): [0..7] whole-item counters, [8] exit ticket,
 // [9] set if a wait for a slab gave up (never, unless the launch is broken), [10] slices drawn so far, [16..23] slice counters, [32 + s] "slab s is
 // published".
-constexpr int SK_CH = 16;          // slices per chunk of one XCD
+constexpr int SK_CH = SCN_SK_CH;    // slices per chunk of one XCD (16: the halo rows of a 14-tile region were fetched by two XCDs)
 constexpr int SK_ITEM_CH = 64;     // whole items per chunk of one XCD (the first rounds)
 constexpr int SK_STATE_WORDS = 32; // counters + ticket in front of the flags
 constexpr bool SK_DRAIN = true;
+constexpr bool SK_PREFETCH_DRAW = false;
 constexpr int SK_SLICES = SCN_SK_SLICES;  // slices of the sliced part of a launch (= the entries of scn_tile_passes' slice tables)
 template <int DBG = 0, int INCOL = -1, int GT = 0, int SK = 0>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (<= 256 registers: hipcc then keeps the accumulators in VGPRs, no v_accvgpr_read)
@@ -861,7 +862,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
                  unsigned in_bytes, unsigned wp_bytes, int ksplit_a,
                  unsigned long long *__restrict__ gtab_a = nullptr, int gstride_a = 0,
                  const int32_t *__restrict__ tile_passes_a = nullptr, unsigned *sk_state_a = nullptr, float *slabs_a = nullptr,
-                 int na_items_a = 0) {
+                 int na_items_a = 0, int sk_static_a = 0) {
   // (mutable copies of everything the set-up and the epilogue of a piece use: a stream-K launch parks them in the lanes of
   //  one VGPR while the pass loop runs, see `park_all` below)
   float *out = out_a;
@@ -927,7 +928,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   // ---- stream-K bookkeeping (scalar; both waves compute the same values)
   int sk_phase = 0, sk_par = 0, sk_steal = 0, sk_steal_a = 0, sk_s = 0, sk_ia = 0, sk_pa = 0, sk_ib = 0, sk_pb = 0, sk_cur = 0, gpar = 0,
-      sk_pf = 0;
+      sk_pf = 0, sk_cb = 0, sk_static = sk_static_a;  // (sk_ia / sk_ib / sk_cur: TILES; sk_cb: the slice's column block)
 #ifdef SCN_TUNING
   if (na_items_a < 0) sk_steal = 8;  // (A/B: whole items only, no sliced part; the item count must be a multiple of SCN_SK_SLICES / 2)
 #endif
@@ -966,7 +967,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     SCN_P64(36, 37, stride); SCN_P64(38, 39, n_out);
     SCN_P32(40, sk_phase); SCN_P32(41, sk_par); SCN_P32(42, sk_steal); SCN_P32(43, sk_s); SCN_P32(44, sk_ia); SCN_P32(45, sk_pa);
     SCN_P32(46, sk_ib); SCN_P32(47, sk_pb); SCN_P32(48, sk_cur); SCN_P32(49, gpar);
-    SCN_P32(50, item); SCN_P32(51, out_slab); SCN_P32(52, tile_parked); SCN_P32(53, sk_steal_a); SCN_P32(54, na_items);
+    SCN_P32(50, item); SCN_P32(51, out_slab); SCN_P32(52, tile_parked); SCN_P32(53, sk_steal_a); SCN_P32(54, na_items); SCN_P32(55, sk_cb); SCN_P32(56, sk_static);
 #undef SCN_P64
 #undef SCN_P32
     if (store) asm volatile("" : "+v"(park));
@@ -978,11 +979,17 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // where slice s begins: entry s of the slice table scn_tile_passes left behind the pass prefix for this column-block count
   // (item, pass inside the item's table in units of nch passes).  One scalar load for both ends of a slice.
   auto sk_bounds = [&](int s_) __attribute__((always_inline)) {
-    const int4 *tab = (const int4 *)(tile_passes + ((ntiles + 2) & ~1) + (size_t)(ncb - 1) * (2 * (SK_SLICES + 1)));
-    const int2 *e = (const int2 *)tab + s_;
+    // slice s_ = (tile slice s_ / ncb, column block s_ % ncb): the sliced part of the TILE sequence is cut into 1024 / ncb equal
+    // parts and each part is walked once per column block, by ncb slices that are drawn one after the other -- so the column
+    // blocks of a tile, which gather the same rows, are in flight on one XCD at the same time (walked one after the other by
+    // one workgroup, the second walk came an item's time later and missed the L2: 2.5 x the fabric reads of the plain launch)
+    // (table slots: ncb - 1 for the drawn schedule, and 2 / 4 / 5 for the static schedule with 1 / 2 / 4 column blocks)
+    const int slot = sk_static ? (ncb == 1 ? 2 : ncb == 2 ? 4 : 5) : ncb - 1;
+    const int2 *e = (const int2 *)(tile_passes + ((ntiles + 2) & ~1)) + (size_t)slot * (SK_SLICES + 1) + s_ / ncb;
     const int2 a = e[0], b = e[1];
     sk_ia = uni(a.x); sk_pa = uni(a.y) * nch;
     sk_ib = uni(b.x); sk_pb = uni(b.y) * nch;
+    sk_cb = s_ % ncb;
   };
   // One draw from this XCD's whole-item counter (which = 1: the first rounds of the launch deal WHOLE items, in the order the
   // one-workgroup-per-tile launch starts them -- chunks of consecutive items per XCD: no slab, no table) or from its slice
@@ -1024,6 +1031,65 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       return true;
     }
 #endif
+    if (sk_static) {
+      // STATIC schedule: workgroup (XCD x = b % 8, j = b / 8) walks item (r * 8 + x) * 128 + j in round r of the whole items, then
+      // slice (c * 8 + x) * SK_CH + i with j = c * SK_CH + i -- nothing is drawn, no counter, no barrier for it.  Workgroups j
+      // and j + 1 of an XCD walk the column blocks of the SAME tiles for the whole launch: identical work, so they stay in
+      // step and one fetch of a gathered row from the fabric serves both (with draws, whoever finished next took the next
+      // item: the pairs drifted apart and the launch read 1.7-2.5 x the plain launch's bytes through the fabric).  The slice
+      // table is built for this schedule: a slice is as much shorter as its owner's whole items are heavier than average
+      // (scn_tile_passes), which is all the balancing a dynamic draw did on an undisturbed chip.
+      for (;;) {
+        if (sk_phase == 0) {
+          if (sk_cur < (na_items >> 10)) {  // rounds of whole items
+            item = ((sk_cur++ * 8) + ((int)blockIdx.x & 7)) * 128 + ((int)blockIdx.x >> 3);
+            p_lo = 0; p_hi = 0x7fffffff; seed_slab = -1; out_slab = -1;
+            return true;
+          }
+          if (sk_steal) return false;  // (the slice is done)
+          sk_steal = 1;
+          {
+            const int j = (int)blockIdx.x >> 3;
+            sk_s = ((j / SK_CH) * 8 + ((int)blockIdx.x & 7)) * SK_CH + j % SK_CH;
+          }
+          sk_bounds(sk_s);
+          if (sk_ia == sk_ib) {
+            // (an EMPTY slice -- both ends at one point -- inside a tile still hands the tile on: a piece of no passes that
+            //  starts from the previous slab and publishes its own; at a tile's first pass there is nothing to hand on)
+            if (sk_pa == sk_pb && sk_pa == 0) return false;
+            item = sk_ia * ncb + sk_cb; p_lo = sk_pa; p_hi = sk_pb;
+            seed_slab = sk_pa > 0 ? sk_s - ncb : -1;
+            out_slab = sk_s;
+            sk_phase = 4;
+            return true;
+          }
+          sk_phase = 1;
+        }
+        if (sk_phase == 1) {
+          sk_phase = 2;
+          sk_cur = sk_pa > 0 ? sk_ia + 1 : sk_ia;
+          if (sk_pb > 0) {
+            item = sk_ib * ncb + sk_cb; p_lo = 0; p_hi = sk_pb; seed_slab = -1; out_slab = sk_s;
+            return true;
+          }
+        }
+        if (sk_phase == 2) {
+          if (sk_cur < sk_ib) {
+            item = sk_cur++ * ncb + sk_cb; p_lo = 0; p_hi = 0x7fffffff; seed_slab = -1; out_slab = -1;
+            return true;
+          }
+          sk_phase = 3;
+        }
+        if (sk_phase == 3) {
+          sk_phase = 4;
+          if (sk_pa > 0) {
+            item = sk_ia * ncb + sk_cb; p_lo = sk_pa; p_hi = 0x7fffffff; seed_slab = sk_s - ncb; out_slab = -1;
+            return true;
+          }
+        }
+        return false;
+      }
+    }
     for (;;) {
       if (sk_phase == 0) {
         if (!sk_steal_a) {
@@ -1062,9 +1128,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         sk_bounds(sk_s);
         if (sk_ia == sk_ib) {  // inside one item (a slice shorter than the item)
-          if (sk_pa == sk_pb) continue;
-          item = sk_ia; p_lo = sk_pa; p_hi = sk_pb;
-          seed_slab = sk_pa > 0 ? sk_s - 1 : -1;
+          if (sk_pa == sk_pb && sk_pa == 0) continue;  // (empty, at a tile's first pass: nothing to hand on; see the static branch)
+          item = sk_ia * ncb + sk_cb; p_lo = sk_pa; p_hi = sk_pb;
+          seed_slab = sk_pa > 0 ? sk_s - ncb : -1;
           out_slab = sk_s;
           return true;
         }
@@ -1074,20 +1140,20 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         sk_phase = 2;
         sk_cur = sk_pa > 0 ? sk_ia + 1 : sk_ia;
         if (sk_pb > 0) {
-          item = sk_ib; p_lo = 0; p_hi = sk_pb; seed_slab = -1; out_slab = sk_s;
+          item = sk_ib * ncb + sk_cb; p_lo = 0; p_hi = sk_pb; seed_slab = -1; out_slab = sk_s;
           return true;
         }
       }
       if (sk_phase == 2) {
         if (sk_cur < sk_ib) {
-          item = sk_cur++; p_lo = 0; p_hi = 0x7fffffff; seed_slab = -1; out_slab = -1;
+          item = sk_cur++ * ncb + sk_cb; p_lo = 0; p_hi = 0x7fffffff; seed_slab = -1; out_slab = -1;
           return true;
         }
         sk_phase = 3;
       }
       sk_phase = 0;
       if (sk_pa > 0) {
-        item = sk_ia; p_lo = sk_pa; p_hi = 0x7fffffff; seed_slab = sk_s - 1; out_slab = -1;
+        item = sk_ia * ncb + sk_cb; p_lo = sk_pa; p_hi = 0x7fffffff; seed_slab = sk_s - ncb; out_slab = -1;
         return true;
       }
     }
@@ -1148,6 +1214,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         while (__hip_atomic_load(sk_flags + seed_slab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 23))
           __builtin_amdgcn_s_sleep(4);
         if (spins >= (1u << 23)) __hip_atomic_store(sk_state + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SCN_TUNING
+        atomicAdd(&g_stamps[6], (unsigned long long)spins);  // (tools/ab_stream_k.py --spins: how long seeded pieces wait)
+        atomicAdd(&g_stamps[7], 1ull);
+#endif
         __hip_atomic_store(sk_flags + seed_slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (one reader per flag)
       }
       __syncthreads();
@@ -1349,7 +1419,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // (sk_phase == 0: the next call of sk_next begins with a draw.  Only draws of WHOLE items are made ahead: a slice drawn while
   //  its workgroup still has a piece to finish sits undone, and the slice behind it waits for its first piece -- measured:
   //  launches 7-12 % slower)
-  const bool pf_now = SK && sk_phase == 0 && !sk_steal_a && na_items > 0 && na_items_a != (int)0x80000000;
+  const bool pf_now = SK && SK_PREFETCH_DRAW && !sk_static && sk_phase == 0 && !sk_steal_a && na_items > 0 && na_items_a != (int)0x80000000;
   const int pf_slot = sk_par, pf_which = 1;
   unsigned pf_val = 0;
   if (pf_now && tid == 0)
@@ -1615,7 +1685,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   }  // pieces
   if ((DBG & 256) && lane == 0)
     for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
-  if (SK && tid == 0 && na_items_a != (int)0x80000000) {  // the last workgroup out leaves the counters as it found them (every flag was reset by its reader)
+  if (SK && tid == 0 && na_items_a != (int)0x80000000 && !sk_static_a) {  // the last workgroup out leaves the counters as it found them (every flag was reset by its reader)
     if (__hip_atomic_fetch_add(sk_state + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
 #pragma unroll
       for (int i = 0; i < 11; ++i)
@@ -3461,10 +3531,11 @@ SCN_KNOB g_conv_expand_persist = 0;  // tuning key 21: 1 = k_conv_expand_p (pers
 SCN_KNOB g_conv_stem_mfma = 1;  // tuning key 15: 0 = the C_i <= 4 stem runs k_conv_generic (scalar FMAs) instead of k_conv_stem (A/B)
 SCN_KNOB g_conv_gtab = 1;       // tuning key 13: 0 = k_conv_tile4 keeps its pass table in LDS (A/B)
 SCN_KNOB g_conv_sk = 1;         // tuning key 16: stream-K for the unsplit k_conv_tile4 launches (0 = one workgroup per tile, the round-3 launch)
-SCN_KNOB g_conv_sk_min_loss = 90;   // tuning key 18: ... and only where one workgroup per tile would leave at least this many permille of the last
-                                    // round of resident workgroups empty (2.70 rounds: 100; 2.83: 57; 4.59: 82).  Measured (tools/ab_stream_k.py,
-                                    // profiles/r04_ab_stream_k.txt): the persistent loop runs ~6 % behind hardware re-dispatch, so stream-K gains
-                                    // 6 % at 2.70 rounds, breaks even at 2.83 and loses 8 % at 4.59.  0: every eligible launch (A/B)
+SCN_KNOB g_conv_sk_static = 1;      // tuning key 22: 0 = stream-K launches draw their items and slices from counters (A/B)
+SCN_KNOB g_conv_sk_min_loss = 30;   // tuning key 18: ... and only where one workgroup per tile would leave at least this many permille of the last
+                                    // round of resident workgroups empty (2.70 rounds: 100; 2.83: 57; 4.59: 82).  Measured with the static
+                                    // schedule (tools/ab_stream_k.py, profiles/r04_ab_stream_k.txt): +12 % at 2.70 rounds, +4-6 % at 2.83,
+                                    // +1-3 % at 4.59; a launch of whole rounds would pay ~1-2 % for nothing.  0: every eligible launch (A/B)
 SCN_KNOB g_conv_sk_min_items = 1024;  // tuning key 17: ... for launches with at least this many (tile, column block) items
 SCN_KNOB g_conv_split_fused = 1;  // tuning key 19: 0 = the partial tiles of a split launch are added by a second launch (k_split_reduce) even
                                   // when the caller hands in a control block (A/B)
@@ -3625,20 +3696,33 @@ static int device_cus() {
   }
   return cus;
 }
+// the static stream-K schedule has every workgroup wait for a slab that another one publishes: all SCN_SK_SLICES workgroups must
+// be resident at once (four per CU on 256 CUs).  Checked once against the runtime's own occupancy answer; otherwise: no stream-K
+static bool sk_all_resident() {
+  static int ok = -1;
+  if (ok < 0) {
+    int per_cu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;  // (no GPU in this process: size queries answer for an MI355X; not cached)
+    const bool q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv_tile4<0, 0, 1, 1>, 128, 0) == hipSuccess;
+    ok = (q && (int64_t)per_cu * device_cus() >= SCN_SK_SLICES && 4 * device_cus() == SCN_SK_SLICES) ? 1 : 0;
+  }
+  return ok == 1;
+}
 static bool tile4_sk_plan(int K, int64_t n_out, int Ci, int Co, SkPlan &sp) {
   if (g_conv_sk <= 0) return false;
   const int64_t items = ((n_out + 127) / 128) * (Co / 64);
   if (items < g_conv_sk_min_items) return false;
-  if (Co / 64 > SCN_SK_MAX_NCB) return false;
+  if (Co / 64 > SCN_SK_MAX_NCB || SCN_SK_SLICES % (Co / 64) != 0) return false;  // (1, 2 or 4 column blocks)
   sp.groups = 4 * device_cus();
+  if (!sk_all_resident()) return false;
   {
     const int64_t rounds_up = (items + sp.groups - 1) / sp.groups;
     if ((rounds_up * sp.groups - items) * 1000 < (int64_t)g_conv_sk_min_loss * rounds_up * sp.groups) return false;
   }
   sp.slices = SK_SLICES;
   sp.shift = 0;
-  // whole items first: all but the last 1 + fraction rounds of SK_SLICES items (the rule k_sk_slices built the table for)
-  sp.na_items = (int)scn_sk_whole_items(items);
+  // whole items first: all but the last 1 + fraction rounds of SK_SLICES items, in whole tiles (the rule k_sk_slices built the table for)
+  sp.na_items = (int)(scn_sk_whole_tiles((n_out + 127) / 128, Co / 64, g_conv_sk_static) * (Co / 64));
 #ifdef SCN_TUNING
   if (g_conv_sk == 2) sp.na_items = -(int)(items / 512 * 512);
   if (g_conv_sk == 3) { sp.na_items = (int)0x80000000; sp.groups = (int)items; }
@@ -3739,10 +3823,10 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
         float *slabs = (float *)((char *)part + sp.gtab_bytes);
         if (in_col)
           k_conv_tile4<0, 1, 1, 1><<<sp.groups, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
-                                                                  ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items);
+                                                                  ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items, g_conv_sk_static);
         else
           k_conv_tile4<0, 0, 1, 1><<<sp.groups, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
-                                                                  ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items);
+                                                                  ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items, g_conv_sk_static);
       } else
       if (gtab != nullptr && in_col)
         k_conv_tile4<0, 1, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
@@ -3764,10 +3848,10 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     float *slabs = (float *)((char *)part + sp.gtab_bytes);
     if (in_col)
       k_conv_tile4<0, 1, 1, 1><<<sp.groups, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
-                                                              ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items);
+                                                              ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items, g_conv_sk_static);
     else
       k_conv_tile4<0, 0, 1, 1><<<sp.groups, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
-                                                              ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items);
+                                                              ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items, g_conv_sk_static);
   } else if (gtab != nullptr) {  // pass table in global memory, read with scalar loads (see k_conv_tile4's GT)
     if (in_col)
       k_conv_tile4<0, 1, 1><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
@@ -3841,6 +3925,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 18 && value >= 0 && value <= 1000) { g_conv_sk_min_loss = value; return 0; }
   if (key == 19) { g_conv_split_fused = value; return 0; }
   if (key == 21) { g_conv_expand_persist = value; return 0; }
+  if (key == 22) { g_conv_sk_static = value; return 0; }
   if (key == 20) { SCN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_prio_dev), &value, sizeof(int))); return 0; }
   if (key == 10 && value >= 0 && value <= 28000) { g_conv_extra_lds = value; return 0; }
   return fail(2, "scn_set_tuning: unknown key/value%s", "");

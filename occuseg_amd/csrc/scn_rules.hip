@@ -351,37 +351,110 @@ __global__ void __launch_bounds__(1024)
   if (tid == 0) passes[n_tiles] = carry;
 }
 
-// Slice tables behind the prefix (one per column-block count ncb = 1 .. SCN_SK_MAX_NCB): entry s = where slice s of the sliced
-// part of a launch begins, as (item = tile * ncb + column block, pass inside the item in units of one pass per input chunk).
-// The sequence: items in order, item (tile, cb) holding L(tile) = passes[tile + 1] - passes[tile] units; the whole items
-// [0, scn_sk_whole_items) are left out.  Boundaries within 4 units of an item's ends move there (a piece of a few passes costs a
-// tile set-up and a slab round trip).
+// Slice tables behind the prefix (one per column-block count ncb that divides SCN_SK_SLICES: 1, 2, 4): entry s = where part s
+// of the sliced TILE sequence begins, as (tile, pass inside the tile in units of one pass per input chunk); SCN_SK_SLICES / ncb
+// parts (each is walked once per column block, by ncb slices).  The sequence: tiles in order, tile t holding
+// L(t) = passes[t + 1] - passes[t] units; the tiles [0, scn_sk_whole_tiles) are left out (their items are dealt whole).
+// Boundaries within 4 units of a tile's ends move there (a piece of a few passes costs a tile set-up and a slab round trip).
 __global__ void __launch_bounds__(256)
     k_sk_slices(const int32_t *__restrict__ passes, int n_tiles, int2 *__restrict__ tab) {
   const int ncb = blockIdx.y + 1;
   const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s > SCN_SK_SLICES) return;
+  if (ncb != 1 && ncb != 2 && ncb != 4) return;  // (slots 2, 4, 5 hold the static schedule's tables)
+  const int parts = SCN_SK_SLICES / ncb;
+  if (s > parts) return;
   int2 *out = tab + (size_t)(ncb - 1) * (SCN_SK_SLICES + 1);
-  const int64_t items = (int64_t)n_tiles * ncb, na = scn_sk_whole_items(items);
-  if (s == SCN_SK_SLICES) { out[s] = make_int2((int)items, 0); return; }
+  const int64_t na = scn_sk_whole_tiles(n_tiles, ncb);
+  if (s == parts) { out[s] = make_int2(n_tiles, 0); return; }
   if (s == 0) { out[s] = make_int2((int)na, 0); return; }
-  const int t_a = (int)(na / ncb), cb_a = (int)(na % ncb);
-  const int64_t X0 = (int64_t)passes[t_a] * ncb + (int64_t)cb_a * (passes[t_a + 1] - passes[t_a]);
-  const int64_t T = (int64_t)passes[n_tiles] * ncb;
-  const int64_t x = X0 + (T - X0) * s / SCN_SK_SLICES;
-  const int64_t y = x / ncb;
-  int lo = 0, hi = n_tiles;  // largest t in [0, n_tiles) with passes[t] <= y
+  const int64_t X0 = passes[na], T = passes[n_tiles];
+  const int64_t x = X0 + (T - X0) * s / parts;
+  int lo = 0, hi = n_tiles;  // largest t in [0, n_tiles) with passes[t] <= x
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (passes[mid] <= y) lo = mid; else hi = mid;
+    if (passes[mid] <= x) lo = mid; else hi = mid;
   }
   const int64_t l0 = passes[lo], L = passes[lo + 1] - l0;
-  const int64_t r = x - l0 * ncb;
-  int64_t cb = r / L, ps = r - cb * L;
+  int64_t ps = x - l0;
   const int64_t d = L / 2 < 4 ? L / 2 : 4;
   if (ps < d) ps = 0;
-  else if (L - ps <= d) { ps = 0; ++cb; }
-  out[s] = make_int2((int)(lo * (int64_t)ncb + cb), (int)ps);
+  else if (L - ps <= d) { ps = 0; ++lo; }
+  out[s] = make_int2(lo, (int)ps);
+}
+
+// The same tables for the STATIC schedule of a stream-K launch (table slots 2 / 4 / 5 for 1 / 2 / 4 column blocks): nothing is
+// drawn, workgroup (XCD x, j) walks item (r * 8 + x) * 128 + j in round r of the whole items and then ONE slice, so a slice can be
+// cut to fit its owner: part ts of the sliced tile sequence holds W - D(ts) units, D(ts) = what the owner's whole items hold and
+// W = the mean of D + part over all owners.  (The owners of the ncb slices of one part walk the column blocks of the same tiles
+// in every round: same D.)  One workgroup of 1024 threads per column-block count.
+__global__ void __launch_bounds__(1024)
+    k_sk_slices_static(const int32_t *__restrict__ passes, int n_tiles, int2 *__restrict__ tab) {
+  const int ncb = blockIdx.y == 0 ? 1 : blockIdx.y == 1 ? 2 : 4, slot = blockIdx.y == 0 ? 2 : blockIdx.y == 1 ? 4 : 5;
+  const int parts = SCN_SK_SLICES / ncb, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int2 *out = tab + (size_t)slot * (SCN_SK_SLICES + 1);
+  __shared__ long long wsum[16];
+  __shared__ long long tot_s;
+  const int64_t na = scn_sk_whole_tiles(n_tiles, ncb, 1);
+  const int rounds = (int)(na * ncb / SCN_SK_SLICES);
+  const int64_t X0 = passes[na], R = passes[n_tiles] - X0;
+  // D of the owner of part tid (slice s = tid * ncb)
+  long long D = 0;
+  if (tid < parts) {
+    const int s = tid * ncb, q = s / SCN_SK_CH, i = s % SCN_SK_CH, x = q % 8, j = (q / 8) * SCN_SK_CH + i;
+    for (int r = 0; r < rounds; ++r) {
+      const int tile = ((r * 8 + x) * 128 + j) / ncb;
+      D += passes[tile + 1] - passes[tile];
+    }
+  }
+  auto block_sum_scan = [&](long long v, long long &excl) {  // exclusive scan over the 1024 threads; returns the total
+    long long incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    long long before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      const long long t = wsum[w];
+      before += w < wv ? t : 0;
+      total += t;
+    }
+    excl = before + incl - v;
+    return total;
+  };
+  long long dummy;
+  const long long Dtot = block_sum_scan(D, dummy);
+  // W = (sum D + R) / parts; share of part tid = W - D, at least one unit's worth so that boundaries stay ordered
+  const long long Wn = Dtot + R;  // (numerator; shares are kept times `parts` to stay in integers)
+  long long share = tid < parts ? Wn - D * parts : 0;
+  if (tid < parts && share < 1) share = 1;
+  long long excl;
+  const long long stot = block_sum_scan(share, excl);
+  if (tid == 0) tot_s = stot;
+  __syncthreads();
+  if (tid >= parts) return;
+  if (tid == 0) {  // the two ends (parts may be 1024 = the block size: no thread of its own for the last entry)
+    out[0] = make_int2((int)na, 0);
+    out[parts] = make_int2(n_tiles, 0);
+    return;
+  }
+  // (128-bit products avoided: excl <= stot ~ parts * (sum D + R) < 2^40, R < 2^31)
+  const int64_t x = X0 + (int64_t)((double)excl / (double)tot_s * (double)R + 0.5);
+  int lo = 0, hi = n_tiles;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (passes[mid] <= x) lo = mid; else hi = mid;
+  }
+  if (lo < (int)na) lo = (int)na;
+  const int64_t l0 = passes[lo], L = passes[lo + 1] - l0;
+  int64_t ps = x - l0;
+  if (ps < 0) ps = 0;
+  const int64_t d = L / 2 < 4 ? L / 2 : 4;
+  if (ps < d) ps = 0;
+  else if (L - ps <= d) { ps = 0; ++lo; }
+  out[tid] = make_int2(lo, (int)ps);
 }
 
 // ------------------------------------------------------------ tile bases ---
@@ -664,6 +737,8 @@ int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes,
   SCN_CHECK_LAUNCH();
   // (8-byte aligned behind the n_tiles + 1 prefix entries)
   k_sk_slices<<<dim3((SCN_SK_SLICES + 256) / 256, SCN_SK_MAX_NCB), 256, 0, stream>>>(passes, (int)n_tiles, (int2 *)(passes + ((n_tiles + 2) & ~(int64_t)1)));
+  SCN_CHECK_LAUNCH();
+  k_sk_slices_static<<<dim3(1, 3), 1024, 0, stream>>>(passes, (int)n_tiles, (int2 *)(passes + ((n_tiles + 2) & ~(int64_t)1)));
   SCN_CHECK_LAUNCH();
   return 0;
 }

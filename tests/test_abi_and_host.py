@@ -27,12 +27,13 @@ def test_library_exports_every_declared_symbol():
     # tuning / ablation entry points are not part of the product library (only of libscn_hip_tuning.so)
     assert not hasattr(lib, "scn_set_tuning") and not hasattr(lib, "scn_debug_stamps")
     assert os.path.exists(_lib.TUNING_LIB_PATH)
-    # big launches (k_conv_tile4) keep one pass table per workgroup in the workspace: 4688 tiles x 116 entries -> 120 entries
-    # (whole 64-byte lines) x 8 bytes (4.58 rounds of 1024 resident workgroups: one workgroup per tile); 1383 tiles x 2 column
-    # blocks = 2.70 rounds run stream-K: two pass tables per persistent workgroup + one 128 x 64 fp32 slab per slice; a coarse
-    # level (few tiles) splits its offsets 9- or 27-fold
-    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64, 0) == 4688 * 120 * 8
+    # big launches (k_conv_tile4) keep one pass table per workgroup in the workspace (116 entries -> 120: whole 64-byte lines,
+    # x 8 bytes); as stream-K launches -- 4688 tiles are 4.58 rounds of 1024 resident workgroups, 1383 tiles x 2 column blocks 2.70:
+    # both would leave more than 3 % of the last round empty -- two pass tables per persistent workgroup + one 128 x 64 fp32 slab
+    # per slice; 4096 tiles are whole rounds: one workgroup per tile.  A coarse level (few tiles) splits its offsets 9- or 27-fold
+    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64, 0) == 1024 * 2 * 120 * 8 + 1024 * 128 * 64 * 4
     assert lib.scn_conv_workspace_bytes(27, 177001, 177001, 177001, 128, 128, 0) == 1024 * 2 * 224 * 8 + 1024 * 128 * 64 * 4
+    assert lib.scn_conv_workspace_bytes(27, 524288, 524288, 524288, 64, 64, 0) == 4096 * 120 * 8
     assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 20, 12, 0) == 0  # generic kernel: none
     ws = lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384, 0)
     assert ws % (2000 * 384 * 4) == 0 and ws // (2000 * 384 * 4) in (3, 9, 27)

@@ -359,19 +359,24 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
         assert part is not None and int(SCN._sk_state(gpu).view(torch.int32).abs().sum().item()) == 0
         return out, sink[0], d_in, part
 
-    got = {"product": run()}
     before = SCN.STREAM_K
+    SCN.STREAM_K = True  # (hand tile_passes and the control block to every launch: off by default)
+    got = {}
     try:
+        got["product"] = run()
         lib = _lib.use_tuning_build()
         lib.scn_set_tuning(18, 0)
         got["stream-K, every launch"] = run()
+        lib.scn_set_tuning(22, 0)
+        got["stream-K, items and slices drawn from counters"] = run()
+        lib.scn_set_tuning(22, 1)
         lib.scn_set_tuning(16, 0)
         got["one workgroup per tile"] = run()
         lib.scn_set_tuning(0, 2)
         got["k_conv_tile2"] = run()
         lib.scn_set_tuning(0, 4)
         lib.scn_set_tuning(16, 1)
-        lib.scn_set_tuning(18, 90)
+        lib.scn_set_tuning(18, 30)
     finally:
         _lib.use_product_build()
         SCN.STREAM_K = before

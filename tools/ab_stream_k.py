@@ -79,6 +79,14 @@ def main():
                         ref = (out.clone(), stats[-1].clone())
                     else:
                         same = " bitwise=%s/%s" % (torch.equal(out, ref[0]), torch.equal(stats[-1], ref[1]))
+                    if sk:
+                        import ctypes
+                        buf = (ctypes.c_ulonglong * 8)()
+                        lib.scn_debug_stamps(buf)
+                        fn()
+                        torch.cuda.synchronize()
+                        lib.scn_debug_stamps(buf)
+                        same += " [seeded pieces %d, polls %d]" % (buf[7], buf[6])
                     st = SCN._sk_state(dev)
                     zero = int(st.view(torch.int32).abs().sum().item()) == 0
                     line += "  sk%d %.3f ms %.1f TF%s%s" % (sk, ms, flops / ms / 1e9, same, "" if zero else " STATE-NOT-ZERO")
