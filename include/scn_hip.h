@@ -121,11 +121,11 @@ int scn_strided_rules(const int32_t *fine_coords, int64_t N, const int32_t *coar
 int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
                    int out_col, int64_t n_out, int32_t *bases, void *stream);
 
-/* passes (scn_tile_passes_bytes(n_out) bytes) = int32 [ceil(n_out / 128) + 1]: prefix sums over the 128-row output tiles of max(1, sum_k ceil(pairs_k(tile) / 32)) -- the
- * number of 32-pair passes the big gather-mm launches (k_conv_tile4) make over a tile per 64-plane input chunk -- from the
- * tile-base table of the output column.  scn_conv_forward's `tile_passes`: with it those launches cut their whole pass
- * sequence into equal slices for persistent workgroups (stream-K) instead of dealing whole tiles, which the reference's
- * chunk kernels (sparseconvnet/SCN/CUDA/Convolution.cu:1059-1152) and round 3's launch both do. */
+/* passes (scn_tile_passes_bytes(n_out) bytes) = int32 [ceil(n_out / 128) + 1]: prefix sums over the 128-row output tiles of
+ * max(1, sum_k ceil(pairs_k(tile) / 32)) -- the number of 32-pair passes the big gather-mm launches (k_conv_tile4) make over a
+ * tile per 64-plane input chunk -- from the tile-base table of the output column; behind it the slice tables of a stream-K
+ * launch (scn_conv_forward's `tile_passes`): where each of its 1024 slices begins, for 1 / 2 / 4 column blocks.  The reference's
+ * chunk kernels (sparseconvnet/SCN/CUDA/Convolution.cu:1059-1152) deal whole chunks in launch order. */
 size_t scn_tile_passes_bytes(int64_t n_out); /* bytes of `passes`: the prefix, then one slice table per column-block count */
 int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes, void *stream);
 
@@ -162,11 +162,14 @@ int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes,
  *   writes its result straight into the right half of the joined tensor and its backward pass reads the right half of the
  *   joined gradient in place.  ld_in: planes that are multiples of 16 (the pipelined kernels); ld_out: out_unique launches with
  *   planes % 64 == 0 only (scn_conv_plan = 5xx).  residual / colstats / bn_bwd->x stay contiguous [n_out, Co].
- *   tile_passes (may be NULL): scn_tile_passes(bases, K, n_out, ..).  With it -- and with sk_state -- the big launches
- *   (k_conv_tile4) run as 4 persistent workgroups per CU that draw equal SLICES of the launch's pass sequence; a tile cut by a
- *   slice boundary is continued, not summed: the workgroup that holds its first passes hands the 128 x 64 partial tile on
- *   through the workspace and the next one goes on from it, so every output element is still accumulated in (offset, chunk,
- *   pair) order: results are bit-identical with and without it.
+ *   tile_passes (may be NULL): scn_tile_passes(bases, K, n_out, ..).  With it -- and with sk_state -- a big launch
+ *   (k_conv_tile4) whose tiles would leave 3 % or more of the last round of resident workgroups empty runs as 1024 persistent
+ *   workgroups on a static schedule (stream-K): whole tiles first, then ONE slice each of the remaining pass sequence, cut so
+ *   that every workgroup ends with the same amount of work.  A tile cut by a slice boundary is continued, not summed: the
+ *   workgroup that holds its first passes hands the 128 x 64 partial tile on through the workspace and the next one goes on from
+ *   it, so every output element is still accumulated in (offset, chunk, pair) order: results are bit-identical with and
+ *   without it.  Needs 4 x 256 workgroups resident at once (checked; otherwise the plain launch).  Faster alone, slower next to
+ *   other kernels on the chip: occuseg_amd/SCN.py passes NULL unless SCN.STREAM_K is set.
  *   sk_state (may be NULL): SCN_SK_STATE_BYTES bytes of device memory that hold ZERO when the launch starts; the launch leaves
  *   them zero.  One such block per stream (launches that may overlap need different blocks).  Launches that split their offsets
  *   (the coarse levels) use it too: the last of a tile's workgroups to finish adds the partial tiles itself, in the same fixed

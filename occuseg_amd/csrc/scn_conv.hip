@@ -826,27 +826,22 @@ __global__ void __launch_bounds__(256)
 // GT = 1: the pass table lives in GLOBAL memory (a 64-byte aligned region per workgroup of the launcher's workspace) and is
 // read with scalar loads: an entry in LDS costs a v_mov (address) + ds_read + two v_readfirstlane per pass -- three
 // vector-ALU instructions at 8-12 matrix-pipe cycles each -- a scalar load none.
-// SK = 1 (needs GT = 1): STREAM-K.  The launch is gridDim.x persistent workgroups (four per CU) and the unit that is dealt
-// out is not a tile but a SLICE: the passes of all (tile, column block) items, in item order, form one sequence of
-// T = nch * ncb * sum_tiles L(tile) passes (`tile_passes`: the prefix of L over the tiles, scn_tile_passes) that is cut into
-// n_slices equal parts.  Whole tiles dealt over 1,024 resident workgroups run ceil(n / 1024) rounds (2,766 tiles: three
-// rounds for 2.70 rounds of work; 4,688: five for 4.58): the last round is 8-10 % of every launch.  A slice begins and ends
-// anywhere inside a tile's pass table, so an item cut by a slice boundary is computed in two PIECES that are chained, not
-// summed: the piece that holds the item's first passes stores its 128 x 64 output tile to a slab (write-through, sc1),
-// the piece that holds the rest starts its LDS tile from that slab and goes on -- every output element still sees
-// its contributions in (offset, chunk, pair) order, so the result is bit-identical to the one-workgroup-per-tile launch
-// and to k_conv_tile2.  Within a slice the piece that FEEDS the next slice runs first and the piece that WAITS for the
-// previous slice last (a slice is >= 1 tile of work: the slab it waits for was published a tile ago).  Slices are drawn
-// from per-XCD counters (a counter hands out chunks of SK_CH consecutive slices, the chunks dealt round robin over the
-// XCDs: neighbouring tiles gather overlapping rows -> shared L2), a slice waits only for a lower one that was drawn
-// earlier or belongs to another XCD's sequence and the lowest unfinished slice never waits: no deadlock, whatever the
-// residency.  Only the END of the launch is cut that way: the first rounds deal whole items to the same persistent workgroups, in
-// the order the one-workgroup-per-tile launch starts them, and the last 1 + fraction rounds are the sliced sequence (slicing
-// everything measured 4-9 % SLOWER than one workgroup per tile: every slice costs a search, a tile set-up and a slab round trip, and
-// workgroups that walk 4.6 consecutive tiles each no longer share gathered rows in the XCD's L2 the way 64 neighbouring tiles in
-// flight do).  `sk_state` (zero when the launch starts and when it ends): [0..7] whole-item counters, [8] exit ticket,
-// [9] set if a wait for a slab gave up (never, unless the launch is broken), [10] slices drawn so far, [16..23] slice counters, [32 + s] "slab s is
-// published".
+// SK = 1 (needs GT = 1): STREAM-K (DESIGN.md section 3.3e has the whole story and every measurement).  The launch is 1024
+// persistent workgroups (four per CU) and what a workgroup is given is not just tiles: the passes of all (tile, column block) items
+// form one sequence (`tile_passes`: the prefix of L = passes per tile and input chunk over the tiles, scn_tile_passes); all but the
+// last 1 + fraction rounds of 1024 items are walked WHOLE, the rest of the sequence is cut into 1024 slices.  Whole tiles dealt
+// over 1,024 resident workgroups run ceil(n / 1024) rounds (2,766 tiles: three rounds for 2.70 rounds of work; 4,688: five for
+// 4.58).  A slice begins and ends anywhere inside a tile's pass table, so an item cut by a slice boundary is computed in two PIECES
+// that are chained, not summed: the piece that holds the item's first passes stores its 128 x 64 output tile to a slab
+// (write-through, sc1), the piece that holds the rest starts its LDS tile from that slab and goes on -- every output element
+// still sees its contributions in (offset, chunk, pair) order, so the result is bit-identical to the one-workgroup-per-tile
+// launch and to k_conv_tile2.  Within a slice the piece that FEEDS the next slice runs first and the piece that WAITS for the
+// previous slice last (a slice is >= 1 tile of work: the slab it waits for was published a tile ago).  Two schedules: STATIC
+// (sk_static, the default: nothing is drawn, see sk_next) and DRAWN (items and slices from per-XCD counters, chunks of SK_CH
+// consecutive slices dealt round robin over the XCDs; a slice waits only for a lower one that was drawn earlier or belongs to
+// another XCD's sequence and the lowest unfinished slice never waits: no deadlock whatever the residency).  `sk_state` (zero when
+// the launch starts and when it ends): [0..7] whole-item counters, [8] exit ticket, [9] set if a wait for a slab gave up (never,
+// unless the launch is broken), [10] slices drawn so far, [16..23] slice counters, [32 + s] "slab s is published".
 constexpr int SK_CH = SCN_SK_CH;    // slices per chunk of one XCD (16: the halo rows of a 14-tile region were fetched by two XCDs)
 constexpr int SK_ITEM_CH = 64;     // whole items per chunk of one XCD (the first rounds)
 constexpr int SK_STATE_WORDS = 32; // counters + ticket in front of the flags
