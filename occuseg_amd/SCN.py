@@ -262,6 +262,8 @@ class Metadata_3(object):
         assert coords.dtype in _COORD_DTYPES, coords.dtype
         key = _size_key(spatialSize)
         _WEPOCH[0] += 1  # a new batch: packed weights are re-made from the module's weights at their next use
+        if not _IN_PREFETCH[0]:
+            _WEPOCH_AT_INPUT[0] += 1  # (a step begins: the coarse-level mark of the step before is stale)
         pre = _PREFETCHED.pop(id(coords), None)
         if pre is not None and pre[0] is coords and pre[4] is normals \
                 and pre[1] == (key, int(mode), _norm_device(device), self.normal_guide_scale):
@@ -501,6 +503,10 @@ def _norm_device(device):
     return device
 
 
+PREFETCH_AT_COARSE_LEVELS = os.environ.get("SCN_PREFETCH_AT_COARSE", "1") != "0"  # A/B switch, see prefetch_input
+_COARSE_MARK = {}        # device index -> [event, input-layer count at which it was recorded]
+_WEPOCH_AT_INPUT = [0]   # counts InputLayer calls that built or adopted a batch
+_IN_PREFETCH = [False]
 PREFETCH_PRIORITY = int(os.environ.get("SCN_PREFETCH_PRIORITY", "-1"))  # HIP stream priority of the rule-build side stream (-1 = high)
 
 
@@ -525,8 +531,20 @@ def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=Tr
         side.wait_stream(torch.cuda.current_stream(device))
     if normal_guide_scale is not None:  # the threshold getRuleBook tests must be the InputLayer's, not the default
         m.setNormalGuideScale(normal_guide_scale)
+    # WHERE in the current step the build runs (round 4): a training loop issues the prefetch when the whole step is queued -- the
+    # GPU is then half a step behind, and the build's ~60 small kernels landed beside the first big dInput launches of the
+    # backward pass (0.5 ms per step: they are vector-ALU work on SIMDs that run MFMAs).  The backward pass marks the point
+    # where it enters the coarse levels -- launches of a few hundred workgroups that leave most of the chip's issue slots
+    # idle -- and the build waits for that mark.
+    mark = _COARSE_MARK.get(device.index) if PREFETCH_AT_COARSE_LEVELS else None
+    if mark is not None and mark[1] == _WEPOCH_AT_INPUT[0]:
+        side.wait_event(mark[0])
     with torch.cuda.stream(side):
-        m.inputLayer(spatialSize, coords, 0, mode, device, normals=normals)
+        _IN_PREFETCH[0] = True
+        try:
+            m.inputLayer(spatialSize, coords, 0, mode, device, normals=normals)
+        finally:
+            _IN_PREFETCH[0] = False
         done = torch.cuda.Event()
         done.record(side)
     _PREFETCHED.clear()  # one batch ahead is all a training loop needs; never keep stale grids alive
@@ -764,6 +782,14 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                 bnb = bn_link.struct()
             else:
                 stats_out.append(cstats)
+    if w_transposed and PREFETCH_AT_COARSE_LEVELS and kind == 2:
+        # the backward pass has reached the coarse levels: the point a rulebook prefetch waits for (prefetch_input)
+        mk = _COARSE_MARK.get(inp.device.index)
+        if mk is None:
+            mk = _COARSE_MARK[inp.device.index] = [torch.cuda.Event(), -1]
+        if mk[1] != _WEPOCH_AT_INPUT[0]:
+            mk[0].record(torch.cuda.current_stream(inp.device))
+            mk[1] = _WEPOCH_AT_INPUT[0]
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None, ptr(residual), ptr(cstats),
