@@ -105,10 +105,10 @@ SPLIT_FUSED = os.environ.get("SCN_SPLIT_FUSED", "1") != "0"
 _SK_STATE = {}  # (device index, stream handle) -> the zeroed control block of that stream's stream-K launches
 
 
-def _sk_state(device):
+def _sk_state(device, stream_handle=None):
     """SCN_SK_STATE_BYTES of zeros per (device, stream): slice counters and slab flags of a stream-K launch.  Every launch
     leaves the block as it found it; launches on ONE stream never overlap, so they can share one."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream if stream_handle is None else stream_handle)
     t = _SK_STATE.get(key)
     if t is None:
         t = _SK_STATE[key] = torch.zeros(_lib.SK_STATE_BYTES, dtype=torch.uint8, device=device)
@@ -356,7 +356,7 @@ class Metadata_3(object):
         rb.n_rows[out_col] = n_out
         # pass prefix of the 128-row tiles (scn_conv_forward's tile_passes): what a stream-K launch cuts into equal slices
         n_tiles = (n_out + 127) // 128
-        if rb.K > 1 and n_tiles >= 128:
+        if STREAM_K and rb.K > 1 and n_tiles >= 128:  # (three small launches per rulebook column: only when somebody will use them)
             passes = torch.empty(lib.scn_tile_passes_bytes(n_out) // 4, dtype=torch.int32, device=bases.device)
             check(lib.scn_tile_passes(ptr(bases), rb.K, n_out, ptr(passes), stream()))
             rb.passes[out_col] = passes
@@ -644,7 +644,7 @@ def _repack_all(device):
         ent.epoch = _WEPOCH[0]
 
 
-def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
+def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co, stream_handle=None):
     """returns (packed tensor, ready flag for scn_conv_forward)"""
     if not w_transposed and _BWD_SEEN[0]:  # a forward-direction call after a backward call: weights may have been updated
         _BWD_SEEN[0] = False
@@ -661,7 +661,7 @@ def _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co):
         ent = _WPACK.get(key)
     if ent is not None and ent.epoch == _WEPOCH[0] and ent.version == weight._version:
         ev = _REPACK_EVENT.get(weight.device.index)
-        if ev is not None and ev[1] != stream():  # re-packed on ANOTHER stream: this one waits for that launch
+        if ev is not None and ev[1] != (stream() if stream_handle is None else stream_handle):  # re-packed on ANOTHER stream: wait for that launch
             torch.cuda.current_stream(weight.device).wait_event(ev[0])
         return ent.wpack, 1
     lib = _lib_()
@@ -727,6 +727,29 @@ def _row_slice(t):
             and t.data_ptr() % 16 == 0 and t.size(0) > 0)
 
 
+_PLAN_CACHE = {}
+_PLAN_CACHEABLE = {}
+
+
+def _plan(lib, K, stride, n_plan, n_out, Ci, Co, uniq):
+    """(scn_conv_plan, scn_conv_workspace_bytes, scn_conv_stats_blocks) of a launch shape, asked once per shape and library build:
+    three ctypes calls per launch are host time the forward-only configuration is bound by"""
+    key = (id(lib), K, stride, n_plan, n_out, Ci, Co, uniq)
+    r = _PLAN_CACHE.get(key)
+    if r is None:
+        r = (lib.scn_conv_plan(K, stride, n_plan, n_out, Ci, Co, uniq),
+             lib.scn_conv_workspace_bytes(K, stride, n_plan, n_out, Ci, Co, uniq),
+             lib.scn_conv_stats_blocks(K, stride, n_plan, n_out, Ci, Co, uniq))
+        cacheable = _PLAN_CACHEABLE.get(id(lib))
+        if cacheable is None:  # (the tuning library's answers change with scn_set_tuning: never cached)
+            cacheable = _PLAN_CACHEABLE[id(lib)] = not hasattr(lib, "scn_set_tuning")
+        if cacheable:
+            if len(_PLAN_CACHE) > 4096:
+                _PLAN_CACHE.clear()
+            _PLAN_CACHE[key] = r
+    return r
+
+
 def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False, w_reverse=False, residual=None,
           stats_out=None, bn_link=None, out_view=None):
     """out = gather-mm-scatter over rb; weight is the module's [K, a, b] tensor, used as [K, Ci, Co]
@@ -753,7 +776,8 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                 ld_in, n_plan = inp.stride(0), n_eff
         if not ld_in:
             inp = inp.contiguous()
-    kind = lib.scn_conv_plan(K, rb.stride, n_plan, n_out, Ci, Co, uniq) // 100
+    code, ws_bytes, nblk_lib = _plan(lib, K, rb.stride, n_plan, n_out, Ci, Co, uniq)
+    kind = code // 100
     ld_out = 0
     if out_view is not None:
         assert kind == 5 and _row_slice(out_view) and tuple(out_view.shape) == (n_out, Co), (kind, out_view.shape)
@@ -762,9 +786,9 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
         out.resize_(n_out, Co)
     if residual is not None:
         assert residual.is_contiguous() and tuple(residual.shape) == (n_out, Co) and residual.data_ptr() != out.data_ptr()
-    wpack, ready = _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co)
+    st = stream()  # (once per call: torch.cuda.current_stream() is 2 us of host time, and the forward-only path is bound there)
+    wpack, ready = _packed_weight(weight, w_transposed, w_reverse, K, Ci, Co, st)
     # launches with few output tiles split their offsets over workgroups; partial tiles go through this workspace
-    ws_bytes = lib.scn_conv_workspace_bytes(K, rb.stride, n_plan, n_out, Ci, Co, uniq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=inp.device) if ws_bytes else None
     # column statistics of the result for the batch norm that consumes it (stats_out: a list that receives the tensor)
     cstats = None
@@ -773,8 +797,8 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                                     and bn_link.x.is_contiguous()):
         bn_link = None
     if stats_out is not None or bn_link is not None:
-        nblk = lib.scn_conv_stats_blocks(K, rb.stride, n_plan, n_out, Ci, Co, uniq)
-        if kind == 2 and not SPLIT_FUSED and lib.scn_conv_plan(K, rb.stride, n_plan, n_out, Ci, Co, uniq) % 100 > 1:
+        nblk = nblk_lib
+        if kind == 2 and not SPLIT_FUSED and code % 100 > 1:
             nblk = 0  # (a split launch emits statistics only when it adds its partial tiles itself: sk_state)
         if nblk > 0:
             cstats = torch.empty((nblk, 2, Co), dtype=torch.float32, device=inp.device)
@@ -797,14 +821,13 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                                ptr(rb.passes.get(out_col)) if STREAM_K else None, ptr(rb.counts), K, rb.stride,
                                in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ld_in, ld_out, ptr(wpack), ready, ptr(ws), ws_bytes,
-                               ptr(_sk_state(inp.device)) if (STREAM_K and kind == 4) or (SPLIT_FUSED and kind == 2) else None, stream()))
+                               ptr(_sk_state(inp.device, st)) if (STREAM_K and kind == 4) or (SPLIT_FUSED and kind == 2) else None, st))
     if bn_link is not None:
         bn_link.offer(out, cstats if bnb is not None else None)
     # algorithmic work of one launch: flops = 2 R Ci Co;
     # bytes = 4 (R Ci + n_out Co) + 8 R + 4 K Ci Co
     if ev is not None:
         R = rb.total_pairs
-        code = lib.scn_conv_plan(K, rb.stride, n_plan, n_out, Ci, Co, uniq)
         name = _CONV_KERNELS.get(code // 100, "conv") + ("_split" if code % 100 > 1 else "")
         if code // 100 == 0 and Ci <= 4 and Co % 16 == 0 and not w_transposed and residual is None:
             name = "conv_stem"  # k_conv_stem: the narrow-input layer as a GEMM on the matrix cores
@@ -1388,10 +1411,27 @@ def _traced(name, fn):
     return wrapper
 
 
+_UNTRACED = {}
+
+
+def _install_traced(on):
+    """swap the boundary functions of this module for their traced wrappers (callers look them up as SCN.<name> at call time);
+    off: the plain functions again -- tracing that is off costs nothing, not even a wrapper call (the forward-only configuration
+    is bound by the host's launch rate)"""
+    g = globals()
+    for n in _TRACED:
+        if on and n not in _UNTRACED:
+            _UNTRACED[n] = g[n]
+            g[n] = _traced(n, g[n])
+        elif not on and n in _UNTRACED:
+            g[n] = _UNTRACED.pop(n)
+
+
 def enable_roctx(on=True):
     """roctx ranges around the boundary functions on / off; returns whether they are on (False: libroctx64.so not found)"""
     if not on:
         _ROCTX[0] = None
+        _install_traced(False)
         return False
     if _ROCTX[0] is None:
         for cand in ("libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so"):
@@ -1404,10 +1444,9 @@ def enable_roctx(on=True):
                 break
             except (OSError, AttributeError):
                 continue
+    _install_traced(_ROCTX[0] is not None)
     return _ROCTX[0] is not None
 
 
-for _n in _TRACED:
-    globals()[_n] = _traced(_n, globals()[_n])
 if os.environ.get("SCN_ROCTX", "0") == "1":
     enable_roctx()

@@ -700,8 +700,8 @@ __global__ void __launch_bounds__(64 * NW * NWM) __attribute__((amdgpu_waves_per
     if (__builtin_amdgcn_readfirstlane(nk_s) != ksplit - 1) return;
     if (tid == 0) __hip_atomic_store(tickets + lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::: "memory");
-    // (slab 0 first -- it holds bias and shortcut --, then 1, 2, ...: k_split_reduce's order.  The split is 3-, 9- or 27-fold:
-    //  three slabs' worth of loads are in flight at a time, eight 16-byte pieces per thread each)
+    // (slab 0 first -- it holds bias and shortcut --, then 1, 2, ...: k_split_reduce's order.  The split is 3-, 9- or 27-fold (8-fold
+    //  for a strided rulebook): three slabs' worth of loads are in flight at a time, eight 16-byte pieces per thread each)
     constexpr int NE = M * (COB / 4) / NT;
     floatx4 acc[NE];
     unsigned off[NE];
@@ -3628,7 +3628,7 @@ static int launch_tile2(const float *in, float *out, const float *Wp, const floa
   const dim3 grid2((unsigned)(ntiles * ncb), (unsigned)ksplit);
   // split launches: with a control block the last workgroup of a tile adds the partial tiles itself (one ticket word per
   // (tile, plane block) behind the stream-K words; slabs < 4 GiB: 32-bit buffer offsets)
-  const bool fused = ksplit > 1 && tickets != nullptr && g_conv_split_fused && ksplit % 3 == 0 &&
+  const bool fused = ksplit > 1 && tickets != nullptr && g_conv_split_fused &&
                      (int64_t)ntiles * ncb + SK_STATE_WORDS <= (int64_t)(SCN_SK_STATE_BYTES / 4) && n_out * Co * 4 < ((int64_t)1 << 31);
 #define SCN_LAUNCH_T2(D)                                                                                   \
   k_conv_tile2<NW, COS, CK, D, NWM, M_><<<grid2, 64 * NW * NWM, 0, stream>>>(                             \
@@ -3948,7 +3948,7 @@ int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out
     // run as ONE launch (k_bn_small_fwd / _bwd), which a hand-over would turn into two.  (A reduction kernel that also
     // reduced columns cost +0.2 ms per step in round 2.)
     const int64_t items = ((n_out + M - 1) / M) * (Co / (16 * p.nw));
-    const bool fused = p.kind == 2 && g_conv_split_fused && p.ksplit % 3 == 0 && items + 32 <= (int64_t)(SCN_SK_STATE_BYTES / 4) &&
+    const bool fused = p.kind == 2 && g_conv_split_fused && items + 32 <= (int64_t)(SCN_SK_STATE_BYTES / 4) &&
                        n_out * Co * 4 < ((int64_t)1 << 31);
     return fused && n_out > 2048 ? (n_out + M - 1) / M : 0;
   }

@@ -57,3 +57,8 @@ def test_bench_two_ranks_code_path(request):
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["parallelism"] == "dp2" and res["config"]["allreduce_bytes"] > 0
     assert res["config"]["backend"] == "gloo" and res["config"]["ranks_seen"] == 2
+    # round 4: the N > 1 line explains itself -- how long each rank's main stream stood still for the gradient exchange, and how
+    # evenly the voxels fell
+    assert res["allreduce_exposed_ms"] >= 0.0 and len(res["per_rank"]["allreduce_exposed_ms"]) == 2
+    assert len(res["per_rank"]["active_voxels"]) == 2 and all(v > 0 for v in res["per_rank"]["active_voxels"])
+    assert abs(sum(res["per_rank"]["active_voxels"]) / max(res["per_rank"]["seconds"]) - res["value"]) < 1e-6 * res["value"]

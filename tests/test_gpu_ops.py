@@ -327,7 +327,13 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
     block is zero again after every launch."""
     from occuseg_amd import SCN, _lib
     from oracle import arith as A, rules as R
-    m, size, grid, _, _ = _setup(gpu, seed=21, n=45000, batch=2, extent=60)
+    before = SCN.STREAM_K
+    SCN.STREAM_K = True  # (off by default; rulebooks carry their pass prefix and slice tables only when it is on)
+    try:
+        m, size, grid, _, _ = _setup(gpu, seed=21, n=45000, batch=2, extent=60)
+        m.getSubmanifoldRuleBook(size, F3)
+    finally:
+        SCN.STREAM_K = before
     N = grid.n
     lib0 = _lib.load()
     tiles = (N + 127) // 128
