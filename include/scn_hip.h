@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 4
+#define SCN_ABI_VERSION 5
 #define SCN_TILE_GRANULE 32 /* output-row granule of the tile-base tables */
 #define SCN_SK_STATE_BYTES 65536 /* scn_conv_forward's sk_state */
+#define SCN_GRID_CHAIN_MAX 12     /* scales one scn_grid_chain_counts call can count */
 
 int scn_abi_version(void);
 const char *scn_last_error(void);
@@ -64,6 +65,22 @@ int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, i
                    void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
                    int32_t *site_of_row, int32_t *site_start, int32_t *n_sites_host,
                    void *stream);
+
+/* One host synchronisation per BATCH instead of one per scale.  The reference builds the grid of every scale when the
+ * first convolution that needs it asks (Metadata::getRuleBook -> Convolution_InputSgsToRulesAndOutputSgs_OMP /
+ * ..._FastDownSampleMode, sparseconvnet/SCN/Metadata/ConvolutionRules.h:741-843, :353-372) and learns its size there;
+ * all of them are functions of the input coordinates alone (scale l holds the voxels of coords >> l for size = stride =
+ * 2).  scn_grid_chain_counts counts the distinct voxels of coords >> l for l = 0..levels-1 in one launch (hash sets in
+ * `temp`) and reads the `levels` counts back with ONE stream synchronisation; scn_grid_build_async is scn_grid_build
+ * without its read-back for a caller that already knows N: it leaves N and the error flag in status_dev[0..1]
+ * (device memory) for the caller to compare with what it assumed at its next read-back.  Same errors as
+ * scn_grid_build. */
+size_t scn_grid_chain_temp_bytes(int64_t P, int levels);
+int scn_grid_chain_counts(const void *coords, int coords_dtype, int ncols, int64_t P, int levels, void *temp,
+                          size_t temp_bytes, int32_t *n_sites_host, void *stream);
+int scn_grid_build_async(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
+                         void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
+                         int32_t *site_of_row, int32_t *site_start, int32_t *status_dev, void *stream);
 
 /* site_coords [N,4] i32 = (x,y,z,b) of the first duplicate of each site
  * (sparseconvnet/SCN/CUDA/CUDPPWrapper.cu:224-226), site_keys [N] u64. */

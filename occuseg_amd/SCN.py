@@ -97,6 +97,14 @@ PREBUILD = True
 # for the whole launch, so the dWeight kernels of the side stream and the next batch's rule build, which plain launches
 # interleave with, delay the workgroups they displace and every slice waits for the slowest (43.5 -> 45.6 ms per step; with
 # drawn items and slices 44.0; DESIGN.md section 3.3e, profiles/r04_ab_stream_k.txt).  SCN_STREAM_K=1 / SCN.STREAM_K = True: on
+# One host read-back per batch for the site counts of ALL scales (scn_grid_chain_counts) instead of one per scale; the
+# scales are those the previous forward pass on the same input size asked for (PREBUILD's plan).  OFF: measured alone on
+# an m64 batch (tools/rules_alone.py, profiles/r04_rules_timeline.txt) the six read-backs cost 0.31 ms together (span
+# 2.45 ms, kernels 2.14 ms) and the counting launch that replaces five of them 0.50 ms (1.5 M compare-and-swaps into hash
+# sets): 2.60 against 2.45 ms per batch.  The build is bound by its ~185 launches and by the sort and probe kernels, not
+# by the read-backs.
+GRID_CHAIN = os.environ.get("SCN_GRID_CHAIN", "0") == "1"
+_GRID_CHAIN_MAX = 12
 STREAM_K = os.environ.get("SCN_STREAM_K", "0") == "1"
 # launches that split their offsets over several workgroups per tile (the coarse levels): the last workgroup of a tile adds the
 # partial tiles itself (scn_conv_forward's sk_state) instead of a second launch, and emits the batch norm's statistics.
@@ -207,12 +215,14 @@ class Metadata_3(object):
         self.input_site_of_row = None
         self.input_site_start = None
         self._plan = []
+        self._chain_counts = {}   # spatial size -> N from the grid chain (scn_grid_chain_counts), this batch
+        self._grid_status = []    # (device [N, error flag] of a grid built without read-back, the N it was built for)
 
     def setNormalGuideScale(self, s):
         self.normal_guide_scale = int(s)
 
     # -- grids ---------------------------------------------------------------
-    def _build_grid(self, coords_dev, dtype_code, ncols, shift, P):
+    def _build_grid(self, coords_dev, dtype_code, ncols, shift, P, n_known=None):
         lib = _lib_()
         dev = coords_dev.device
         ev = _prof_begin("rules")
@@ -222,11 +232,19 @@ class Metadata_3(object):
         order = torch.empty(P, dtype=torch.int32, device=dev)
         site_of_row = torch.empty(P, dtype=torch.int32, device=dev)
         site_start = torch.empty(P + 1, dtype=torch.int32, device=dev)
-        n = ctypes.c_int32(0)
-        check(lib.scn_grid_build(ptr(coords_dev), int(dtype_code), ncols, shift, P, ptr(temp), tb,
-                                 ptr(keys_sorted), ptr(order), ptr(site_of_row), ptr(site_start),
-                                 ctypes.byref(n), stream()))
-        N = int(n.value)
+        if n_known is None:
+            n = ctypes.c_int32(0)
+            check(lib.scn_grid_build(ptr(coords_dev), int(dtype_code), ncols, shift, P, ptr(temp), tb,
+                                     ptr(keys_sorted), ptr(order), ptr(site_of_row), ptr(site_start),
+                                     ctypes.byref(n), stream()))
+            N = int(n.value)
+        else:  # counted by the grid chain: no read-back here, the build's own count is compared at the batch's next one
+            N = int(n_known)
+            status = torch.empty(2, dtype=torch.int32, device=dev)
+            check(lib.scn_grid_build_async(ptr(coords_dev), int(dtype_code), ncols, shift, P, ptr(temp), tb,
+                                           ptr(keys_sorted), ptr(order), ptr(site_of_row), ptr(site_start),
+                                           ptr(status), stream()))
+            self._grid_status.append((status, N))
         site_coords = torch.empty((N, 4), dtype=torch.int32, device=dev)
         site_keys = torch.empty(N, dtype=torch.int64, device=dev)
         check(lib.scn_grid_finalize(ptr(coords_dev), int(dtype_code), ncols, shift, P, N, ptr(keys_sorted),
@@ -274,7 +292,10 @@ class Metadata_3(object):
         self.inputSpatialSize = key
         c = coords.to(device, non_blocking=True).contiguous()
         P = c.size(0)
-        g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P)
+        old_plan = _PLANS.get(key, [])
+        self._chain(c, key, old_plan if PREBUILD and GRID_CHAIN else [])
+        g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P,
+                                                             n_known=self._chain_counts.get(key))
         self.grids[key] = g
         self.nActive[key] = g.n
         self.input_mode = int(mode)
@@ -287,7 +308,6 @@ class Metadata_3(object):
             ori = torch.empty(g.n, dtype=torch.int32, device=c.device)
             check(_lib_().scn_site_normals(ptr(pn), ptr(order), ptr(site_start), g.n, ptr(sn), ptr(ori), stream()))
             self.normals[key] = (sn, ori)
-        old_plan = _PLANS.get(key, [])
         self._plan = []          # requests made by the ops of THIS forward pass (stale ones drop out)
         _PLANS[key] = self._plan
         if PREBUILD and old_plan:
@@ -301,10 +321,48 @@ class Metadata_3(object):
                         self.getRuleBook(req[1], req[2], req[3], req[4], _defer=True)
                 except NotImplementedError:
                     break  # not buildable for THIS batch (e.g. normals now guide a strided scale): the op itself will say so
-            if pending:  # ONE device->host copy for the pair counts of all submanifold rulebooks
-                totals = torch.stack([rb.counts.sum() for rb in pending]).cpu().tolist()
+            if pending or self._grid_status:
+                # ONE device->host copy for the pair counts of all submanifold rulebooks and for the site counts the
+                # grids built without read-back found themselves
+                st = self._grid_status
+                parts = [rb.counts.sum().reshape(1) for rb in pending] + [s for s, _ in st]
+                totals = torch.cat(parts).cpu().tolist()
                 for rb, t in zip(pending, totals):
                     rb.total_pairs = int(t)
+                self._check_grid_status(totals[len(pending):])
+
+    def _chain(self, c, key, old_plan):
+        """Site counts of every scale the previous forward pass on this input size built (its strided rulebook
+        requests chain down from the input size) with ONE read-back: scn_grid_chain_counts."""
+        sizes = [key]
+        for req in old_plan:
+            if req[0] != "sub" and req[1] == sizes[-1] and req[3] == (2, 2, 2) and req[4] == (2, 2, 2):
+                sizes.append(req[2])
+        if len(sizes) < 2 or len(sizes) > _GRID_CHAIN_MAX:
+            return
+        lib = _lib_()
+        P = c.size(0)
+        tb = lib.scn_grid_chain_temp_bytes(P, len(sizes))
+        temp = torch.empty(tb, dtype=torch.uint8, device=c.device)
+        n = (ctypes.c_int32 * len(sizes))()
+        ev = _prof_begin("rules")
+        check(lib.scn_grid_chain_counts(ptr(c), _COORD_DTYPES[c.dtype], c.size(1), P, len(sizes), ptr(temp), tb, n,
+                                        stream()))
+        _prof_end(ev, "grid_chain", 0.0, float(P * c.size(1) * c.element_size() + tb), (P, len(sizes)))
+        self._chain_counts = {sz: int(v) for sz, v in zip(sizes, n)}
+
+    def _flush_grid_status(self):
+        if self._grid_status:  # (a grid built outside the replayed plan: its own read-back)
+            self._check_grid_status(torch.cat([s for s, _ in self._grid_status]).cpu().tolist())
+
+    def _check_grid_status(self, flat):
+        """[N found, error flag] of every grid that was built for a site count taken from the chain"""
+        st, self._grid_status = self._grid_status, []
+        for i, (_, want) in enumerate(st):
+            got, err = int(flat[2 * i]), int(flat[2 * i + 1])
+            if err or got != want:
+                raise RuntimeError("occuseg_amd: grid built for %d sites found %d (error flag %d): "
+                                   "scn_grid_chain_counts and scn_grid_build disagree" % (want, got, err))
 
     def _tensors(self):
         for g in self.grids.values():
@@ -460,7 +518,8 @@ class Metadata_3(object):
             fine = self.grids[iS]
             dev = fine.coords.device
             Nf = fine.n
-            coarse, _order, coarse_of_fine, _start = self._build_grid(fine.coords, 0, 4, 1, Nf)
+            coarse, _order, coarse_of_fine, _start = self._build_grid(fine.coords, 0, 4, 1, Nf,
+                                                                      n_known=self._chain_counts.get(oS))
             self.grids[oS] = coarse
             self.nActive[oS] = coarse.n
             rules = torch.empty((8, Nf, 2), dtype=torch.int32, device=dev)
@@ -479,6 +538,7 @@ class Metadata_3(object):
             self.ruleBooks[key] = rb
         if not _defer:
             self._record(("conv", iS, oS, fs, st))
+            self._flush_grid_status()
         return rb
 
     # -- host views for tests / tooling ---------------------------------------

@@ -20,6 +20,9 @@ SIGNATURES = {
     "scn_grid_build_temp_bytes": (c_size_t, [c_int64]),
     "scn_grid_build": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, c_size_t, _P, _P, _P, _P,
                                ctypes.POINTER(c_int32), _P]),
+    "scn_grid_chain_temp_bytes": (c_size_t, [c_int64, c_int]),
+    "scn_grid_chain_counts": (c_int, [_P, c_int, c_int, c_int64, c_int, _P, c_size_t, ctypes.POINTER(c_int32), _P]),
+    "scn_grid_build_async": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, c_size_t, _P, _P, _P, _P, _P, _P]),
     "scn_grid_finalize": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
     "scn_hash_capacity": (c_int64, [c_int64]),
     "scn_hash_build": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
@@ -75,8 +78,9 @@ TUNING_SIGNATURES = {
     "scn_peak_read": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
 }
 TUNING_LIB_PATH = os.path.join(_HERE, "libscn_hip_tuning.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 SK_STATE_BYTES = 65536  # SCN_SK_STATE_BYTES
+GRID_CHAIN_MAX = 12     # SCN_GRID_CHAIN_MAX
 
 _lib = None
 

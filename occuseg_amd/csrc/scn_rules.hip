@@ -122,6 +122,46 @@ __global__ void k_site_coords(const void *coords_, int ncols, int shift, int64_t
   }
 }
 
+// ---------------------------------------------------- grid chain counts ---
+// Site counts of a whole chain of grids (the input grid and `levels - 1` 2/2 coarsenings of it) in ONE launch, so that a
+// batch needs ONE host read-back for all of them instead of one per scale: every input row inserts its voxel key of
+// scale 0, 1, ... into that scale's open-addressing set and stops at the first scale where the key was already there
+// (whoever put it there goes on to the coarser scales: P + N_0 + N_1 + ... insertions in all, not levels x P).
+template <int DT>
+__global__ void __launch_bounds__(256)
+    k_chain_count(const void *coords_, int ncols, int64_t P, int levels, uint64_t *tables, uint32_t mask, int *info) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool live = p < P;
+  int64_t x = 0, y = 0, z = 0, b = 0;
+  if (live) {
+    read_coords<DT>(coords_, p, ncols, x, y, z, b);
+    if (x < 0 || x >= 1024 || y < 0 || y >= 2048 || z < 0 || z >= 1024 || b < 0 || b >= 65536) {
+      atomicOr(info + levels, 1);
+      x = y = z = b = 0;
+    }
+  }
+  for (int l = 0; l < levels; ++l) {
+    if (live) {
+      const uint64_t key = voxel_key((int)(x >> l), (int)(y >> l), (int)(z >> l), (int)b);
+      uint64_t *t = tables + (size_t)l * ((size_t)mask + 1);
+      uint32_t slot = hash_slot(key, mask);
+      while (true) {
+        const unsigned long long prev =
+            atomicCAS((unsigned long long *)&t[slot], (unsigned long long)HASH_EMPTY, (unsigned long long)key);
+        if (prev == HASH_EMPTY) break;
+        if (prev == key) {
+          live = false;
+          break;
+        }
+        slot = (slot + 1) & mask;
+      }
+    }
+    const uint64_t m = __ballot(live);
+    if (m == 0) break;  // (wave-uniform)
+    if (lane_id() == (int)__builtin_ctzll(m)) atomicAdd(info + l, __popcll(m));
+  }
+}
+
 // ------------------------------------------------------------ hash map ---
 __global__ void k_hash_insert(const uint64_t *site_keys, int64_t N, uint64_t *tkeys,
                               int32_t *tvals, uint32_t mask) {
@@ -567,11 +607,10 @@ size_t scn_grid_build_temp_bytes(int64_t P) {
   return t.total;
 }
 
-int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
-                   void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
-                   int32_t *site_of_row, int32_t *site_start, int32_t *n_sites_host,
-                   void *stream_) {
-  hipStream_t stream = as_stream(stream_);
+// the launches of one grid build; `info` (device): [0] = N, [1] = error flag
+static int grid_build_launches(const void *coords, int coords_dtype, int ncols, int shift, int64_t P, void *temp,
+                               size_t temp_bytes, uint64_t *keys_sorted, int32_t *order, int32_t *site_of_row,
+                               int32_t *site_start, int *info, hipStream_t stream) {
   SCN_REQUIRE(P > 0 && P < (int64_t)1 << 31, "scn_grid_build: P out of range");
   SCN_REQUIRE(ncols == 3 || ncols == 4, "scn_grid_build: ncols must be 3 or 4");
   SCN_REQUIRE(coords_dtype >= 0 && coords_dtype <= 2, "scn_grid_build: coords_dtype must be 0 (int32), 1 (int64) or 2 (float32)");
@@ -582,9 +621,9 @@ int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, i
   uint64_t *keys_in = (uint64_t *)(base + t.keys_in);
   uint32_t *idx_in = (uint32_t *)(base + t.idx_in);
   int *blk_cnt = (int *)(base + t.blk_cnt);
-  int *info = (int *)(base + t.info);  // [0]=N [1]=error flag
+  if (info == nullptr) info = (int *)(base + t.info);
   const int nblk = (int)((P + 255) / 256);
-  SCN_CHECK_HIP(hipMemsetAsync(info, 0, 16, stream));
+  SCN_CHECK_HIP(hipMemsetAsync(info, 0, 8, stream));
   if (coords_dtype == 1)
     k_make_keys<1><<<grid_for(P), 256, 0, stream>>>(coords, ncols, shift, P, keys_in, idx_in, info + 1);
   else if (coords_dtype == 0)
@@ -601,12 +640,74 @@ int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, i
   k_assign_sites<<<nblk, 256, 0, stream>>>(keys_sorted, (const uint32_t *)order, P, blk_cnt,
                                           site_of_row, site_start);
   SCN_CHECK_LAUNCH();
+  return 0;
+}
+
+int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
+                   void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
+                   int32_t *site_of_row, int32_t *site_start, int32_t *n_sites_host,
+                   void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  if (int rc = grid_build_launches(coords, coords_dtype, ncols, shift, P, temp, temp_bytes, keys_sorted, order,
+                                   site_of_row, site_start, nullptr, stream))
+    return rc;
+  GridTemp t;
+  grid_temp_layout(P, t);
   int host_info[2] = {0, 0};
-  SCN_CHECK_HIP(hipMemcpyAsync(host_info, info, 8, hipMemcpyDeviceToHost, stream));
+  SCN_CHECK_HIP(hipMemcpyAsync(host_info, (char *)temp + t.info, 8, hipMemcpyDeviceToHost, stream));
   SCN_CHECK_HIP(hipStreamSynchronize(stream));
   if (host_info[1])
     return fail(3, "scn_grid_build: coordinate outside the 31-bit key box (0<=x<1024, 0<=y<2048, 0<=z<1024) or bad sample index%s", "");
   *n_sites_host = host_info[0];
+  return 0;
+}
+
+int scn_grid_build_async(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
+                         void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
+                         int32_t *site_of_row, int32_t *site_start, int32_t *status_dev, void *stream_) {
+  SCN_REQUIRE(status_dev != nullptr, "scn_grid_build_async: status_dev is required");
+  return grid_build_launches(coords, coords_dtype, ncols, shift, P, temp, temp_bytes, keys_sorted, order, site_of_row,
+                             site_start, (int *)status_dev, as_stream(stream_));
+}
+
+static int64_t chain_capacity(int64_t P) {
+  int64_t cap = 1024;
+  while (cap < 2 * P) cap <<= 1;
+  return cap;
+}
+
+size_t scn_grid_chain_temp_bytes(int64_t P, int levels) {
+  if (P <= 0 || levels < 1 || levels > SCN_GRID_CHAIN_MAX) return 0;
+  return (size_t)levels * (size_t)chain_capacity(P) * 8 + 256;
+}
+
+int scn_grid_chain_counts(const void *coords, int coords_dtype, int ncols, int64_t P, int levels, void *temp,
+                          size_t temp_bytes, int32_t *n_sites_host, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(P > 0 && P < (int64_t)1 << 30, "scn_grid_chain_counts: P out of range");
+  SCN_REQUIRE(ncols == 3 || ncols == 4, "scn_grid_chain_counts: ncols must be 3 or 4");
+  SCN_REQUIRE(coords_dtype >= 0 && coords_dtype <= 2, "scn_grid_chain_counts: coords_dtype must be 0 (int32), 1 (int64) or 2 (float32)");
+  SCN_REQUIRE(levels >= 1 && levels <= SCN_GRID_CHAIN_MAX, "scn_grid_chain_counts: levels must be 1..SCN_GRID_CHAIN_MAX");
+  SCN_REQUIRE(temp_bytes >= scn_grid_chain_temp_bytes(P, levels), "scn_grid_chain_counts: workspace too small");
+  const int64_t cap = chain_capacity(P);
+  uint64_t *tables = (uint64_t *)temp;
+  int *info = (int *)((char *)temp + (size_t)levels * (size_t)cap * 8);  // [levels] counts, [levels] error flag
+  SCN_CHECK_HIP(hipMemsetAsync(tables, 0xFF, (size_t)levels * (size_t)cap * 8, stream));
+  SCN_CHECK_HIP(hipMemsetAsync(info, 0, 4 * (SCN_GRID_CHAIN_MAX + 1), stream));
+  const int nblk = (int)((P + 255) / 256);
+  if (coords_dtype == 1)
+    k_chain_count<1><<<nblk, 256, 0, stream>>>(coords, ncols, P, levels, tables, (uint32_t)(cap - 1), info);
+  else if (coords_dtype == 0)
+    k_chain_count<0><<<nblk, 256, 0, stream>>>(coords, ncols, P, levels, tables, (uint32_t)(cap - 1), info);
+  else
+    k_chain_count<2><<<nblk, 256, 0, stream>>>(coords, ncols, P, levels, tables, (uint32_t)(cap - 1), info);
+  SCN_CHECK_LAUNCH();
+  int host_info[SCN_GRID_CHAIN_MAX + 1];
+  SCN_CHECK_HIP(hipMemcpyAsync(host_info, info, 4 * (levels + 1), hipMemcpyDeviceToHost, stream));
+  SCN_CHECK_HIP(hipStreamSynchronize(stream));
+  if (host_info[levels])
+    return fail(3, "scn_grid_chain_counts: coordinate outside the 31-bit key box (0<=x<1024, 0<=y<2048, 0<=z<1024) or bad sample index%s", "");
+  for (int l = 0; l < levels; ++l) n_sites_host[l] = host_info[l];
   return 0;
 }
 

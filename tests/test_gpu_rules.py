@@ -174,3 +174,92 @@ def test_tile_passes_prefix_and_stream_k_changes_nothing(gpu):
     finally:
         SCN.STREAM_K = before
     assert torch.equal(outs[0], outs[1])
+
+
+def _walk_levels(m, size, levels):
+    """what a UNet's forward pass asks of the metadata: 3x3x3 rules of every scale, 2/2 rules between them"""
+    f3, f2 = torch.tensor([3, 3, 3]), torch.tensor([2, 2, 2])
+    out = []
+    for level in range(levels):
+        rb = m.getSubmanifoldRuleBook(size, f3)
+        g = m.grids[tuple(int(v) for v in size)]
+        out.append((g.n, g.coords.clone(), g.keys.clone(), rb.host_lists(), rb.counts.clone(), rb.total_pairs))
+        if level + 1 < levels:
+            rb2 = m.getRuleBook(size, size // 2, f2, f2)
+            out.append((rb2.host_lists(), rb2.counts.clone(), rb2.bases[0].clone(), rb2.bases[1].clone()))
+            size = size // 2
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32, torch.float32])
+def test_grid_chain_one_read_back_same_grids(gpu, monkeypatch, dtype):
+    """scn_grid_chain_counts: the second batch on an input size counts the sites of all six scales in one launch and
+    builds every grid without a read-back of its own -- the same grids, rulebooks and pair counts as the per-scale
+    path, which is the one test_rulebooks_bit_exact holds against the oracle."""
+    from occuseg_amd import SCN, scenes
+    c, _ = scenes.batch([1000, 1001], target_sites=8000)
+    coords = torch.from_numpy(np.ascontiguousarray(c)).to(dtype)
+    size = torch.tensor([4096] * 3, dtype=torch.int64)
+    lib = SCN._lib_()
+    calls = {"scn_grid_build": 0, "scn_grid_build_async": 0, "scn_grid_chain_counts": 0}
+    for name in calls:
+        real = getattr(lib, name)
+        monkeypatch.setattr(lib, name, lambda *a, _r=real, _n=name: (calls.__setitem__(_n, calls[_n] + 1), _r(*a))[1])
+
+    def run(chain):
+        monkeypatch.setattr(SCN, "GRID_CHAIN", chain)
+        for k in calls:
+            calls[k] = 0
+        m = SCN.Metadata_3()
+        m.inputLayer(size, coords, 0, 4, gpu)
+        res = _walk_levels(m, size, 6)
+        assert not m._grid_status  # every grid built on a counted size has been checked against its own count
+        return res, dict(calls)
+
+    SCN._PLANS.pop((4096,) * 3, None)
+    ref, n0 = run(False)               # no plan yet: one read-back per scale
+    assert n0 == {"scn_grid_build": 6, "scn_grid_build_async": 0, "scn_grid_chain_counts": 0}
+    again, n1 = run(False)             # plan replayed, chain off
+    assert n1 == n0
+    got, n2 = run(True)                # plan replayed with the chain
+    assert n2 == {"scn_grid_build": 0, "scn_grid_build_async": 6, "scn_grid_chain_counts": 1}
+    assert [r[0] for r in ref[0::2]] == [r[0] for r in got[0::2]] and ref[0][0] > ref[2][0] > ref[10][0] > 0
+    for a, b, d in zip(ref, again, got):
+        for x, y, z in zip(a, b, d):
+            if torch.is_tensor(x):
+                assert torch.equal(x, y) and torch.equal(x, z)
+            elif isinstance(x, list):  # the lists of a rulebook (the rows behind counts[k] are unwritten memory)
+                assert len(x) == len(y) == len(z)
+                assert all(np.array_equal(i, j) and np.array_equal(i, k) for i, j, k in zip(x, y, z))
+            else:
+                assert x == y == z
+    # the error a coordinate outside the key box raises comes from the chain now
+    bad = coords.clone()
+    bad[5, 1] = 2048
+    monkeypatch.setattr(SCN, "GRID_CHAIN", True)
+    with pytest.raises(RuntimeError, match="key box"):
+        SCN.Metadata_3().inputLayer(size, bad, 0, 4, gpu)
+
+
+def test_grid_chain_counts_abi(gpu):
+    """the C entry by itself: counts of coords >> l against numpy's unique, duplicates, three samples, 12 scales"""
+    import ctypes
+    from occuseg_amd import SCN
+    from occuseg_amd.SCN import ptr, stream, check
+    lib = SCN._lib_()
+    rng = np.random.default_rng(5)
+    for P, span, ncols in ((1, 8, 3), (5000, 40, 4), (200000, 900, 4)):
+        c = rng.integers(0, span, size=(P, ncols)).astype(np.int32)
+        if ncols == 4:
+            c[:, 3] = rng.integers(0, 3, size=P)
+        levels = 12
+        t = torch.from_numpy(c).to(gpu)
+        tb = lib.scn_grid_chain_temp_bytes(P, levels)
+        temp = torch.empty(tb, dtype=torch.uint8, device=gpu)
+        n = (ctypes.c_int32 * levels)()
+        check(lib.scn_grid_chain_counts(ptr(t), 0, ncols, P, levels, ptr(temp), tb, n, stream()))
+        for l in range(levels):
+            cc = c.copy()
+            cc[:, :3] >>= l
+            assert n[l] == len(np.unique(cc, axis=0)), (P, l)
+    assert lib.scn_grid_chain_temp_bytes(100, 13) == 0 and lib.scn_grid_chain_temp_bytes(0, 2) == 0

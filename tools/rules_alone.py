@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""The rule build of one m64 batch (six grids, six submanifold and five strided rulebooks) alone on the GPU, ten times:
-under `rocprofv3 --kernel-trace --stats` its per-kernel cost without the train step's kernels beside it.
-usage: python tools/rules_alone.py [iterations]"""
+"""The rule build of one m64 batch (six grids, six submanifold and five strided rulebooks) alone on the GPU: the
+first call walks the scales as a UNet's forward pass does (that records the plan), every later InputLayer call replays
+the plan -- what a training or inference loop does from its second batch on.  Under `rocprofv3 --kernel-trace` its
+per-kernel cost and the gaps between the kernels (tools/rules_timeline.py) without a train step beside it.
+usage: python tools/rules_alone.py [iterations]      (SCN_GRID_CHAIN=0|1)"""
 import os
 import sys
 import time
@@ -12,15 +14,15 @@ import torch
 from occuseg_amd import SCN, scenes
 
 
-def build(coords, dev):
+def first(coords, dev):
     md = SCN.Metadata_3()
     size = torch.tensor([4096] * 3)
     md.inputLayer(size, coords, 0, 4, dev)
     f3, f2 = torch.tensor([3, 3, 3]), torch.tensor([2, 2, 2])
     for lv in range(6):
-        md.getSubmanifoldRuleBook(size, f3, _defer=True)
+        md.getSubmanifoldRuleBook(size, f3)
         if lv < 5:
-            md.getRuleBook(size, size // 2, f2, f2, _defer=True)
+            md.getRuleBook(size, size // 2, f2, f2)
             size = size // 2
     return md
 
@@ -30,13 +32,26 @@ def main():
     dev = torch.device("cuda:0")
     coords, _ = scenes.batch([1000, 1001, 1002, 1003], 150000)
     c = torch.from_numpy(coords).to(dev)
-    build(c, dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        build(c, dev)
-    torch.cuda.synchronize()
-    print("rule build alone: %.3f ms per batch (host clock, %d iterations)" % ((time.perf_counter() - t0) / iters * 1e3, iters))
+    first(c, dev)
+    plan = list(SCN._PLANS_USED[(4096,) * 3])
+    size = torch.tensor([4096] * 3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = []
+    for _ in range(iters + 2):
+        SCN._PLANS[(4096,) * 3] = list(plan)
+        md = SCN.Metadata_3()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        md.inputLayer(size, c, 0, 4, dev)
+        e1.record()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        ms.append((e0.elapsed_time(e1), (t1 - t0) * 1e3))
+    ms = ms[2:]
+    print("rule build alone, GRID_CHAIN=%s: %.3f ms per batch (events; min %.3f), host issue time %.3f ms, %d rulebooks, "
+          "sites %s" % (SCN.GRID_CHAIN, sum(m[0] for m in ms) / len(ms), min(m[0] for m in ms),
+                        sum(m[1] for m in ms) / len(ms), len(plan), [g.n for g in md.grids.values()]))
 
 
 if __name__ == "__main__":
