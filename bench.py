@@ -490,6 +490,8 @@ def main():
                        "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "rulebook_prefetch": bool(args.prefetch), "dweight_side_stream": dw_side,
                        "deterministic_dweight": bool(SCN.DETERMINISTIC_DW),
+                       "stream_k": ("off" if not SCN.STREAM_K else "forward launches" if SCN.STREAM_K_FWD_ONLY else "all launches"),
+                       "stream_k_gave_up": bool(SCN.stream_k_gave_up()),
                        "weight_repack": "every (weight, orientation) pair re-laid out once per step in one launch "
                                         "(SCN weight epochs): %d multi-tensor launches, %d single ones in the timed region"
                                         % (wpack_after["batch"] - wpack_before["batch"], wpack_after["single"] - wpack_before["single"]),

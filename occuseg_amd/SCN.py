@@ -92,11 +92,13 @@ PREBUILD = True
 # stream-K for the big gather-mm launches (k_conv_tile4): every rulebook carries the pass prefix of its 128-row tiles and the
 # slice tables (scn_tile_passes); handed those and a control block, a launch whose tiles would leave 3 % or more of the last
 # round of resident workgroups empty runs as 1,024 persistent workgroups on a static schedule: whole tiles first, then one slice of
-# the remaining pass sequence each, cut to fit -- bit-identical results.  OFF by default: alone such a launch is 1-13 % faster
-# (tools/ab_stream_k.py), but inside the train step the same launches are SLOWER -- persistent workgroups hold every CU's LDS
-# for the whole launch, so the dWeight kernels of the side stream and the next batch's rule build, which plain launches
-# interleave with, delay the workgroups they displace and every slice waits for the slowest (43.5 -> 45.6 ms per step; with
-# drawn items and slices 44.0; DESIGN.md section 3.3e, profiles/r04_ab_stream_k.txt).  SCN_STREAM_K=1 / SCN.STREAM_K = True: on
+# the remaining pass sequence each, cut to fit -- bit-identical results.  Alone such a launch is 1-13 % faster
+# (tools/ab_stream_k.py).  Inside the train step that holds for the launches of the FORWARD direction, which have the chip to
+# themselves: 43.25 -> 42.81 ms per step (profiles/r04_ab_stream_k_fwd.txt).  In the backward pass persistent workgroups hold
+# every CU's LDS for the whole launch, so the dWeight kernels of the side stream and the next batch's rule build, which plain
+# launches interleave with, queue behind them or delay the workgroups they displace, and every slice waits for the slowest
+# (45.2 ms with stream-K everywhere; DESIGN.md section 3.3e, profiles/r04_ab_stream_k.txt).
+# SCN_STREAM_K=fwd (default): forward launches only; =1: every launch; =0: off.  SCN.STREAM_K / SCN.STREAM_K_FWD_ONLY at run time.
 # One host read-back per batch for the site counts of ALL scales (scn_grid_chain_counts) instead of one per scale; the
 # scales are those the previous forward pass on the same input size asked for (PREBUILD's plan).  OFF: measured alone on
 # an m64 batch (tools/rules_alone.py, profiles/r04_rules_timeline.txt) the six read-backs cost 0.31 ms together (span
@@ -105,7 +107,8 @@ PREBUILD = True
 # by the read-backs.
 GRID_CHAIN = os.environ.get("SCN_GRID_CHAIN", "0") == "1"
 _GRID_CHAIN_MAX = 12
-STREAM_K = os.environ.get("SCN_STREAM_K", "0") == "1"
+STREAM_K = os.environ.get("SCN_STREAM_K", "fwd") in ("1", "fwd")
+STREAM_K_FWD_ONLY = os.environ.get("SCN_STREAM_K", "fwd") == "fwd"
 # launches that split their offsets over several workgroups per tile (the coarse levels): the last workgroup of a tile adds the
 # partial tiles itself (scn_conv_forward's sk_state) instead of a second launch, and emits the batch norm's statistics.
 # False: k_split_reduce as in round 3 (A/B: tools/ab_step.py SPLIT_FUSED=0,1)
@@ -121,6 +124,15 @@ def _sk_state(device, stream_handle=None):
     if t is None:
         t = _SK_STATE[key] = torch.zeros(_lib.SK_STATE_BYTES, dtype=torch.uint8, device=device)
     return t
+
+
+def stream_k_gave_up():
+    """True if a stream-K launch of this process ever stopped waiting for another workgroup's partial tile (word 9 of the
+    control block; a bounded wait, so that a broken launch cannot hang the GPU): its result is then wrong.  Never observed;
+    tests and bench.py ask after their runs."""
+    return any(bool(t.view(torch.int32)[9].item()) for t in _SK_STATE.values())
+
+
 KEEP_NBR = False  # tests only: keep each submanifold rulebook's neighbour table (`d_global_query_result`) alive
 _COORD_DTYPES = {torch.int32: 0, torch.int64: 1, torch.float32: 2}  # scn_grid_build coords_dtype
 
@@ -878,7 +890,8 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None, ptr(residual), ptr(cstats),
                                ctypes.byref(bnb) if bnb is not None else None, ptr(rb.rules), ptr(rb.bases[out_col]),
-                               ptr(rb.passes.get(out_col)) if STREAM_K else None, ptr(rb.counts), K, rb.stride,
+                               ptr(rb.passes.get(out_col)) if STREAM_K and not (STREAM_K_FWD_ONLY and w_transposed) else None,
+                               ptr(rb.counts), K, rb.stride,
                                in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ld_in, ld_out, ptr(wpack), ready, ptr(ws), ws_bytes,
                                ptr(_sk_state(inp.device, st)) if (STREAM_K and kind == 4) or (SPLIT_FUSED and kind == 2) else None, st))

@@ -328,7 +328,7 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
     from occuseg_amd import SCN, _lib
     from oracle import arith as A, rules as R
     before = SCN.STREAM_K
-    SCN.STREAM_K = True  # (off by default; rulebooks carry their pass prefix and slice tables only when it is on)
+    SCN.STREAM_K = True  # (rulebooks carry their pass prefix and slice tables only when it is on: SCN_STREAM_K=0 must not break the test)
     try:
         m, size, grid, _, _ = _setup(gpu, seed=21, n=45000, batch=2, extent=60)
         m.getSubmanifoldRuleBook(size, F3)
@@ -366,7 +366,7 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
         return out, sink[0], d_in, part
 
     before = SCN.STREAM_K
-    SCN.STREAM_K = True  # (hand tile_passes and the control block to every launch: off by default)
+    SCN.STREAM_K = True  # (hand tile_passes and the control block to every launch)
     got = {}
     try:
         got["product"] = run()
