@@ -400,11 +400,14 @@ def main():
                  "counted_bytes_per_launch": cb, "counted_over_algorithmic": (cb / algo_pl) if cb else None,
                  "hbm_bytes": "counted" if (cb and cb < algo_pl) else "algorithmic",
                  "hbm_frac": use * cnt / secs / 1e9 / HBM_PEAK_GBS}
+            if k["hbm_frac"] > 1.0:  # (only without a counter file for these sources: the formula's over-count, not a rate)
+                k["hbm_frac"] = None
+                k["hbm_bytes"] = "algorithmic, over-counted (no counter file for these kernel sources)"
             if flops > 0:
                 k["tflops"] = flops / secs / 1e12
                 k["mfma_frac"] = flops / secs / 1e12 / F32_MFMA_PEAK_TFLOPS
                 k["bound"] = "mfma" if flops / max(use * cnt, 1.0) > F32_MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"
-            if hbm_meas:
+            if hbm_meas and k["hbm_frac"] is not None:
                 k["hbm_frac_of_measured"] = use * cnt / secs / 1e9 / hbm_meas
             kernels[kname] = k
         groups = {"bn": ("bn_fwd", "bn_bwd"), "rules": ("grid_build", "sub_rules", "strided_rules"), "io": ("io",)}

@@ -426,7 +426,9 @@ class Metadata_3(object):
         rb.n_rows[out_col] = n_out
         # pass prefix of the 128-row tiles (scn_conv_forward's tile_passes): what a stream-K launch cuts into equal slices
         n_tiles = (n_out + 127) // 128
-        if STREAM_K and rb.K > 1 and n_tiles >= 128:  # (three small launches per rulebook column: only when somebody will use them)
+        # (three small launches per rulebook column: only when somebody will use them -- with stream-K on the forward launches
+        #  only, that is the column the forward direction writes)
+        if STREAM_K and rb.K > 1 and n_tiles >= 128 and (out_col == 1 or not STREAM_K_FWD_ONLY):
             passes = torch.empty(lib.scn_tile_passes_bytes(n_out) // 4, dtype=torch.int32, device=bases.device)
             check(lib.scn_tile_passes(ptr(bases), rb.K, n_out, ptr(passes), stream()))
             rb.passes[out_col] = passes
@@ -942,10 +944,29 @@ def dw_async(allowed):
         _DW_ALLOW[0] = before
 
 
+# HIP stream priority of the dWeight side stream: 0 = a torch stream of normal priority; 1 = HIP's LOW priority (torch's own
+# streams know high and normal only: created with hipStreamCreateWithPriority and wrapped) -- the dInput / batch-norm kernels
+# of the main stream are the critical path of the backward pass, the dWeight kernels only have to be done at its end.
+DW_PRIORITY = int(os.environ.get("SCN_DW_PRIORITY", "0"))
+_HIP_RT = []
+
+
+def _low_priority_stream(dev, priority):
+    if not _HIP_RT:
+        _HIP_RT.append(ctypes.CDLL("libamdhip64.so"))
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = _HIP_RT[0].hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))  # 1 = hipStreamNonBlocking
+    if rc != 0 or not h.value:
+        raise RuntimeError("occuseg_amd: hipStreamCreateWithPriority(%d) failed (%d)" % (priority, rc))
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 def _dw_state(dev):
     st = _DW_STATE.get(dev.index)
     if st is None:
-        st = _DW_STATE[dev.index] = [torch.cuda.Stream(device=dev), None, []]
+        side = _low_priority_stream(dev, DW_PRIORITY) if DW_PRIORITY > 0 else torch.cuda.Stream(device=dev)
+        st = _DW_STATE[dev.index] = [side, None, []]
     return st
 
 
