@@ -428,6 +428,7 @@ def main():
             alone = []
             plan_key = (4096, 4096, 4096)
             plan = list(SCN._PLANS_USED.get(plan_key, []))  # the rulebook requests of one forward pass of this network
+            chain, SCN.GRID_CHAIN = SCN.GRID_CHAIN, False  # (as prefetch_input builds it in training: a read-back per scale)
             for b in batches + batches:
                 SCN._PLANS[plan_key] = list(plan)
                 md = SCN.Metadata_3()
@@ -436,6 +437,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 alone.append(e0.elapsed_time(e1))
+            SCN.GRID_CHAIN = chain
             kernels["rules"]["alone_ms_per_batch"] = min(alone)
             kernels["rules"]["alone_ms_all"] = alone
             kernels["rules"]["alone_rulebooks_built"] = len(plan)

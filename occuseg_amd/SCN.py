@@ -67,8 +67,20 @@ def _lib_():
     return _lib.load()
 
 
+_SIZE_KEYS = {}  # id(tensor) -> (tensor, version, key): the modules pass the same few size tensors on every call
+
+
 def _size_key(t):
-    return tuple(int(v) for v in t.tolist()) if torch.is_tensor(t) else tuple(int(v) for v in t)
+    if not torch.is_tensor(t):
+        return tuple(int(v) for v in t)
+    e = _SIZE_KEYS.get(id(t))
+    if e is not None and e[0] is t and e[1] == t._version:
+        return e[2]
+    key = tuple(int(v) for v in t.tolist())
+    if len(_SIZE_KEYS) > 4096:
+        _SIZE_KEYS.clear()
+    _SIZE_KEYS[id(t)] = (t, t._version, key)
+    return key
 
 
 def _need_cuda(t, what):
@@ -100,12 +112,16 @@ PREBUILD = True
 # (45.2 ms with stream-K everywhere; DESIGN.md section 3.3e, profiles/r04_ab_stream_k.txt).
 # SCN_STREAM_K=fwd (default): forward launches only; =1: every launch; =0: off.  SCN.STREAM_K / SCN.STREAM_K_FWD_ONLY at run time.
 # One host read-back per batch for the site counts of ALL scales (scn_grid_chain_counts) instead of one per scale; the
-# scales are those the previous forward pass on the same input size asked for (PREBUILD's plan).  OFF: measured alone on
-# an m64 batch (tools/rules_alone.py, profiles/r04_rules_timeline.txt) the six read-backs cost 0.31 ms together (span
-# 2.45 ms, kernels 2.14 ms) and the counting launch that replaces five of them 0.50 ms (1.5 M compare-and-swaps into hash
-# sets): 2.60 against 2.45 ms per batch.  The build is bound by its ~185 launches and by the sort and probe kernels, not
-# by the read-backs.
-GRID_CHAIN = os.environ.get("SCN_GRID_CHAIN", "0") == "1"
+# scales are those the previous forward pass on the same input size asked for (PREBUILD's plan).  Measured (m64 batch alone,
+# tools/rules_alone.py, profiles/r04_rules_timeline.txt): the six read-backs cost 0.31 ms together (span 2.45 ms, kernels
+# 2.14 ms) and the counting launch that replaces five of them 0.50 ms (1.5 M compare-and-swaps into hash sets): 2.60
+# against 2.45 ms per batch -- the build is bound by its kernels and its ~185 launches, not by the read-backs.  But with ONE
+# early read-back the host issues the rest of the build and the forward pass behind it without waiting: the forward-only
+# configuration, which builds its rulebooks in the forward pass and is bound by host time, gains 4-8 % (cfg2 4.56 -> 4.18,
+# 4.23 -> 4.06 ms).  "auto" (default): the chain for builds inside a forward pass, per-scale read-backs for builds that
+# prefetch_input runs on its side stream (there the host has nothing else to issue and the device time counts).
+_GC = os.environ.get("SCN_GRID_CHAIN", "auto")
+GRID_CHAIN = True if _GC == "1" else False if _GC == "0" else "auto"
 _GRID_CHAIN_MAX = 12
 STREAM_K = os.environ.get("SCN_STREAM_K", "fwd") in ("1", "fwd")
 STREAM_K_FWD_ONLY = os.environ.get("SCN_STREAM_K", "fwd") == "fwd"
@@ -305,7 +321,8 @@ class Metadata_3(object):
         c = coords.to(device, non_blocking=True).contiguous()
         P = c.size(0)
         old_plan = _PLANS.get(key, [])
-        self._chain(c, key, old_plan if PREBUILD and GRID_CHAIN else [])
+        chain = GRID_CHAIN if GRID_CHAIN != "auto" else not _IN_PREFETCH[0]
+        self._chain(c, key, old_plan if PREBUILD and chain else [])
         g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P,
                                                              n_known=self._chain_counts.get(key))
         self.grids[key] = g

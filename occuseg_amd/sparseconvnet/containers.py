@@ -10,7 +10,7 @@ from torch.nn import Module, Parameter
 
 from .. import SCN
 from . import counters
-from .tensor import GradJoin, SparseConvNetTensor, like_empty, optionalTensor
+from .tensor import GradJoin, SparseConvNetTensor, apply_function, like_empty, optionalTensor
 
 
 class Sequential(torch.nn.Sequential):
@@ -154,7 +154,7 @@ class JoinTable(torch.nn.Sequential):
                 join = None  # (the table's left entry is not the tensor the batch norm at the head of the path received)
             if join is not None:
                 join.armed = True
-            out = _like(input[0], _JoinFunction.apply(left, right, base, join))
+            out = _like(input[0], apply_function(_JoinFunction, left, right, base, join))
         else:
             out = _like(input[0], torch.cat([t.features for t in input], 1))
         if all(stats):  # the statistics of a concatenation are the concatenation of the statistics
@@ -227,7 +227,7 @@ class NetworkInNetwork(Module):
 
     def forward(self, input, join=None):
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, input.features.shape)
-        return _like(input, _NiNFunction.apply(input.features, self.weight, optionalTensor(self, "bias"), join))
+        return _like(input, apply_function(_NiNFunction, input.features, self.weight, optionalTensor(self, "bias"), join))
 
     def input_spatial_size(self, out_size):
         return out_size

@@ -12,7 +12,7 @@ from torch.nn import Module, Parameter
 
 from .. import SCN
 from . import counters
-from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTensorReturn, toLongTensor
+from .tensor import SparseConvNetTensor, apply_function, like_empty, optionalTensor, optionalTensorReturn, toLongTensor
 
 
 def grad_owner(*params):
@@ -163,8 +163,7 @@ class _RuleConv(Module):
         # LDS) for the batch norm that usually follows
         sink = [] if (self.training and EMIT_COLSTATS) else None
         base = [] if (self.kind == "deconv" and getattr(self, "join_right", False) and JOIN_IN_PLACE) else None
-        output.features = _RuleConvFunction.apply(
-            input.features, self.weight, optionalTensor(self, "bias"), self.kind, input.metadata,
+        output.features = apply_function(_RuleConvFunction, input.features, self.weight, optionalTensor(self, "bias"), self.kind, input.metadata,
             input.spatial_size, out_size, self.filter_size, self.filter_stride, self.dilated_rate, residual, sink,
             input.get_bn_link() if hasattr(input, "get_bn_link") else None, join if residual is not None else None, base)
         if sink:

@@ -10,7 +10,7 @@ from torch.autograd import Function
 from torch.nn import Module
 
 from .. import SCN
-from .tensor import Metadata, SparseConvNetTensor, like_empty, toLongTensor
+from .tensor import Metadata, SparseConvNetTensor, apply_function, like_empty, toLongTensor
 
 
 class _InputLayerFunction(Function):
@@ -67,7 +67,7 @@ class InputLayer(Module):
         normals = input[2] if len(input) > 2 else None
         batch_size = input[3] if len(input) > 3 else 0
         output = SparseConvNetTensor(metadata=Metadata(self.dimension), spatial_size=self.spatial_size)
-        output.features = _InputLayerFunction.apply(features, output.metadata, self.spatial_size,
+        output.features = apply_function(_InputLayerFunction, features, output.metadata, self.spatial_size,
                                                     _coords(coords), batch_size, self.mode, normals,
                                                     self.normal_guide_scale)
         return output
@@ -92,4 +92,4 @@ class OutputLayer(Module):
         self.dimension = dimension
 
     def forward(self, input):
-        return _OutputLayerFunction.apply(input.features, input.metadata)
+        return apply_function(_OutputLayerFunction, input.features, input.metadata)

@@ -11,7 +11,7 @@ from torch.nn import Module, Parameter
 
 from .. import SCN
 from . import conv
-from .tensor import SparseConvNetTensor, like_empty, optionalTensor, optionalTensorReturn
+from .tensor import SparseConvNetTensor, apply_function, like_empty, optionalTensor, optionalTensorReturn
 
 
 class _BatchNormFunction(Function):
@@ -93,8 +93,7 @@ class BatchNormalization(Module):
         if ext and sum(n for n, _ in ext) != self.nPlanes:
             ext = None
         link_out = [] if (self.training and torch.is_grad_enabled() and input.features.requires_grad) else None
-        output.features = _BatchNormFunction.apply(
-            input.features, optionalTensor(self, "weight"), optionalTensor(self, "bias"), self.running_mean,
+        output.features = apply_function(_BatchNormFunction, input.features, optionalTensor(self, "weight"), optionalTensor(self, "bias"), self.running_mean,
             self.running_var, self.eps, self.momentum, self.training, self.leakiness, ext, link_out, join)
         if link_out:
             output.set_bn_link(link_out[0])

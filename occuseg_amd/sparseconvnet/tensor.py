@@ -142,3 +142,27 @@ def optionalTensorReturn(t):
 def like_empty(t):
     """the `input_features.new()` of the reference: an empty tensor on the same device"""
     return torch.empty(0, dtype=t.dtype, device=t.device)
+
+
+
+class _NoGraphCtx(object):
+    """what a Function's forward sees of autograd's context when no graph is recorded"""
+    needs_input_grad = ()
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_dirty(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def apply_function(fn, *args):
+    """``fn.apply(*args)``; under torch.no_grad() the forward is called directly -- Function.apply costs ~6 us of host time
+    per call whether or not it records anything, and the forward-only configuration is bound by its host time (80 calls per
+    forward pass of a UNet)."""
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_NoGraphCtx(), *args)
