@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--no-dw-side-stream", action="store_true",
                     help="keep the dWeight kernels on the main stream in every step (kernel durations in a profile of this "
                          "command are then exclusive ones, as on the steps whose launches carry events)")
+    ap.add_argument("--atomic-dweight", action="store_true",
+                    help="SCN.DETERMINISTIC_DW = False: dWeight partial sums added with float atomics (the reference's way)")
     ap.add_argument("--deterministic", action="store_true",
                     help="SCN.DETERMINISTIC_DW: dWeight partial sums added in a fixed order (bitwise reproducible gradients)")
     ap.add_argument("--same-batch", action="store_true", help="replay ONE batch (round-1 behaviour) instead of alternating two")
@@ -215,7 +217,10 @@ def main():
     import occuseg_amd
     from occuseg_amd import SCN, dp, scenes
     scn = occuseg_amd.install()
-    SCN.DETERMINISTIC_DW = bool(args.deterministic)
+    if args.deterministic:
+        SCN.DETERMINISTIC_DW = True
+    if args.atomic_dweight:
+        SCN.DETERMINISTIC_DW = False
     for sw in filter(None, os.environ.get("SCN_BENCH_SWITCHES", "").split(",")):  # debugging: e.g. conv.JOIN_IN_PLACE=0,tune13=0
         name, val = sw.split("=")
         if name.startswith("tune"):

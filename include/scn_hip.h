@@ -33,6 +33,7 @@ extern "C" {
 #define SCN_TILE_GRANULE 32 /* output-row granule of the tile-base tables */
 #define SCN_SK_STATE_BYTES 65536 /* scn_conv_forward's sk_state */
 #define SCN_GRID_CHAIN_MAX 12     /* scales one scn_grid_chain_counts call can count */
+#define SCN_DW_STATE_BYTES 1048576 /* scn_conv_dweight's dw_state */
 
 int scn_abi_version(void);
 const char *scn_last_error(void);
@@ -254,13 +255,18 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
  * output-row major (every dOut row read once instead of once per pair).
  * workspace (may be NULL): scn_conv_dweight_workspace_bytes(...) bytes.  Without it the workgroups add their partial sums to
  * dW with float atomics (as the reference, Convolution.cu:749): the result is reproducible to rounding only.  With it every
- * workgroup stores its partial sums to a slot of its own and a second kernel adds the slots to dW in a fixed order: dW is
- * bitwise reproducible run to run (costs a memset and a pass over slots x |dW| floats). */
+ * workgroup stores its partial sums to a slot of its own and the slots are added to dW in a fixed order: dW is bitwise
+ * reproducible run to run.
+ * dw_state (may be NULL; used with a workspace only): SCN_DW_STATE_BYTES bytes of device memory that hold ZERO when the launch
+ * starts; the launch leaves them zero (arrival tickets).  Launches that may overlap -- different streams -- need different
+ * blocks.  With it the fixed-order addition happens INSIDE the dWeight kernel (the last workgroup of every group of 16 slices
+ * adds the group, the last group of an (offset, plane block) adds the groups and updates dW): no memset of the workspace, no
+ * second launch.  Without it: memset + kernel + reduction kernel.  The two forms add in different (each fixed) orders. */
 size_t scn_conv_dweight_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_dout, int Ci, int Co, int has_bases);
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, const int32_t *bases, int K, int64_t stride, int in_col,
                      int out_col, int64_t n_in, int64_t n_dout, int Ci, int Co, int64_t ld_in, int64_t ld_dout,
-                     void *workspace, size_t workspace_bytes, void *stream);
+                     void *workspace, size_t workspace_bytes, void *dw_state, void *stream);
 
 /* column sums: d_bias[c] = sum_rows dOut[r][c] (sparseconvnet/SCN/CUDA/Convolution.cu:52-75) */
 int scn_column_sum(const float *x, float *out, int64_t rows, int C, void *stream);

@@ -1048,8 +1048,24 @@ def _dw_finish(idx):
 DW_SIDE_TEST_DELAY_CYCLES = 0  # tests only: a spin kernel in front of every side-stream dWeight kernel, so that the side stream
                                # lags the main stream by milliseconds and anything the kernel reads that is not pinned is gone
                                # by the time it runs (tests/test_gpu_memory_safety.py)
-DETERMINISTIC_DW = False  # True: parameter gradients bitwise reproducible run to run (scn_conv_dweight's workspace: partial
-                          # sums added in a fixed order instead of float atomics); costs a memset + a reduction per launch
+# Parameter gradients bitwise reproducible run to run (on by default since round 4; SCN_DETERMINISTIC_DW=0 / False: float atomics
+# as the reference, sparseconvnet/SCN/CUDA/Convolution.cu:749).  scn_conv_dweight gets a workspace -- a slot per workgroup -- and
+# a ticket block: k_dw_tile adds the slots in a fixed order INSIDE the kernel (no memset, no second launch: the first form, memset +
+# kernel + reduction kernel, cost 0.8 ms per train step in 74 extra launches; this one 0.05-0.2 ms, profiles/r04_ab_deterministic_dw.txt).
+DETERMINISTIC_DW = os.environ.get("SCN_DETERMINISTIC_DW", "1") != "0"
+
+
+_DW_TICKETS = {}
+
+
+def _dw_ticket_state(device):
+    """SCN_DW_STATE_BYTES of zeros per (device, stream): the arrival tickets of scn_conv_dweight's in-kernel fixed-order
+    reduction.  Every launch leaves the block as it found it; launches on one stream never overlap."""
+    key = (device.index, stream())
+    t = _DW_TICKETS.get(key)
+    if t is None:
+        t = _DW_TICKETS[key] = torch.zeros(_lib.DW_STATE_BYTES, dtype=torch.uint8, device=device)
+    return t
 
 
 def _dw_workspace(rb, out_col, K, n_in, n_dout, Ci, Co, device):
@@ -1099,7 +1115,8 @@ def _conv_backward(inp, d_in, d_out, weight, d_weight, d_bias, rb, in_col, out_c
             ws, wsb = _dw_workspace(rb, out_col, K, inp.size(0), d_out.size(0), Ci, Co, inp.device)
             check(lib.scn_conv_dweight(ptr(inp), ptr(d_out), ptr(d_weight), ptr(rb.rules), ptr(rb.counts),
                                        ptr(rb.bases.get(out_col)), K, rb.stride, in_col, out_col, inp.size(0),
-                                       d_out.size(0), Ci, Co, 0, ld_dout, ptr(ws), wsb, stream()))
+                                       d_out.size(0), Ci, Co, 0, ld_dout, ptr(ws), wsb, ptr(_dw_ticket_state(inp.device)) if ws is not None else None,
+                                       stream()))
             R = rb.total_pairs
             _prof_end(ev, "dw_tile" if Ci % 32 == 0 and Co % 32 == 0 else
                       ("dw_stem" if Ci <= 4 and Co % 16 == 0 and rb.bases.get(out_col) is not None else "dw_narrow"), 2.0 * R * Ci * Co,
@@ -1440,7 +1457,8 @@ def NetworkInNetwork_accGradParameters(input_features, d_output_features, d_weig
         ws, wsb = _dw_workspace(rb, 1, 1, n, n, Ci, Co, input_features.device)
         check(_lib_().scn_conv_dweight(ptr(input_features.contiguous()), ptr(d_output_features.contiguous()),
                                        ptr(d_weight), ptr(rb.rules), ptr(rb.counts), ptr(rb.bases.get(1)), 1, rb.stride,
-                                       0, 1, n, n, Ci, Co, 0, 0, ptr(ws), wsb, stream()))
+                                       0, 1, n, n, Ci, Co, 0, 0, ptr(ws), wsb,
+                                       ptr(_dw_ticket_state(input_features.device)) if ws is not None else None, stream()))
         _prof_end(ev, "dw_tile", 2.0 * n * Ci * Co, 4.0 * n * (Ci + Co) + 8.0 * n + 4.0 * Ci * Co, (1, n, Ci, Co, 0, 0))
         return
     if n:

@@ -46,7 +46,7 @@ SIGNATURES = {
                                  c_int64, c_int64, c_int, c_int, c_int64, c_int64, _P, c_int, _P, c_size_t, _P, _P]),
     "scn_conv_dweight_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "scn_conv_dweight": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64,
-                                 c_int64, _P, c_size_t, _P]),
+                                 c_int64, _P, c_size_t, _P, _P]),
     "scn_column_sum": (c_int, [_P, _P, c_int64, c_int, _P]),
     "scn_bn_temp_bytes": (c_size_t, [c_int]),
     "scn_bn_forward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_int, c_double,
@@ -81,6 +81,7 @@ TUNING_LIB_PATH = os.path.join(_HERE, "libscn_hip_tuning.so")
 ABI_VERSION = 5
 SK_STATE_BYTES = 65536  # SCN_SK_STATE_BYTES
 GRID_CHAIN_MAX = 12     # SCN_GRID_CHAIN_MAX
+DW_STATE_BYTES = 1048576  # SCN_DW_STATE_BYTES
 
 _lib = None
 

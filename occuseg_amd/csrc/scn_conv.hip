@@ -2943,6 +2943,8 @@ struct DwOut {
   float *dW, *part;
   int64_t elems;  // K * Ci * Co
   int ldi, ldd;   // leading dimensions (floats) of `in` / `dout` when they are column slices of wider tensors (k_dw_tile only)
+  unsigned *tickets;  // k_dw_tile<.., DET = 1> only: arrival counters of the in-kernel fixed-order reduction (zero before and after)
+  int grp;            // ... and its group size: 16, or 32 when a list has more than 256 slices (one list only: NetworkInNetwork)
   __device__ __forceinline__ void add(int64_t slot, int64_t idx, float v) const {
     if (part) part[slot * elems + idx] = v;
     else unsafeAtomicAdd(dW + idx, v);
@@ -2962,6 +2964,30 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Few elements, many slots (the stem: 27 x 3 x 64 floats in up to 1,024 slots -- five workgroups of k_dw_reduce walked 21 MB, 0.24 ms):
+// one WAVE per float4, lane l adds slots l, l + 64, ... in that order and the 64 lane sums meet in a butterfly -- an order
+// fixed by lane numbers, not by timing.
+__global__ void __launch_bounds__(256)
+    k_dw_reduce_wide(const float *__restrict__ part, float *__restrict__ dW, int64_t elems4, int nslots) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= elems4) return;
+  const int lane = threadIdx.x & 63;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = lane; s < nslots; s += 64) {
+    const float4 b = ((const float4 *)part)[(int64_t)s * elems4 + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    a.x += __shfl_xor(a.x, m); a.y += __shfl_xor(a.y, m); a.z += __shfl_xor(a.z, m); a.w += __shfl_xor(a.w, m);
+  }
+  if (lane == 0) {
+    float4 d = ((float4 *)dW)[i];
+    d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+    ((float4 *)dW)[i] = d;
+  }
+}
+
 __global__ void __launch_bounds__(256)
     k_dw_reduce1(const float *__restrict__ part, float *__restrict__ dW, int64_t elems, int nslots) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -2972,7 +2998,16 @@ __global__ void __launch_bounds__(256)
 }
 
 // block: 4 waves as 2x2; wave owns TI x TJ 16x16 tiles; block tile CIB x COB.
-template <int TI, int TJ, int PS = 32, int ABL = 0>
+// DET = 1 (round 4): bitwise reproducible WITHOUT a memset and a second launch.  Every workgroup stores its 32 TI x 32 TJ block of
+// partial sums to a slot of its own (write-through), then draws a ticket; the slices of one (offset, plane block) form groups of
+// DW_GROUP consecutive slices (2 DW_GROUP when a list has more than DW_GROUP^2 slices: the single list of a NetworkInNetwork layer): the last workgroup of a group to arrive adds the group's slots in slice order and leaves the sum
+// in the group's first slot, the last GROUP of the (offset, plane block) to finish adds the group sums in group order and adds
+// the result to dW -- two levels, so that no workgroup reads more than DW_GROUP slots (one workgroup adding all ~250 slices of a
+// level-0 list would be a 60 us tail behind a 300 us launch).  The order of every addition is fixed by the slice numbers, not by
+// who arrives when.  Tickets go back to zero.  The two-launch form (memset, k_dw_tile, k_dw_reduce) cost 0.8 ms per train step,
+// almost all of it the 74 extra launches.
+constexpr int DW_GROUP = 16;
+template <int TI, int TJ, int PS = 32, int ABL = 0, int DET = 0>
 __global__ void __launch_bounds__(256)
     k_dw_tile(const float *__restrict__ in, const float *__restrict__ dout, DwOut dwo,
               const int2 *__restrict__ rules, const int32_t *__restrict__ counts, int64_t stride,
@@ -3123,6 +3158,87 @@ __global__ void __launch_bounds__(256)
   stage();
   __syncthreads();
   compute();
+  if (DET) {
+    // slot of (slice c, offset k, plane block t): 256 lanes x TI TJ float4, lane-major per accumulator (coalesced 16-byte stores)
+    constexpr int NA = TI * TJ;
+    const int grp = dwo.grp;
+    constexpr unsigned SLOT_B = 256u * NA * 16u;
+    __syncthreads();  // (in_t is read by compute() above and reused for the ticket below)
+    int *tk = (int *)in_t;
+    const int64_t kt = (int64_t)k * nt + t;
+    auto slot_rsrc = [&](int cc) __attribute__((always_inline)) {
+      return __builtin_amdgcn_make_buffer_rsrc((void *)((char *)dwo.part + (((int64_t)cc * K + k) * nt + t) * (int64_t)SLOT_B), 0, (int)SLOT_B, 0x00020000);
+    };
+    auto put = [&](int cc, const floatx4 *v) __attribute__((always_inline)) {
+      const __amdgpu_buffer_rsrc_t rs = slot_rsrc(cc);
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[a].x), __float_as_uint(v[a].y), __float_as_uint(v[a].z), __float_as_uint(v[a].w)}, rs,
+                                               ((unsigned)a * 256u + (unsigned)tid) * 16u, 0, 16 /* sc1 */);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // sum of `n` slots first, first + step, ... in that order (four slots' loads in flight at a time)
+    auto gather = [&](int first, int step, int n, floatx4 *sum) __attribute__((always_inline)) {
+      for (int j0 = 0; j0 < n; j0 += 4) {
+        u32x4 b[4][NA];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const __amdgpu_buffer_rsrc_t rs = slot_rsrc(first + min(j0 + u, n - 1) * step);
+#pragma unroll
+          for (int a = 0; a < NA; ++a) b[u][a] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((unsigned)a * 256u + (unsigned)tid) * 16u, 0, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u < n) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+              const floatx4 bf = floatx4{__uint_as_float(b[u][a].x), __uint_as_float(b[u][a].y), __uint_as_float(b[u][a].z), __uint_as_float(b[u][a].w)};
+              sum[a] = (j0 + u == 0) ? bf : sum[a] + bf;
+            }
+          }
+      }
+    };
+    auto arrive = [&](unsigned *word, int expect) __attribute__((always_inline)) {
+      __syncthreads();  // (every wave has drained its stores)
+      if (tid == 0) tk[0] = (int)__hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const bool last = __builtin_amdgcn_readfirstlane(tk[0]) == expect - 1;
+      __syncthreads();
+      if (last && tid == 0) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return last;
+    };
+    floatx4 v[NA];
+#pragma unroll
+    for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < TJ; ++tb) v[ta * TJ + tb] = acc[ta][tb];
+    const int n_k = (count + per - 1) / per;        // slices of this list that hold pairs (all of them arrive here)
+    const int g = c / grp, ng = (n_k + grp - 1) / grp;
+    if (n_k > 1) {  // (a list of ONE slice -- the coarse levels -- has nothing to add up: its workgroup updates dW itself)
+    put(c, v);
+    if (!arrive(dwo.tickets + kt * grp + g, min(grp, n_k - g * grp))) return;
+    asm volatile("" ::: "memory");
+    gather(g * grp, 1, min(grp, n_k - g * grp), v);
+    }
+    if (ng > 1) {
+      put(g * grp, v);  // (the group's first slot has been read: it now holds the group's sum)
+      if (!arrive(dwo.tickets + (int64_t)K * nt * grp + kt, ng)) return;
+      asm volatile("" ::: "memory");
+      gather(0, grp, ng, v);
+    }
+    // dW += the sum: this workgroup is the only one of the launch that touches the block
+#pragma unroll
+    for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < TJ; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = ci0 + (wi * TI + ta) * 16 + 4 * lq + r;
+          const int co = co0 + (wj * TJ + tb) * 16 + li;
+          dwo.dW[((int64_t)k * Ci + ci) * Co + co] += v[ta * TJ + tb][r];
+        }
+    return;
+  }
   // D[row = ci][col = co]: lane holds rows 4 lq + r, column li
 #pragma unroll
   for (int ta = 0; ta < TI; ++ta)
@@ -3532,6 +3648,7 @@ SCN_KNOB g_conv_sk_min_loss = 30;   // tuning key 18: ... and only where one wor
                                     // schedule (tools/ab_stream_k.py, profiles/r04_ab_stream_k.txt): +12 % at 2.70 rounds, +4-6 % at 2.83,
                                     // +1-3 % at 4.59; a launch of whole rounds would pay ~1-2 % for nothing.  0: every eligible launch (A/B)
 SCN_KNOB g_conv_sk_min_items = 1024;  // tuning key 17: ... for launches with at least this many (tile, column block) items
+SCN_KNOB g_dw_fused = 1;          // tuning key 23: 0 = deterministic dWeight as memset + kernel + k_dw_reduce even when scn_conv_dweight is handed dw_state (A/B)
 SCN_KNOB g_conv_split_fused = 1;  // tuning key 19: 0 = the partial tiles of a split launch are added by a second launch (k_split_reduce) even
                                   // when the caller hands in a control block (A/B)
 SCN_KNOB g_conv_wide = 0;       // tuning key 2: 1 = use the 8-wave 128-plane configuration when Co % 128 == 0
@@ -3919,6 +4036,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 17 && value >= 1) { g_conv_sk_min_items = value; return 0; }
   if (key == 18 && value >= 0 && value <= 1000) { g_conv_sk_min_loss = value; return 0; }
   if (key == 19) { g_conv_split_fused = value; return 0; }
+  if (key == 23) { g_dw_fused = value; return 0; }
   if (key == 21) { g_conv_expand_persist = value; return 0; }
   if (key == 22) { g_conv_sk_static = value; return 0; }
   if (key == 20) { SCN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_prio_dev), &value, sizeof(int))); return 0; }
@@ -4131,6 +4249,8 @@ static int dw_pairs_per_wg(int K, int64_t stride, int Ci, int Co) {
     int64_t p2 = (stride * cb / 2048 + 63) / 64 * 64;
     if (p2 < 512) p2 = 512;
     if (p2 < per) per = (int)p2;
+    // (at most 1024 slices: what the in-kernel fixed-order reduction's two levels of 32 cover)
+    if ((stride + per - 1) / per > 1024) per = (int)(((stride + 1023) / 1024 + 63) / 64 * 64);
   }
   return per;
 }
@@ -4158,7 +4278,7 @@ size_t scn_conv_dweight_workspace_bytes(int K, int64_t stride, int64_t n_in, int
 int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_t *rules,
                      const int32_t *counts, const int32_t *bases, int K, int64_t stride, int in_col, int out_col,
                      int64_t n_in, int64_t n_dout, int Ci, int Co, int64_t ld_in, int64_t ld_dout, void *workspace,
-                     size_t workspace_bytes, void *stream_) {
+                     size_t workspace_bytes, void *dw_state, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   if (ld_in == 0) ld_in = Ci;
   if (ld_dout == 0) ld_dout = Co;
@@ -4170,14 +4290,28 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
   // deterministic mode: per-workgroup partial sums in the (zeroed) workspace, added to dW in a fixed order afterwards
   const int64_t elems = (int64_t)K * Ci * Co;
   const int64_t nslots = workspace ? dw_slots(K, stride, n_dout, Ci, Co, bases != nullptr, n_in) : 0;
+  const bool huge_ = n_in * ld_in * 4 >= ((int64_t)1 << 32) || n_dout * ld_dout * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
+                     n_dout >= (1 << 24) || stride >= (1 << 28);
+  // the fixed-order reduction INSIDE k_dw_tile (dw_state: its tickets): no memset, no second launch
+  bool fused = false;
+  int grp = DW_GROUP;
+  if (workspace && dw_state && g_dw_fused && Ci % 32 == 0 && Co % 32 == 0 && !huge_ && !(g_dw_direct && Ci % 64 == 0 && Co % 64 == 0)) {
+    const int per = dw_pairs_per_wg(K, stride, Ci, Co);
+    const int64_t gx = (stride + per - 1) / per;
+    const int64_t nt = (Ci % 64 == 0 && Co % 64 == 0) ? (int64_t)(Ci / 64) * (Co / 64) : (int64_t)(Ci / 32) * (Co / 32);
+    grp = gx <= DW_GROUP * DW_GROUP ? DW_GROUP : 2 * DW_GROUP;
+    fused = gx <= (int64_t)grp * grp && (int64_t)K * nt * (grp + 1) * 4 <= (int64_t)SCN_DW_STATE_BYTES;
+  }
   if (workspace) {
     SCN_REQUIRE(workspace_bytes >= (size_t)nslots * (size_t)elems * 4, "scn_conv_dweight: workspace smaller than scn_conv_dweight_workspace_bytes()");
-    SCN_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)nslots * (size_t)elems * 4, stream));
+    if (!fused) SCN_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)nslots * (size_t)elems * 4, stream));
   }
-  const DwOut dwo{dW, (float *)workspace, elems, (int)ld_in, (int)ld_dout};
+  const DwOut dwo{dW, (float *)workspace, elems, (int)ld_in, (int)ld_dout, fused ? (unsigned *)dw_state : nullptr, grp};
   auto finish = [&]() -> int {
-    if (workspace) {
-      if (elems % 4 == 0) {
+    if (workspace && !fused) {
+      if (elems % 4 == 0 && nslots >= 128 && elems / 4 <= 65536) {
+        k_dw_reduce_wide<<<(unsigned)((elems / 4 + 3) / 4), 256, 0, stream>>>((const float *)workspace, dW, elems / 4, (int)nslots);
+      } else if (elems % 4 == 0) {
         int64_t g = (elems / 4 + 255) / 256;
         if (g > 4096) g = 4096;
         k_dw_reduce<<<(unsigned)g, 256, 0, stream>>>((const float *)workspace, dW, elems / 4, (int)nslots);
@@ -4216,10 +4350,16 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
         k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col + 2, Ci, Co, gx, in_bytes, do_bytes, -K);
       else
 #endif
+      if (fused)
+        k_dw_tile<2, 2, 64, 0, 1><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+      else
         k_dw_tile<2, 2, 64><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
     } else {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 32) * (Co / 32));
-      k_dw_tile<1, 1, 64><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+      if (fused)
+        k_dw_tile<1, 1, 64, 0, 1><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+      else
+        k_dw_tile<1, 1, 64><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
     }
     SCN_CHECK_LAUNCH();
     return finish();

@@ -701,3 +701,78 @@ def test_deconvolution_into_and_out_of_a_joined_tensor(gpu, p, n, extent):
                                         _d_x_add=add)
         outs.append(dx)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("ci,co,n,extent", [(64, 64, 200000, 110), (128, 64, 60000, 70), (96, 32, 9000, 34), (64, 128, 700, 12)])
+def test_dweight_fixed_order_inside_the_kernel(gpu, ci, co, n, extent):
+    """scn_conv_dweight with a workspace AND dw_state: every workgroup's block of partial sums goes to its own slot, the last
+    workgroup of each group of 16 slices adds the group, the last group adds the groups and updates dW -- no float atomics, no
+    memset, no second launch.  Against the float64 oracle; bitwise equal run to run and with a delay that changes which
+    workgroup arrives last; the two-launch form (no dw_state) and the atomic form agree at 1e-5; the ticket block is zero
+    again after every launch; a dW that is not zero is added to.  (~190 k sites: ~90 slices per list = 6 groups, two levels;
+    ~57 k sites: 2 groups; 9,000 and 700 sites: one group, no second level; 96 -> 32: the 32-plane blocks.)"""
+    from occuseg_amd import SCN, _lib
+    from occuseg_amd.SCN import ptr, stream, check
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu, seed=31, n=n, batch=2, extent=extent)
+    rb = m.getSubmanifoldRuleBook(size, F3)
+    rules, _ = R.submanifold_rules(grid)
+    N = grid.n
+    rng = np.random.default_rng(ci + co)
+    x = rng.normal(size=(N, ci)).astype(np.float32)
+    dy = rng.normal(size=(N, co)).astype(np.float32)
+    w = np.zeros((27, ci, co), np.float32)
+    _, want, _ = A.conv_backward(x, dy, w, rules, dtype=np.float64)
+    lib = _lib.load()
+    xt, dyt = _t(x, gpu), _t(dy, gpu)
+    wsb = lib.scn_conv_dweight_workspace_bytes(27, rb.stride, N, N, ci, co, 1)
+    state = torch.zeros(_lib.DW_STATE_BYTES, dtype=torch.uint8, device=gpu)
+
+    def run(mode, dw0=None, poison=False):
+        dw = torch.zeros(27, ci, co, device=gpu) if dw0 is None else dw0.clone()
+        ws = torch.empty(wsb, dtype=torch.uint8, device=gpu) if mode else None
+        if poison and ws is not None:
+            ws.fill_(0x7f)  # (the fused form never reads a slot it has not written: NaN-ish garbage must not show)
+        check(lib.scn_conv_dweight(ptr(xt), ptr(dyt), ptr(dw), ptr(rb.rules), ptr(rb.counts), ptr(rb.bases.get(1)), 27,
+                                   rb.stride, 0, 1, N, N, ci, co, 0, 0, ptr(ws), wsb if mode else 0,
+                                   ptr(state) if mode == 2 else None, stream()))
+        return dw
+
+    fused = run(2, poison=True)
+    assert int(state.view(torch.int32).abs().sum().item()) == 0
+    assert_close(fused.cpu().numpy(), want, "dW, fixed order inside the kernel", rel=1e-4)
+    for _ in range(3):
+        assert torch.equal(run(2, poison=True), fused)
+        assert int(state.view(torch.int32).abs().sum().item()) == 0
+    two = run(1)
+    atomic = run(0)
+    assert_close(two.cpu().numpy(), fused.cpu().numpy(), "two-launch against in-kernel", rel=1e-5)
+    assert_close(atomic.cpu().numpy(), fused.cpu().numpy(), "atomic against in-kernel", rel=1e-5)
+    base = torch.randn(27, ci, co, device=gpu)
+    assert_close(run(2, dw0=base).cpu().numpy(), (base + fused).cpu().numpy(), "dW += ...", rel=1e-6)
+
+
+def test_dweight_fixed_order_one_list_many_slices(gpu):
+    """NetworkInNetwork's dWeight is ONE list (the identity rulebook) cut into up to 1024 slices: groups of 32.  600,000 rows,
+    128 -> 64: 938 slices; against x^T dy in float64, bitwise equal run to run, tickets zero afterwards."""
+    from occuseg_amd import SCN, _lib
+    from occuseg_amd.SCN import ptr, stream, check
+    n, ci, co = 600000, 128, 64
+    torch.manual_seed(3)
+    x, dy = torch.randn(n, ci, device=gpu), torch.randn(n, co, device=gpu)
+    rb = SCN._identity_rulebook(n, gpu)
+    lib = _lib.load()
+    wsb = lib.scn_conv_dweight_workspace_bytes(1, rb.stride, n, n, ci, co, int(rb.bases.get(1) is not None))
+    assert wsb // (ci * co * 4) > 256  # (more slices than two levels of 16 cover)
+    state = torch.zeros(_lib.DW_STATE_BYTES, dtype=torch.uint8, device=gpu)
+    outs = []
+    for _ in range(3):
+        dw = torch.zeros(ci, co, device=gpu)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=gpu).fill_(0x7f)
+        check(lib.scn_conv_dweight(ptr(x), ptr(dy), ptr(dw), ptr(rb.rules), ptr(rb.counts), ptr(rb.bases.get(1)), 1, rb.stride,
+                                   0, 1, n, n, ci, co, 0, 0, ptr(ws), wsb, ptr(state), stream()))
+        assert int(state.view(torch.int32).abs().sum().item()) == 0
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    want = (x.double().t() @ dy.double()).cpu().numpy()
+    assert_close(outs[0].cpu().numpy(), want, "NiN dW, fixed order inside the kernel", rel=1e-4)

@@ -156,8 +156,9 @@ def test_colstats_follow_the_features_assignment(gpu):
 
 
 def test_deterministic_mode_train_steps_are_bitwise_equal(gpu):
-    """SCN.DETERMINISTIC_DW: every dWeight launch adds its workgroups' partial sums in a fixed order (workspace + reduce)
-    instead of with float atomics.  Forward, dInput and batch norm are deterministic anyway, so two runs of three whole
+    """The DEFAULT (SCN.DETERMINISTIC_DW, on since round 4): every dWeight launch adds its workgroups' partial sums in a fixed
+    order -- inside the kernel for k_dw_tile (slots, arrival tickets, two levels), memset + kernel + reduction for the stem and
+    the narrow fallbacks -- instead of with float atomics.  Forward, dInput and batch norm are deterministic anyway, so two runs of three whole
     train steps (fused Adam included) from the same seed end in bitwise-equal parameters -- which the reference's own
     backward pass cannot do (float atomics, sparseconvnet/SCN/CUDA/Convolution.cu:749) -- and the gradients equal the default
     mode's at 1e-5.  m64 levels 0-1 at 2 x 40k sites (k_dw_tile over 64-plane blocks, the stem's k_dw_rows, NiN) and
@@ -166,8 +167,11 @@ def test_deterministic_mode_train_steps_are_bitwise_equal(gpu):
     from occuseg_amd import SCN, dp, scenes
     scn = occuseg_amd.install()
 
+    assert SCN.DETERMINISTIC_DW is True  # (no switch: the default)
+
     def run(m, levels, sites, deterministic, steps=3):
-        SCN.DETERMINISTIC_DW = deterministic
+        if not deterministic:
+            SCN.DETERMINISTIC_DW = False
         torch.manual_seed(77)
         net = _net(scn, m, levels).to(gpu)
         coords, feats = scenes.batch([1000, 1001], target_sites=sites)
@@ -185,6 +189,7 @@ def test_deterministic_mode_train_steps_are_bitwise_equal(gpu):
                 opt.step()
         finally:
             bucket.close()
+            SCN.DETERMINISTIC_DW = True
         return first, [p.detach().clone() for p in net.parameters()]
 
     try:
@@ -196,4 +201,4 @@ def test_deterministic_mode_train_steps_are_bitwise_equal(gpu):
             g0, _ = run(m, levels, sites, False, steps=1)
             assert_close(g1.cpu().numpy(), g0.cpu().numpy(), "deterministic against atomic gradients", rel=1e-5)
     finally:
-        SCN.DETERMINISTIC_DW = False
+        SCN.DETERMINISTIC_DW = True

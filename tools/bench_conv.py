@@ -73,7 +73,7 @@ def main():
                     dy = torch.randn(n, co, device=dev)
                     dw = torch.zeros_like(w)
                     ms = timeit(lambda: _lib.check(lib.scn_conv_dweight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
-                                rb.rules.data_ptr(), rb.counts.data_ptr(), None, 27, rb.stride, 0, 1, n, n, ci, co, 0, 0, None, 0, _lib.stream())))
+                                rb.rules.data_ptr(), rb.counts.data_ptr(), None, 27, rb.stride, 0, 1, n, n, ci, co, 0, 0, None, 0, None, _lib.stream())))
                     line += "  dW[%d] %.3f ms %.1f TF" % (dv, ms, flops / ms / 1e9)
                 lib.scn_set_tuning(6, 0)
                 lib.scn_set_tuning(12, 1)

@@ -53,7 +53,7 @@ def main():
 
             def dweight():
                 _lib.check(lib.scn_conv_dweight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), rb.rules.data_ptr(),
-                                                rb.counts.data_ptr(), None, 27, rb.stride, 0, 1, n, n, ci, co, 0, 0, None, 0, _lib.stream()))
+                                                rb.counts.data_ptr(), None, 27, rb.stride, 0, 1, n, n, ci, co, 0, 0, None, 0, None, _lib.stream()))
             conv()
             line = "L%d %d->%d:" % (lv, ci, co)
             for name, fn in (("conv", conv), ("dW", dweight)):

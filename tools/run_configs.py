@@ -78,7 +78,7 @@ for name, c in (("cfg5a_bernoulli160", scenes.bernoulli_grid(160, 0.488, 7, offs
     lib = occuseg_amd._lib.load()
     t_dw = timeit(lambda: occuseg_amd._lib.check(lib.scn_conv_dweight(
         x.data_ptr(), dy.data_ptr(), gw.data_ptr(), rb.rules.data_ptr(), rb.counts.data_ptr(), None, 27, rb.stride, 0, 1,
-        n, n, 128, 128, 0, 0, None, 0, occuseg_amd._lib.stream())), 10, 3)
+        n, n, 128, 128, 0, 0, None, 0, None, occuseg_amd._lib.stream())), 10, 3)
     flops = 2.0 * R * 128 * 128
     fb = 4.0 * (R * 128 + n * 128) + 8.0 * R + 4.0 * 27 * 128 * 128
     wb = 4.0 * R * 256 + 8.0 * R + 4.0 * 27 * 128 * 128
