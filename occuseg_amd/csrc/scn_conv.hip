@@ -3648,6 +3648,7 @@ SCN_KNOB g_conv_sk_min_loss = 30;   // tuning key 18: ... and only where one wor
                                     // schedule (tools/ab_stream_k.py, profiles/r04_ab_stream_k.txt): +12 % at 2.70 rounds, +4-6 % at 2.83,
                                     // +1-3 % at 4.59; a launch of whole rounds would pay ~1-2 % for nothing.  0: every eligible launch (A/B)
 SCN_KNOB g_conv_sk_min_items = 1024;  // tuning key 17: ... for launches with at least this many (tile, column block) items
+SCN_KNOB g_dw_k8 = 1;             // tuning key 24: 0 = strided rulebooks' dWeight cut into as many slices as a submanifold rulebook's (A/B)
 SCN_KNOB g_dw_fused = 1;          // tuning key 23: 0 = deterministic dWeight as memset + kernel + k_dw_reduce even when scn_conv_dweight is handed dw_state (A/B)
 SCN_KNOB g_conv_split_fused = 1;  // tuning key 19: 0 = the partial tiles of a split launch are added by a second launch (k_split_reduce) even
                                   // when the caller hands in a control block (A/B)
@@ -4037,6 +4038,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 18 && value >= 0 && value <= 1000) { g_conv_sk_min_loss = value; return 0; }
   if (key == 19) { g_conv_split_fused = value; return 0; }
   if (key == 23) { g_dw_fused = value; return 0; }
+  if (key == 24) { g_dw_k8 = value; return 0; }
   if (key == 21) { g_conv_expand_persist = value; return 0; }
   if (key == 22) { g_conv_sk_static = value; return 0; }
   if (key == 20) { SCN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_prio_dev), &value, sizeof(int))); return 0; }
@@ -4251,6 +4253,17 @@ static int dw_pairs_per_wg(int K, int64_t stride, int Ci, int Co) {
     if (p2 < per) per = (int)p2;
     // (at most 1024 slices: what the in-kernel fixed-order reduction's two levels of 32 cover)
     if ((stride + per - 1) / per > 1024) per = (int)(((stride + 1023) / 1024 + 63) / 64 * 64);
+  } else if (K <= 8 && g_dw_k8) {
+    // the lists of a strided rulebook PARTITION the fine sites (each ~ stride / K pairs): cut like a submanifold rulebook, whose
+    // longest list has `stride` pairs, their workgroups got ~300 pairs = 5 steps between a prologue and 4,096 atomics (the 16
+    // launches of this kind in a train step ran at 0.55 of the peak).  ~2,300 workgroups of >= 512 pairs instead.
+    const int64_t cb = (Ci % 64 == 0 && Co % 64 == 0) ? (int64_t)(Ci / 64) * (Co / 64) : (int64_t)(Ci / 32) * (Co / 32);
+    int64_t gx = (2304 + K * cb - 1) / (K * cb);
+    const int64_t most = stride / K / 512, least = (768 + K * cb - 1) / (K * cb);  // (>= 512 pairs each, but one round of the chip at least)
+    if (gx > most) gx = most;
+    if (gx < least) gx = least;
+    const int64_t p2 = ((stride + gx - 1) / gx + 63) / 64 * 64;
+    if (p2 > per) per = (int)(p2 < (1 << 24) ? p2 : (1 << 24));  // (never MORE slices than before)
   }
   return per;
 }
