@@ -118,8 +118,9 @@ PREBUILD = True
 # against 2.45 ms per batch -- the build is bound by its kernels and its ~185 launches, not by the read-backs.  But with ONE
 # early read-back the host issues the rest of the build and the forward pass behind it without waiting: the forward-only
 # configuration, which builds its rulebooks in the forward pass and is bound by host time, gains 4-8 % (cfg2 4.56 -> 4.18,
-# 4.23 -> 4.06 ms).  "auto" (default): the chain for builds inside a forward pass, per-scale read-backs for builds that
-# prefetch_input runs on its side stream (there the host has nothing else to issue and the device time counts).
+# 4.23 -> 4.06 ms).  "auto" (default): the chain for builds inside a forward pass or under torch.no_grad(), per-scale read-backs
+# for builds that prefetch_input runs on its side stream beside a backward pass (there the host has nothing else to issue and
+# the device time counts).
 _GC = os.environ.get("SCN_GRID_CHAIN", "auto")
 GRID_CHAIN = True if _GC == "1" else False if _GC == "0" else "auto"
 _GRID_CHAIN_MAX = 12
@@ -321,7 +322,9 @@ class Metadata_3(object):
         c = coords.to(device, non_blocking=True).contiguous()
         P = c.size(0)
         old_plan = _PLANS.get(key, [])
-        chain = GRID_CHAIN if GRID_CHAIN != "auto" else not _IN_PREFETCH[0]
+        # auto: inside a forward pass, and in a prefetch issued under torch.no_grad() (a serving loop: the same host thread
+        # issues the forward pass, nothing hides a read-back); not in a prefetch beside a backward pass
+        chain = GRID_CHAIN if GRID_CHAIN != "auto" else (not _IN_PREFETCH[0] or not torch.is_grad_enabled())
         self._chain(c, key, old_plan if PREBUILD and chain else [])
         g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P,
                                                              n_known=self._chain_counts.get(key))
