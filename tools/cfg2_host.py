@@ -40,3 +40,4 @@ with torch.no_grad():
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
     st.sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
+    st.sort_stats("cumulative").print_stats(30)

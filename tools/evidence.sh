@@ -37,7 +37,9 @@ python3 tools/mfma_probe.py > $E/mfma_probe.txt 2>&1
 python3 tools/bench_conv.py --levels 0,1 --variants 4 --extra-lds 0,2000,15200 > $E/occupancy_probe.txt 2>&1
 python3 tools/ab_step.py DW_SIDE_STREAM=0,1 > $E/ab_dw_side_stream.txt 2>&1
 python3 tools/ab_step.py DETERMINISTIC_DW=0,1 > $E/ab_deterministic_dw.txt 2>&1
-python3 tools/ab_step.py STREAM_K=0,1 > $E/ab_stream_k_step.txt 2>&1
+python3 tools/ab_step.py STREAM_K=0,1 > $E/ab_stream_k_step.txt 2>&1   # (off against the default: the forward launches)
+python3 tools/ab_dw_det.py > $E/ab_dw_det_layers.txt 2>&1
+for c in 0 1 0 1; do SCN_GRID_CHAIN=$c python3 tools/rules_alone.py 20; done > $E/rules_alone.txt 2>&1
 python3 tools/ab_step.py SPLIT_FUSED=0,1 > $E/ab_split_fused.txt 2>&1
 python3 tools/ab_step.py tune21=0,1 > $E/ab_expand_persistent_step.txt 2>&1
 python3 tools/ab_stream_k.py --levels 0,1 --sk 0,1,0,1 > $E/ab_stream_k_layers.txt 2>&1
