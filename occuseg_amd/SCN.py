@@ -143,6 +143,18 @@ def _sk_state(device, stream_handle=None):
     return t
 
 
+_SK_WANTED = set()   # (lists of the rulebook, output column) of the stream-K launches seen so far
+_SK_MIN_TILES = 512  # (k_conv_tile4 takes launches of >= 512 tiles)
+
+
+def _tile_passes(rb, out_col, n_out):
+    lib = _lib_()
+    passes = torch.empty(lib.scn_tile_passes_bytes(n_out) // 4, dtype=torch.int32, device=rb.rules.device)
+    check(lib.scn_tile_passes(ptr(rb.bases[out_col]), rb.K, n_out, ptr(passes), stream()))
+    rb.passes[out_col] = passes
+    return passes
+
+
 def stream_k_gave_up():
     """True if a stream-K launch of this process ever stopped waiting for another workgroup's partial tile (word 9 of the
     control block; a bounded wait, so that a broken launch cannot hang the GPU): its result is then wrong.  Never observed;
@@ -444,14 +456,12 @@ class Metadata_3(object):
                                  ptr(bases), stream()))
         rb.bases[out_col] = bases
         rb.n_rows[out_col] = n_out
-        # pass prefix of the 128-row tiles (scn_conv_forward's tile_passes): what a stream-K launch cuts into equal slices
-        n_tiles = (n_out + 127) // 128
-        # (three small launches per rulebook column: only when somebody will use them -- with stream-K on the forward launches
-        #  only, that is the column the forward direction writes)
-        if STREAM_K and rb.K > 1 and n_tiles >= 128 and (out_col == 1 or not STREAM_K_FWD_ONLY):
-            passes = torch.empty(lib.scn_tile_passes_bytes(n_out) // 4, dtype=torch.int32, device=bases.device)
-            check(lib.scn_tile_passes(ptr(bases), rb.K, n_out, ptr(passes), stream()))
-            rb.passes[out_col] = passes
+        # pass prefix of the 128-row tiles (scn_conv_forward's tile_passes): what a stream-K launch cuts into equal slices.
+        # Three small launches per rulebook column: built with the rulebook only when a launch of the big gather-mm kernel has
+        # asked for the tables of such a rulebook before (_SK_WANTED; the first time _conv builds them itself) -- a network
+        # whose planes keep it off that kernel (the m32 UNet of the forward-only configuration) never pays for them.
+        if STREAM_K and (rb.K, out_col) in _SK_WANTED and (n_out + 127) // 128 >= _SK_MIN_TILES:
+            _tile_passes(rb, out_col, n_out)
 
     def getSubmanifoldRuleBook(self, spatialSize, filterSize, dilated_rate=1, _defer=False):
         """cache key (spatialSize, filterSize) as sparseconvnet/SCN/Metadata/Metadata.cpp:504-529"""
@@ -908,11 +918,17 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
         if mk[1] != _WEPOCH_AT_INPUT[0]:
             mk[0].record(torch.cuda.current_stream(inp.device))
             mk[1] = _WEPOCH_AT_INPUT[0]
+    passes = None
+    if kind == 4 and STREAM_K and not (STREAM_K_FWD_ONLY and w_transposed) and K > 1:
+        passes = rb.passes.get(out_col)
+        if passes is None and (n_out + 127) // 128 >= _SK_MIN_TILES:
+            _SK_WANTED.add((K, out_col))  # (from the next batch on the tables come with the rulebook)
+            passes = _tile_passes(rb, out_col, n_out)
     ev = _prof_begin()
     check(lib.scn_conv_forward(ptr(inp), ptr(out), ptr(weight), int(w_transposed), int(w_reverse),
                                ptr(bias) if bias is not None and bias.numel() else None, ptr(residual), ptr(cstats),
                                ctypes.byref(bnb) if bnb is not None else None, ptr(rb.rules), ptr(rb.bases[out_col]),
-                               ptr(rb.passes.get(out_col)) if STREAM_K and not (STREAM_K_FWD_ONLY and w_transposed) else None,
+                               ptr(passes),
                                ptr(rb.counts), K, rb.stride,
                                in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ld_in, ld_out, ptr(wpack), ready, ptr(ws), ws_bytes,

@@ -3178,17 +3178,18 @@ __global__ void __launch_bounds__(256)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // sum of `n` slots first, first + step, ... in that order (four slots' loads in flight at a time)
+    constexpr int GB = NA <= 4 ? 4 : 1;  // slots in flight (64 registers' worth of loads)
     auto gather = [&](int first, int step, int n, floatx4 *sum) __attribute__((always_inline)) {
-      for (int j0 = 0; j0 < n; j0 += 4) {
-        u32x4 b[4][NA];
+      for (int j0 = 0; j0 < n; j0 += GB) {
+        u32x4 b[GB][NA];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GB; ++u) {
           const __amdgpu_buffer_rsrc_t rs = slot_rsrc(first + min(j0 + u, n - 1) * step);
 #pragma unroll
           for (int a = 0; a < NA; ++a) b[u][a] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((unsigned)a * 256u + (unsigned)tid) * 16u, 0, 16 /* sc1 */);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GB; ++u)
           if (j0 + u < n) {
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
@@ -3648,6 +3649,7 @@ SCN_KNOB g_conv_sk_min_loss = 30;   // tuning key 18: ... and only where one wor
                                     // schedule (tools/ab_stream_k.py, profiles/r04_ab_stream_k.txt): +12 % at 2.70 rounds, +4-6 % at 2.83,
                                     // +1-3 % at 4.59; a launch of whole rounds would pay ~1-2 % for nothing.  0: every eligible launch (A/B)
 SCN_KNOB g_conv_sk_min_items = 1024;  // tuning key 17: ... for launches with at least this many (tile, column block) items
+SCN_KNOB g_dw_big = 0;            // tuning key 25: 1 = k_dw_tile with 128 x 128 blocks where both plane counts are multiples of 128 (A/B)
 SCN_KNOB g_dw_k8 = 1;             // tuning key 24: 0 = strided rulebooks' dWeight cut into as many slices as a submanifold rulebook's (A/B)
 SCN_KNOB g_dw_fused = 1;          // tuning key 23: 0 = deterministic dWeight as memset + kernel + k_dw_reduce even when scn_conv_dweight is handed dw_state (A/B)
 SCN_KNOB g_conv_split_fused = 1;  // tuning key 19: 0 = the partial tiles of a split launch are added by a second launch (k_split_reduce) even
@@ -4039,6 +4041,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 19) { g_conv_split_fused = value; return 0; }
   if (key == 23) { g_dw_fused = value; return 0; }
   if (key == 24) { g_dw_k8 = value; return 0; }
+  if (key == 25) { g_dw_big = value; return 0; }
   if (key == 21) { g_conv_expand_persist = value; return 0; }
   if (key == 22) { g_conv_sk_static = value; return 0; }
   if (key == 20) { SCN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_prio_dev), &value, sizeof(int))); return 0; }
@@ -4306,12 +4309,14 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
   const bool huge_ = n_in * ld_in * 4 >= ((int64_t)1 << 32) || n_dout * ld_dout * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
                      n_dout >= (1 << 24) || stride >= (1 << 28);
   // the fixed-order reduction INSIDE k_dw_tile (dw_state: its tickets): no memset, no second launch
+  const bool big = g_dw_big && K > 1 && Ci % 128 == 0 && Co % 128 == 0 && Ci % 32 == 0 && !huge_ && g_dw_dbg == 0 && !g_dw_direct;
   bool fused = false;
   int grp = DW_GROUP;
   if (workspace && dw_state && g_dw_fused && Ci % 32 == 0 && Co % 32 == 0 && !huge_ && !(g_dw_direct && Ci % 64 == 0 && Co % 64 == 0)) {
     const int per = dw_pairs_per_wg(K, stride, Ci, Co);
     const int64_t gx = (stride + per - 1) / per;
-    const int64_t nt = (Ci % 64 == 0 && Co % 64 == 0) ? (int64_t)(Ci / 64) * (Co / 64) : (int64_t)(Ci / 32) * (Co / 32);
+    const int64_t nt = big ? (int64_t)(Ci / 128) * (Co / 128)
+                           : (Ci % 64 == 0 && Co % 64 == 0) ? (int64_t)(Ci / 64) * (Co / 64) : (int64_t)(Ci / 32) * (Co / 32);
     grp = gx <= DW_GROUP * DW_GROUP ? DW_GROUP : 2 * DW_GROUP;
     fused = gx <= (int64_t)grp * grp && (int64_t)K * nt * (grp + 1) * 4 <= (int64_t)SCN_DW_STATE_BYTES;
   }
@@ -4344,6 +4349,18 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
     const unsigned in_bytes = (unsigned)((n_in - 1) * ld_in * 4 + Ci * 4), do_bytes = (unsigned)((n_dout - 1) * ld_dout * 4 + Co * 4);
     const int per = dw_pairs_per_wg(K, stride, Ci, Co);  // slices per list
     const int gx = (int)((stride + per - 1) / per);
+#ifdef SCN_TUNING
+    // 128 x 128 blocks (tuning key 25): 64 bytes of operand per MFMA from L2 instead of 128 -- and 192-244 registers, two waves
+    // per SIMD: 0.938 against 0.883 ms at 128 -> 128 on level 1, 0.208 against 0.144 at level 3 (round 4, tools/ab_dw_det.py
+    // with DW_BIG=1).  Not the product's kernel.
+    if (big) {
+      const unsigned nblk = (unsigned)(gx * K * (Ci / 128) * (Co / 128));
+      if (fused)
+        k_dw_tile<4, 4, 32, 0, 1><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+      else
+        k_dw_tile<4, 4, 32><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+    } else
+#endif
     if (Ci % 64 == 0 && Co % 64 == 0) {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 64) * (Co / 64));
       if (g_dw_direct && g_dw_dbg == 0) {

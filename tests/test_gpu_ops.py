@@ -365,11 +365,13 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
         assert part is not None and int(SCN._sk_state(gpu).view(torch.int32).abs().sum().item()) == 0
         return out, sink[0], d_in, part
 
-    before = SCN.STREAM_K
-    SCN.STREAM_K = True  # (hand tile_passes and the control block to every launch)
+    before, before_fwd = SCN.STREAM_K, SCN.STREAM_K_FWD_ONLY
+    SCN.STREAM_K = True  # (hand tile_passes and the control block to every launch ...
+    SCN.STREAM_K_FWD_ONLY = False  # ... the dInput launch too: the default keeps stream-K to the forward direction)
     got = {}
     try:
         got["product"] = run()
+        assert 1 in m.getSubmanifoldRuleBook(size, F3).passes  # (built at first use; the dInput launch walks the same lists)
         lib = _lib.use_tuning_build()
         lib.scn_set_tuning(18, 0)
         got["stream-K, every launch"] = run()
@@ -385,7 +387,7 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
         lib.scn_set_tuning(18, 30)
     finally:
         _lib.use_product_build()
-        SCN.STREAM_K = before
+        SCN.STREAM_K, SCN.STREAM_K_FWD_ONLY = before, before_fwd
     ref = got["one workgroup per tile"]
     for name, g in got.items():
         for i, what in enumerate(("forward", "column statistics", "dInput", "batch-norm-backward sums")):

@@ -155,13 +155,6 @@ def test_tile_passes_prefix_and_stream_k_changes_nothing(gpu):
             rb = md.getSubmanifoldRuleBook(size, f3)
             n = md.getNActive(size)
             n_tiles = (n + 127) // 128
-            assert (1 in rb.passes) == mode  # (built only when somebody will use them)
-            if mode:
-                passes = rb.passes[1].cpu().numpy().astype(np.int64)[:n_tiles + 1]
-                bases = rb.bases[1].cpu().numpy().astype(np.int64)
-                g = np.minimum(np.arange(n_tiles + 1) * 4, bases.shape[1] - 1)
-                per_tile = np.maximum(((bases[:, g[1:]] - bases[:, g[:-1]] + 31) // 32).sum(0), 1)
-                assert np.array_equal(passes, np.concatenate([[0], np.cumsum(per_tile)]))
             torch.manual_seed(0)
             x = torch.randn(n, 64, device=gpu)
             w = torch.randn(27, 64, 64, device=gpu) * 0.05
@@ -171,6 +164,18 @@ def test_tile_passes_prefix_and_stream_k_changes_nothing(gpu):
                 SCN.SubmanifoldConvolution_updateOutput(size, f3, md, x, out, w, torch.empty(0, device=gpu), 1)
                 assert int(SCN._sk_state(gpu).view(torch.int32).abs().sum().item()) == 0
             outs.append(out)
+            # the tables are built when a launch of the big kernel first asks for them (and from then on with the rulebook)
+            assert (1 in rb.passes) == mode and 0 not in rb.passes
+            if mode:
+                assert (27, 1) in SCN._SK_WANTED
+                passes = rb.passes[1].cpu().numpy().astype(np.int64)[:n_tiles + 1]
+                bases = rb.bases[1].cpu().numpy().astype(np.int64)
+                g = np.minimum(np.arange(n_tiles + 1) * 4, bases.shape[1] - 1)
+                per_tile = np.maximum(((bases[:, g[1:]] - bases[:, g[:-1]] + 31) // 32).sum(0), 1)
+                assert np.array_equal(passes, np.concatenate([[0], np.cumsum(per_tile)]))
+                md2 = SCN.Metadata_3()
+                md2.inputLayer(size, torch.from_numpy(coords), 0, 4, gpu)
+                assert 1 in md2.getSubmanifoldRuleBook(size, f3).passes  # (... with the rulebook)
     finally:
         SCN.STREAM_K = before
     assert torch.equal(outs[0], outs[1])

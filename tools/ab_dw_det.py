@@ -12,7 +12,7 @@ from occuseg_amd import SCN, _lib, scenes
 from occuseg_amd.SCN import check, ptr, stream
 
 dev = torch.device("cuda:0")
-lib = _lib.load()
+lib = _lib.use_tuning_build() if os.environ.get("DW_BIG") else _lib.load()
 coords, _ = scenes.batch([1000, 1001, 1002, 1003], 150000)
 md = SCN.Metadata_3()
 size = torch.tensor([4096] * 3)
@@ -28,7 +28,12 @@ for lv, shapes in enumerate((((64, 64), (128, 64)), ((128, 128), (256, 128)), ((
         wsb = lib.scn_conv_dweight_workspace_bytes(27, rb.stride, n, n, ci, co, 1)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         line = "L%d N=%d %d->%d slots %.0f MB:" % (lv, n, ci, co, wsb / 1e6)
-        for name, w, st in (("atomic", None, None), ("in-kernel", ws, state), ("two-launch", ws, None), ("atomic", None, None), ("in-kernel", ws, state)):
+        modes = (("atomic", None, None), ("in-kernel", ws, state), ("two-launch", ws, None), ("atomic", None, None), ("in-kernel", ws, state))
+        if os.environ.get("DW_BIG"):  # 128 x 128 blocks (tuning key 25) against 64 x 64, fixed order in-kernel and atomics
+            modes = (("64 in-kernel", ws, state), ("128 in-kernel", ws, state), ("64 atomic", None, None), ("128 atomic", None, None)) * 2
+        for name, w, st in modes:
+            if os.environ.get("DW_BIG"):
+                lib.scn_set_tuning(25, 1 if name.startswith("128") else 0)
             def call():
                 check(lib.scn_conv_dweight(ptr(x), ptr(dy), ptr(dw), ptr(rb.rules), ptr(rb.counts), ptr(rb.bases.get(1)), 27, rb.stride,
                                            0, 1, n, n, ci, co, 0, 0, ptr(w), wsb if w is not None else 0, ptr(st), stream()))
