@@ -181,3 +181,16 @@ def test_roctx_ranges_wrap_the_boundary_functions():
         SCN._ROCTX[0] = before
         SCN._install_traced(before is not None)
     assert before is not None or SCN.BatchNormalization_updateOutput is plain  # off: not even a wrapper call
+
+
+def test_size_keys_are_cached_per_tensor_and_version():
+    """SCN._size_key: the modules hand the same few size tensors to every call; the tuple is cached per tensor object and
+    follows an in-place change"""
+    import torch
+    from occuseg_amd import SCN
+    t = torch.tensor([4096, 4096, 2048])
+    assert SCN._size_key(t) == (4096, 4096, 2048) and SCN._size_key(t) == (4096, 4096, 2048)
+    assert SCN._SIZE_KEYS[id(t)][0] is t
+    t[2] = 4096
+    assert SCN._size_key(t) == (4096, 4096, 4096)
+    assert SCN._size_key([3, 3, 3]) == (3, 3, 3) and SCN._size_key(torch.tensor([2, 2, 2]) // 2) == (1, 1, 1)

@@ -487,3 +487,28 @@ def test_fused_backward_paths_equal_the_plain_ones(gpu, m, levels, sites):
                 assert_close(g.cpu().numpy(), r.cpu().numpy(), "%s with %s" % (name, combo), rel=1e-5)
     finally:
         SCN.BN_BWD_STATS_FROM_CONV, containers.GRAD_JOIN = True, True
+
+
+def test_no_grad_forward_is_the_same_forward(gpu):
+    """Under torch.no_grad() the modules call their Functions' forward directly (tensor.apply_function: no autograd
+    bookkeeping, the host time of the forward-only configuration) and InputLayer takes the site counts of all scales with one
+    read-back (SCN.GRID_CHAIN = "auto"): the outputs -- training-mode batch norm, running statistics included -- are bitwise
+    those of the recorded forward pass, nothing requires a gradient, and no stream-K wait ever gave up."""
+    import copy
+    import occuseg_amd
+    from occuseg_amd import SCN, scenes
+    scn = occuseg_amd.install()
+    torch.manual_seed(5)
+    net_a = _net(scn, 32, 4, 0.0).to(gpu)
+    net_b = copy.deepcopy(net_a)
+    coords, feats = scenes.batch([1000, 1001], target_sites=12000)
+    batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 2]
+    for _ in range(2):  # (the second pass replays the rulebook plan: the grid chain)
+        out_a = net_a(batch)
+        with torch.no_grad():
+            out_b = net_b(batch)
+        assert out_a.requires_grad and not out_b.requires_grad
+        assert torch.equal(out_a.detach(), out_b)
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert not SCN.stream_k_gave_up()
