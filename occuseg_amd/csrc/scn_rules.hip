@@ -194,7 +194,13 @@ __device__ __forceinline__ int hash_lookup(const uint64_t *tkeys, const int32_t 
 }
 
 // ----------------------------------------------- submanifold 3x3x3 rules ---
-// pass 1: probe the 27 neighbours of each site, write nbr[k][o], count per block
+// pass 1: find the 27 neighbours of each site, write nbr[k][o], count per block.
+// Sites are numbered in key order (sample, z, y, x) with x in the lowest bits, so the sites of one (sample, z, y) row with
+// consecutive x have consecutive numbers: a row of three neighbours (x - 1, x, x + 1 at one (y + dy, z + dz)) needs ONE hash
+// probe when its first member exists -- the other two are the next one or two sites, or absent, which a look at their
+// coordinates tells -- a second probe when it does not, a third when the middle one is missing too (1.75 on the average at
+// half-full neighbourhoods), and the site's own row none at all: ~14 probes per site instead of 26 (round 4: the probe kernel
+// was 0.65 of the 2.14 ms of kernel time of an m64 batch's rule build, random 8-byte reads of a 16-24 MB table).
 __global__ void __launch_bounds__(256)
     k_sub_probe(const int4 *coords, int64_t N, const uint64_t *tkeys, const int32_t *tvals,
                 uint32_t mask, int32_t *nbr, int *blk_cnt, int nblk, const int32_t *site_ori, int only_class) {
@@ -206,23 +212,52 @@ __global__ void __launch_bounds__(256)
   if (valid) c = coords[o];
   // only_class >= 0: keep only the output sites whose orientation class (0 / 2 / 4) is only_class
   const bool keep = valid && (only_class < 0 || site_ori[o] == only_class);
+  // is site t the voxel (x, y, z) of this sample?
+  auto is_at = [&](int64_t t, int x, int y, int z) __attribute__((always_inline)) {
+    if (t < 0 || t >= N) return false;
+    const int4 q = coords[t];
+    return q.x == x && q.y == y && q.z == z && q.w == c.w;
+  };
+  auto lookup = [&](int x, int y, int z) __attribute__((always_inline)) {
+    return in_key_box(x, y, z) ? hash_lookup(tkeys, tvals, mask, voxel_key(x, y, z, c.w)) : -1;
+  };
 #pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    // k = (dx+1)*9 + (dy+1)*3 + (dz+1): sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:61-74
-    const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
-    int i = -1;
+  for (int r = 0; r < 9; ++r) {
+    // k = (dx+1)*9 + (dy+1)*3 + (dz+1): sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:61-74; r = (dy+1)*3 + (dz+1)
+    const int dy = r / 3 - 1, dz = r % 3 - 1;
+    int i[3] = {-1, -1, -1};
     if (valid) {
-      if (k == 13) {
-        i = (int)o;
+      const int y = c.y + dy, z = c.z + dz;
+      if (r == 4) {  // the site's own row
+        i[1] = (int)o;
+        if (is_at(o - 1, c.x - 1, y, z)) i[0] = (int)o - 1;
+        if (is_at(o + 1, c.x + 1, y, z)) i[2] = (int)o + 1;
       } else {
-        const int x = c.x + dx, y = c.y + dy, z = c.z + dz;
-        if (in_key_box(x, y, z)) i = hash_lookup(tkeys, tvals, mask, voxel_key(x, y, z, c.w));
+        const int t0 = lookup(c.x - 1, y, z);
+        if (t0 >= 0) {
+          i[0] = t0;
+          if (is_at((int64_t)t0 + 1, c.x, y, z)) i[1] = t0 + 1;
+          const int64_t nx = (int64_t)(i[1] >= 0 ? i[1] : t0) + 1;
+          if (is_at(nx, c.x + 1, y, z)) i[2] = (int)nx;
+        } else {
+          const int t1 = lookup(c.x, y, z);
+          if (t1 >= 0) {
+            i[1] = t1;
+            if (is_at((int64_t)t1 + 1, c.x + 1, y, z)) i[2] = t1 + 1;
+          } else {
+            i[2] = lookup(c.x + 1, y, z);
+          }
+        }
       }
-      if (!keep) i = -1;
-      nbr[(int64_t)k * N + o] = i;
     }
-    const unsigned long long m = __ballot(i >= 0);
-    if (lane == 0) wcnt[w][k] = __popcll(m);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int k = d * 9 + r;
+      int v = keep ? i[d] : -1;
+      if (valid) nbr[(int64_t)k * N + o] = v;
+      const unsigned long long m = __ballot(v >= 0);
+      if (lane == 0) wcnt[w][k] = __popcll(m);
+    }
   }
   __syncthreads();
   if (threadIdx.x < 27) {
