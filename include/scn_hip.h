@@ -79,6 +79,9 @@ int scn_grid_build(const void *coords, int coords_dtype, int ncols, int shift, i
 size_t scn_grid_chain_temp_bytes(int64_t P, int levels);
 int scn_grid_chain_counts(const void *coords, int coords_dtype, int ncols, int64_t P, int levels, void *temp,
                           size_t temp_bytes, int32_t *n_sites_host, void *stream);
+/* n_sites_host = NULL above: the counting launch is only queued; this reads the counts back (the one synchronisation) -- a caller
+ * queues the launches of the first grid, whose sizes depend on P alone, in between, so that the device works while the host waits */
+int scn_grid_chain_fetch(const void *temp, int64_t P, int levels, int32_t *n_sites_host, void *stream);
 int scn_grid_build_async(const void *coords, int coords_dtype, int ncols, int shift, int64_t P,
                          void *temp, size_t temp_bytes, uint64_t *keys_sorted, int32_t *order,
                          int32_t *site_of_row, int32_t *site_start, int32_t *status_dev, void *stream);

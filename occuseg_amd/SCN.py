@@ -280,11 +280,12 @@ class Metadata_3(object):
                                      ctypes.byref(n), stream()))
             N = int(n.value)
         else:  # counted by the grid chain: no read-back here, the build's own count is compared at the batch's next one
-            N = int(n_known)
             status = torch.empty(2, dtype=torch.int32, device=dev)
             check(lib.scn_grid_build_async(ptr(coords_dev), int(dtype_code), ncols, shift, P, ptr(temp), tb,
                                            ptr(keys_sorted), ptr(order), ptr(site_of_row), ptr(site_start),
                                            ptr(status), stream()))
+            # (a callable: the chain's counts are fetched only now, with this grid's launches -- sized by P alone -- queued)
+            N = int(n_known() if callable(n_known) else n_known)
             self._grid_status.append((status, N))
         site_coords = torch.empty((N, 4), dtype=torch.int32, device=dev)
         site_keys = torch.empty(N, dtype=torch.int64, device=dev)
@@ -337,9 +338,9 @@ class Metadata_3(object):
         # auto: inside a forward pass, and in a prefetch issued under torch.no_grad() (a serving loop: the same host thread
         # issues the forward pass, nothing hides a read-back); not in a prefetch beside a backward pass
         chain = GRID_CHAIN if GRID_CHAIN != "auto" else (not _IN_PREFETCH[0] or not torch.is_grad_enabled())
-        self._chain(c, key, old_plan if PREBUILD and chain else [])
+        fetch = self._chain(c, key, old_plan if PREBUILD and chain else [])
         g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P,
-                                                             n_known=self._chain_counts.get(key))
+                                                             n_known=(lambda: fetch()[key]) if fetch is not None else None)
         self.grids[key] = g
         self.nActive[key] = g.n
         self.input_mode = int(mode)
@@ -383,17 +384,22 @@ class Metadata_3(object):
             if req[0] != "sub" and req[1] == sizes[-1] and req[3] == (2, 2, 2) and req[4] == (2, 2, 2):
                 sizes.append(req[2])
         if len(sizes) < 2 or len(sizes) > _GRID_CHAIN_MAX:
-            return
+            return None
         lib = _lib_()
         P = c.size(0)
         tb = lib.scn_grid_chain_temp_bytes(P, len(sizes))
         temp = torch.empty(tb, dtype=torch.uint8, device=c.device)
-        n = (ctypes.c_int32 * len(sizes))()
         ev = _prof_begin("rules")
-        check(lib.scn_grid_chain_counts(ptr(c), _COORD_DTYPES[c.dtype], c.size(1), P, len(sizes), ptr(temp), tb, n,
-                                        stream()))
+        check(lib.scn_grid_chain_counts(ptr(c), _COORD_DTYPES[c.dtype], c.size(1), P, len(sizes), ptr(temp), tb, None,
+                                        stream()))  # (queued; the read-back comes when the first grid's launches are queued too)
         _prof_end(ev, "grid_chain", 0.0, float(P * c.size(1) * c.element_size() + tb), (P, len(sizes)))
-        self._chain_counts = {sz: int(v) for sz, v in zip(sizes, n)}
+
+        def fetch():
+            n = (ctypes.c_int32 * len(sizes))()
+            check(lib.scn_grid_chain_fetch(ptr(temp), P, len(sizes), n, stream()))
+            self._chain_counts = {sz: int(v) for sz, v in zip(sizes, n)}
+            return self._chain_counts
+        return fetch
 
     def _flush_grid_status(self):
         if self._grid_status:  # (a grid built outside the replayed plan: its own read-back)

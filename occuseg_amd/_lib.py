@@ -22,6 +22,7 @@ SIGNATURES = {
                                ctypes.POINTER(c_int32), _P]),
     "scn_grid_chain_temp_bytes": (c_size_t, [c_int64, c_int]),
     "scn_grid_chain_counts": (c_int, [_P, c_int, c_int, c_int64, c_int, _P, c_size_t, ctypes.POINTER(c_int32), _P]),
+    "scn_grid_chain_fetch": (c_int, [_P, c_int64, c_int, ctypes.POINTER(c_int32), _P]),
     "scn_grid_build_async": (c_int, [_P, c_int, c_int, c_int, c_int64, _P, c_size_t, _P, _P, _P, _P, _P, _P]),
     "scn_grid_finalize": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
     "scn_hash_capacity": (c_int64, [c_int64]),

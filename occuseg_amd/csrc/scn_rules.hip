@@ -737,6 +737,14 @@ int scn_grid_chain_counts(const void *coords, int coords_dtype, int ncols, int64
   else
     k_chain_count<2><<<nblk, 256, 0, stream>>>(coords, ncols, P, levels, tables, (uint32_t)(cap - 1), info);
   SCN_CHECK_LAUNCH();
+  if (n_sites_host == nullptr) return 0;  // (queued only: scn_grid_chain_fetch reads the counts back)
+  return scn_grid_chain_fetch(temp, P, levels, n_sites_host, stream_);
+}
+
+int scn_grid_chain_fetch(const void *temp, int64_t P, int levels, int32_t *n_sites_host, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(P > 0 && levels >= 1 && levels <= SCN_GRID_CHAIN_MAX && n_sites_host != nullptr, "scn_grid_chain_fetch: bad arguments");
+  const int *info = (const int *)((const char *)temp + (size_t)levels * (size_t)chain_capacity(P) * 8);
   int host_info[SCN_GRID_CHAIN_MAX + 1];
   SCN_CHECK_HIP(hipMemcpyAsync(host_info, info, 4 * (levels + 1), hipMemcpyDeviceToHost, stream));
   SCN_CHECK_HIP(hipStreamSynchronize(stream));
