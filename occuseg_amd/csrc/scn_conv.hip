@@ -3178,7 +3178,7 @@ __global__ void __launch_bounds__(256)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // sum of `n` slots first, first + step, ... in that order (four slots' loads in flight at a time)
-    constexpr int GB = NA <= 4 ? 4 : 1;  // slots in flight (64 registers' worth of loads)
+    constexpr int GB = NA <= 4 ? 4 : NA <= 8 ? 2 : 1;  // slots in flight (64 registers' worth of loads)
     auto gather = [&](int first, int step, int n, floatx4 *sum) __attribute__((always_inline)) {
       for (int j0 = 0; j0 < n; j0 += GB) {
         u32x4 b[GB][NA];
@@ -4309,13 +4309,13 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
   const bool huge_ = n_in * ld_in * 4 >= ((int64_t)1 << 32) || n_dout * ld_dout * 4 >= ((int64_t)1 << 32) || n_in >= (1 << 24) ||
                      n_dout >= (1 << 24) || stride >= (1 << 28);
   // the fixed-order reduction INSIDE k_dw_tile (dw_state: its tickets): no memset, no second launch
-  const bool big = g_dw_big && K > 1 && Ci % 128 == 0 && Co % 128 == 0 && Ci % 32 == 0 && !huge_ && g_dw_dbg == 0 && !g_dw_direct;
+  const bool big = g_dw_big && K > 1 && Ci % 128 == 0 && Co % (g_dw_big == 2 ? 64 : 128) == 0 && !huge_ && g_dw_dbg == 0 && !g_dw_direct;
   bool fused = false;
   int grp = DW_GROUP;
   if (workspace && dw_state && g_dw_fused && Ci % 32 == 0 && Co % 32 == 0 && !huge_ && !(g_dw_direct && Ci % 64 == 0 && Co % 64 == 0)) {
     const int per = dw_pairs_per_wg(K, stride, Ci, Co);
     const int64_t gx = (stride + per - 1) / per;
-    const int64_t nt = big ? (int64_t)(Ci / 128) * (Co / 128)
+    const int64_t nt = big ? (int64_t)(Ci / 128) * (Co / (g_dw_big == 2 ? 64 : 128))
                            : (Ci % 64 == 0 && Co % 64 == 0) ? (int64_t)(Ci / 64) * (Co / 64) : (int64_t)(Ci / 32) * (Co / 32);
     grp = gx <= DW_GROUP * DW_GROUP ? DW_GROUP : 2 * DW_GROUP;
     fused = gx <= (int64_t)grp * grp && (int64_t)K * nt * (grp + 1) * 4 <= (int64_t)SCN_DW_STATE_BYTES;
@@ -4352,8 +4352,16 @@ int scn_conv_dweight(const float *in, const float *dout, float *dW, const int32_
 #ifdef SCN_TUNING
     // 128 x 128 blocks (tuning key 25): 64 bytes of operand per MFMA from L2 instead of 128 -- and 192-244 registers, two waves
     // per SIMD: 0.938 against 0.883 ms at 128 -> 128 on level 1, 0.208 against 0.144 at level 3 (round 4, tools/ab_dw_det.py
-    // with DW_BIG=1).  Not the product's kernel.
-    if (big) {
+    // with DW_BIG=1).  Key 25 = 2: 128 x 64 blocks (96 bytes per MFMA, 116-140 registers): 3-5.5 % faster than 64 x 64 with float
+    // atomics on the big shapes with 128 input planes, -2..+2 % with the fixed-order slots, slower on the coarse levels.  Neither
+    // is the product's kernel.
+    if (big && g_dw_big == 2) {  // 128 x 64 blocks: 96 bytes of operand per MFMA
+      const unsigned nblk = (unsigned)(gx * K * (Ci / 128) * (Co / 64));
+      if (fused)
+        k_dw_tile<4, 2, 32, 0, 1><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+      else
+        k_dw_tile<4, 2, 32><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);
+    } else if (big) {
       const unsigned nblk = (unsigned)(gx * K * (Ci / 128) * (Co / 128));
       if (fused)
         k_dw_tile<4, 4, 32, 0, 1><<<nblk, 256, 0, stream>>>(in, dout, dwo, (const int2 *)rules, counts, stride, in_col, Ci, Co, gx, in_bytes, do_bytes, K);

@@ -30,10 +30,11 @@ for lv, shapes in enumerate((((64, 64), (128, 64)), ((128, 128), (256, 128)), ((
         line = "L%d N=%d %d->%d slots %.0f MB:" % (lv, n, ci, co, wsb / 1e6)
         modes = (("atomic", None, None), ("in-kernel", ws, state), ("two-launch", ws, None), ("atomic", None, None), ("in-kernel", ws, state))
         if os.environ.get("DW_BIG"):  # 128 x 128 blocks (tuning key 25) against 64 x 64, fixed order in-kernel and atomics
+            big = int(os.environ["DW_BIG"])  # 1: 128 x 128 blocks, 2: 128 x 64
             modes = (("64 in-kernel", ws, state), ("128 in-kernel", ws, state), ("64 atomic", None, None), ("128 atomic", None, None)) * 2
         for name, w, st in modes:
             if os.environ.get("DW_BIG"):
-                lib.scn_set_tuning(25, 1 if name.startswith("128") else 0)
+                lib.scn_set_tuning(25, big if name.startswith("128") else 0)
             def call():
                 check(lib.scn_conv_dweight(ptr(x), ptr(dy), ptr(dw), ptr(rb.rules), ptr(rb.counts), ptr(rb.bases.get(1)), 27, rb.stride,
                                            0, 1, n, n, ci, co, 0, 0, ptr(w), wsb if w is not None else 0, ptr(st), stream()))
