@@ -908,7 +908,7 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
         bn_link = None
     if stats_out is not None or bn_link is not None:
         nblk = nblk_lib
-        if kind == 2 and not SPLIT_FUSED and code % 100 > 1:
+        if kind in (2, 4) and not SPLIT_FUSED and code % 100 > 1:
             nblk = 0  # (a split launch emits statistics only when it adds its partial tiles itself: sk_state)
         if nblk > 0:
             cstats = torch.empty((nblk, 2, Co), dtype=torch.float32, device=inp.device)
@@ -938,7 +938,7 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                                ptr(rb.counts), K, rb.stride,
                                in_col, out_col, uniq,
                                inp.size(0), n_out, Ci, Co, ld_in, ld_out, ptr(wpack), ready, ptr(ws), ws_bytes,
-                               ptr(_sk_state(inp.device, st)) if (STREAM_K and kind == 4) or (SPLIT_FUSED and kind == 2) else None, st))
+                               ptr(_sk_state(inp.device, st)) if (STREAM_K and kind == 4) or (SPLIT_FUSED and kind in (2, 4) and code % 100 > 1) else None, st))
     if bn_link is not None:
         bn_link.offer(out, cstats if bnb is not None else None)
     # algorithmic work of one launch: flops = 2 R Ci Co;

@@ -848,7 +848,14 @@ constexpr int SK_STATE_WORDS = 32; // counters + ticket in front of the flags
 constexpr bool SK_DRAIN = true;
 constexpr bool SK_PREFETCH_DRAW = false;
 constexpr int SK_SLICES = SCN_SK_SLICES;  // slices of the sliced part of a launch (= the entries of scn_tile_passes' slice tables)
-template <int DBG = 0, int INCOL = -1, int GT = 0, int SK = 0>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
+// SPLIT = 1 (needs GT = 1, not SK): a launch that splits its offsets over ksplit workgroups per (tile, column block) -- the coarse
+// UNet levels, a few hundred to a few thousand sites -- adds its partial tiles ITSELF (round 5; k_conv_tile2 does since round 4):
+// every workgroup stores its partial tile to slab blockIdx.y of `out_a` (write-through), draws the item's ticket
+// (`sk_state_a` = the ticket words), and the last one to arrive reads the ksplit slabs back in slab order, writes the sum to
+// `slabs_a` (= the launch's real output) and emits the column statistics.  The pieces of a tile are ADDED by its last arriver, not
+// chained as stream-K's are: the ksplit workgroups of a tile run at the same time.  Same slabs, same order as k_conv_tile2's
+// split launch: bit-identical to it.
+template <int DBG = 0, int INCOL = -1, int GT = 0, int SK = 0, int SPLIT = 0>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (<= 256 registers: hipcc then keeps the accumulators in VGPRs, no v_accvgpr_read)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out_a, const float *__restrict__ Wp,
                  const float *__restrict__ bias_a, const float *__restrict__ residual_a, StatsArg colstats_a, const int2 *__restrict__ rules,
@@ -876,6 +883,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   __shared__ __attribute__((aligned(8))) unsigned ptab[GT ? 1 : TMAX][2];  // {byte offset of the pass's first pair in `rules`,
                                                                   //  pairs left in the list | chunk<<8 | k<<12 | first<<20}
   static_assert(!SK || GT, "stream-K keeps its pass tables in global memory");
+  static_assert(!SPLIT || (GT && !SK), "the fused split launch keeps its pass tables in global memory and is not a stream-K launch");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1645,6 +1653,103 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // each wave stores its own 32 planes: no barrier needed
   const int rows = (int)min((int64_t)M, n_out - o0_e);
   float *dst = out + (int64_t)blockIdx.y * n_out * Co;
+  if (SPLIT && ksplit > 1) {
+    // ---- split launch, partial tiles added by the tile's last workgroup (see SPLIT above).  The hand-over that the L2 caches
+    // of eight XCDs require: write-through (sc1) stores of the partial tile, every wave drains them, the barrier, ONE lane draws
+    // the item's ticket; the workgroup that draws the last one reads all slabs with sc1 loads.  The ticket word goes back to 0.
+    const int co_w = (item % ncb) * COB + 32 * w;
+    const size_t slab_elems = (size_t)n_out * (size_t)Co;
+    const unsigned row_b = (unsigned)Co * 4u;
+    const unsigned tile_b = (unsigned)(((size_t)o0_e * (size_t)Co + (size_t)co_w) * 4);  // (< 2 GiB: the launcher checks)
+    {
+      const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(dst), 0, (int)(slab_elems * 4), 0x00020000);
+      for (int i = lane; i < rows * 8; i += 64) {
+        const int r = i >> 3, c4 = (i & 7) * 4;
+        const floatx4 v = *(const floatx4 *)(o_tile + r * OS + 32 * w + c4);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ds,
+                                               tile_b + (unsigned)r * row_b + (unsigned)c4 * 4u, 0, 16 /* sc1 */);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *const tk_slot = (int *)(o_tile + M * OS);  // (row M: the unused sink row)
+    if (tid == 0) tk_slot[0] = (int)__hip_atomic_fetch_add(sk_state + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (uni(tk_slot[0]) != ksplit - 1) return;
+    if (tid == 0) __hip_atomic_store(sk_state + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory");
+    // slab 0 first -- it holds bias and shortcut --, then 1, 2, ...: k_split_reduce's order.  Three slabs' worth of loads in
+    // flight, eight 16-byte pieces per lane each; a wave adds, stores and sums ITS 32 planes (no barrier from here on).
+    float *const fin = slabs;
+    const bool st_on = colstats.out != nullptr;
+    floatx4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
+    StatsCols sc;
+    sc.bn = false;
+    if (st_on) sc.init(colstats, co_w + (lane & 7) * 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      constexpr int NE = 8;
+      floatx4 sum[NE];
+      unsigned off[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int i = lane + 64 * (h * NE + e), r = i >> 3, c4 = (i & 7) * 4;
+        off[e] = r < rows ? tile_b + (unsigned)r * row_b + (unsigned)c4 * 4u : 0x80000000u;  // (out of range: reads zeros)
+      }
+      // (every load that is issued is consumed: a load left in flight over the loop's back edge is what tools/check_asm_loads.py
+      //  exists to find.  ksplit is 3, 9 or 27, or 8 for a strided rulebook: whole groups of three, then single slabs)
+      auto slab_rsrc = [&](int j) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(uni_ptr(out + (size_t)j * slab_elems), 0, (int)(slab_elems * 4), 0x00020000);
+      };
+      auto as_f4 = [](const u32x4 &v) __attribute__((always_inline)) {
+        return floatx4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+      };
+      int j0 = 0;
+      for (; j0 + 3 <= ksplit; j0 += 3) {
+        u32x4 b[3][NE];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const __amdgpu_buffer_rsrc_t ps = slab_rsrc(j0 + u);
+#pragma unroll
+          for (int e = 0; e < NE; ++e) b[u][e] = __builtin_amdgcn_raw_buffer_load_b128(ps, off[e], 0, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) sum[e] = (j0 + u == 0) ? as_f4(b[u][e]) : sum[e] + as_f4(b[u][e]);
+      }
+      for (; j0 < ksplit; ++j0) {
+        u32x4 b[NE];
+        const __amdgpu_buffer_rsrc_t ps = slab_rsrc(j0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) b[e] = __builtin_amdgcn_raw_buffer_load_b128(ps, off[e], 0, 16 /* sc1 */);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) sum[e] = (j0 == 0) ? as_f4(b[e]) : sum[e] + as_f4(b[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int i = lane + 64 * (h * NE + e), r = i >> 3, c4 = (i & 7) * 4;
+        if (r < rows) {
+          *(floatx4 *)(fin + (o0_e + r) * Co + co_w + c4) = sum[e];
+          if (st_on) sc.add(sum[e], colstats.x + (o0_e + r) * Co + co_w + c4, cs, css);
+        }
+      }
+    }
+    if (st_on) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cs[e] += __shfl_xor(cs[e], o);
+          css[e] += __shfl_xor(css[e], o);
+        }
+      if (lane < 8) {
+        *(floatx4 *)(colstats.out + ((int64_t)tile_e * 2 + 0) * Co + co_w + lane * 4) = cs;
+        *(floatx4 *)(colstats.out + ((int64_t)tile_e * 2 + 1) * Co + co_w + lane * 4) = css;
+      }
+    }
+    return;
+  }
   // ... and the column statistics of these 32 planes over the tile's rows come from the SAME 16-byte reads: lane (row
   // octet lane >> 3, plane quad lane & 7) sums its 16 rows, a butterfly over the eight lanes of a plane quad finishes.  (The
   // first version walked the tile again, one float per lane and row, 64 dependent LDS reads per lane: 3-6 % of a forward
@@ -3626,8 +3731,14 @@ SCN_KNOB g_conv_small_policy = 1500;  // tuning key 4: launches with few tiles k
 SCN_KNOB g_conv_small_off = 0;  // tuning key 3: 1 = always use the widest tile, never split offsets (A/B runs)
 SCN_KNOB g_conv_variant = 4;    // tuning key 0: 1 = first synchronous kernel, 2 = LDS-staged pipelined kernel for every
                                 // shape, 4 (default) = barrier-free k_conv_tile4 where it applies, else as 2
-SCN_KNOB g_conv_small_tile4 = 0;  // tuning key 7: 1 = launches with few tiles use k_conv_tile4 with the offset split instead of
-                                  // k_conv_tile2 (A/B on the train step: 53.14 against 52.79 ms, so off)
+SCN_KNOB g_conv_small_tile4 = 1;  // tuning key 7: n > 0 = launches with few tiles and at least n output rows use k_conv_tile4 with the offset
+                                  // split instead of k_conv_tile2 (1 = all of them, the default since round 5; 0 = none).  Round 2 measured
+                                  // this 0.35 ms per step SLOWER (the kernel of that time, partial tiles added by a second launch); with the
+                                  // pass table in global memory and the tile's last workgroup adding the partial tiles (SPLIT): level 3
+                                  // (7 k sites) 1-12 % faster per launch alone, levels 4 and 5 6-25 % slower alone -- and the train step
+                                  // 0.55-0.8 ms SHORTER with all of them (44.6-44.7 against 45.2-45.5 ms, four runs of tools/ab_step.py
+                                  // tune7=0,1,1000,4000: two waves and 35 KB of LDS per workgroup share a CU with the side stream's dWeight
+                                  // workgroups where k_conv_tile2's four waves and 70 KB do not)
 SCN_KNOB g_conv_tile5 = 0;      // tuning key 9: 1 = k_conv_tile5 (one wave per tile, 64 planes) where k_conv_tile4 would run
 SCN_KNOB g_conv_expand = 1;     // tuning key 8: 0 = launches with one contribution per output row use the tile kernels (A/B)
 SCN_KNOB g_conv_tile6 = 0;      // tuning key 11: 96 / 128 = k_conv_tile6 with that many rows per tile where k_conv_tile4 would run unsplit
@@ -3694,7 +3805,7 @@ static ConvPlan conv_plan(int K, int64_t stride, int64_t n_in, int64_t n_out, in
   }
   // few tiles (coarse UNet levels): the same barrier-free kernel with the offsets split 3-, 9- or 27-fold over workgroups,
   // as long as the pass table of one workgroup (<= 4 passes per offset and C_i chunk) fits
-  if (g_conv_small_tile4 && g_conv_variant == 4 && !g_conv_small_off && K > 1 && s16 % 4 == 0 && Ci % 64 == 0 && Ci / 64 <= 15 &&
+  if (g_conv_small_tile4 > 0 && n_out >= g_conv_small_tile4 && g_conv_variant == 4 && !g_conv_small_off && K > 1 && s16 % 4 == 0 && Ci % 64 == 0 && Ci / 64 <= 15 &&
       blocks(4) >= 8 && blocks(4) < want && n_in < (1 << 24) && (int64_t)K * stride * 8 < (int64_t)0x7fffffff) {
     int ks = 1;
     while (ks < 27 && blocks(4) * ks < g_conv_small_policy) ks *= 3;
@@ -3792,6 +3903,17 @@ static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ?
 // entries (8 bytes each) of one workgroup's region of k_conv_tile4's global pass table: <= 4 passes per (offset, chunk), 8
 // sentinels, rounded to whole 64-byte lines (a scalar-cache line never holds entries of two workgroups)
 static int tile4_gtab_stride(int K, int Ci) { return (K * 4 * (Ci / 64) + 8 + 7) / 8 * 8; }
+// a split launch that adds its partial tiles itself (k_conv_tile4's SPLIT): ticket words behind the stream-K words of the control
+// block, slabs addressed with 32-bit buffer offsets
+static bool split_fused_ok(int64_t items, int64_t n_out, int Co) {
+  return g_conv_split_fused && items + SK_STATE_WORDS <= (int64_t)(SCN_SK_STATE_BYTES / 4) && n_out * Co * 4 < ((int64_t)1 << 31);
+}
+// workspace of a split k_conv_tile4 launch: the ksplit slabs, then (64-byte aligned) one pass-table region per workgroup
+static size_t tile4_split_slab_bytes(int ksplit, int64_t n_out, int Co) { return ((size_t)ksplit * (size_t)n_out * (size_t)Co * 4 + 63) / 64 * 64; }
+static size_t tile4_split_workspace_bytes(int K, int ksplit, int64_t n_out, int Ci, int Co) {
+  const size_t regions = (size_t)((n_out + 127) / 128) * (size_t)(Co / 64) * (size_t)ksplit;
+  return tile4_split_slab_bytes(ksplit, n_out, Co) + regions * (size_t)tile4_gtab_stride((K + ksplit - 1) / ksplit, Ci) * 8;
+}
 // k_conv_expand: blocks of 32 pairs per wave, and an upper bound of the waves of a launch (one statistics slot each)
 static int expand_nb() { return g_conv_expand_nb >= 4 ? 4 : g_conv_expand_nb >= 2 ? 2 : 1; }
 static int64_t expand_waves(int64_t n_out, int K) { return (n_out + 32 * expand_nb() - 1) / (32 * expand_nb()) + K; }
@@ -3869,6 +3991,21 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
   unsigned long long *gtab = (ksplit == 1 && g_conv_gtab) ? (unsigned long long *)part : nullptr;
   const int gstride = tile4_gtab_stride(K, Ci);
   const dim3 grid4((unsigned)(ntiles * ncb), (unsigned)ksplit);
+  // split launches with a control block: the last workgroup of a tile adds the partial tiles itself (k_conv_tile4's SPLIT; one
+  // ticket word per (tile, column block) behind the stream-K words), pass tables in global memory behind the slabs
+  if (ksplit > 1 && sk_state != nullptr && g_conv_gtab && g_conv_dbg == 0 && g_conv_tile5 == 0 && M == 128 &&
+      split_fused_ok((int64_t)ntiles * ncb, n_out, Co)) {
+    unsigned long long *gtab_s = (unsigned long long *)((char *)part + tile4_split_slab_bytes(ksplit, n_out, Co));
+    const int gs = tile4_gtab_stride((K + ksplit - 1) / ksplit, Ci);
+    if (in_col)
+      k_conv_tile4<0, 1, 1, 0, 1><<<grid4, 128, 0, stream>>>(in, part, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran,
+                                                             Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab_s, gs, nullptr, sk_state + SK_STATE_WORDS, out, 0, 0);
+    else
+      k_conv_tile4<0, 0, 1, 0, 1><<<grid4, 128, 0, stream>>>(in, part, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran,
+                                                             Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab_s, gs, nullptr, sk_state + SK_STATE_WORDS, out, 0, 0);
+    SCN_CHECK_LAUNCH();
+    return 0;
+  }
 #ifdef SCN_TUNING  // k_conv_tile6: experimental (tools/ab_tile6.py), not faster than k_conv_tile4
   if (M != 128 || g_conv_tile6 == 128) {
 #define SCN_LAUNCH_TILE6(MM, IC)                                                                                            \
@@ -4056,6 +4193,7 @@ size_t scn_conv_workspace_bytes(int K, int64_t stride, int64_t n_in, int64_t n_o
   if (K < 1 || n_out <= 0 || Ci <= 0 || Co <= 0) return 0;
   const ConvPlan p = conv_plan(K, stride, n_in, n_out, Ci, Co, out_unique);
   if (p.kind == 4 && p.ksplit == 1) return tile4_workspace_bytes(K, n_out, Ci, Co);
+  if (p.kind == 4) return tile4_split_workspace_bytes(K, p.ksplit, n_out, Ci, Co);
   return p.ksplit > 1 ? (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4 : 0;
 }
 
@@ -4070,9 +4208,8 @@ int64_t scn_conv_stats_blocks(int K, int64_t stride, int64_t n_in, int64_t n_out
     // the finished tile in LDS and emits its sums like an unsplit launch.  Tensors of <= 2048 rows: none -- their batch norms
     // run as ONE launch (k_bn_small_fwd / _bwd), which a hand-over would turn into two.  (A reduction kernel that also
     // reduced columns cost +0.2 ms per step in round 2.)
-    const int64_t items = ((n_out + M - 1) / M) * (Co / (16 * p.nw));
-    const bool fused = p.kind == 2 && g_conv_split_fused && items + 32 <= (int64_t)(SCN_SK_STATE_BYTES / 4) &&
-                       n_out * Co * 4 < ((int64_t)1 << 31);
+    const int64_t items = ((n_out + M - 1) / M) * (p.kind == 4 ? Co / 64 : Co / (16 * p.nw));
+    const bool fused = (p.kind == 2 || (p.kind == 4 && g_conv_gtab)) && split_fused_ok(items, n_out, Co);
     return fused && n_out > 2048 ? (n_out + M - 1) / M : 0;
   }
   return (n_out + M - 1) / M;
@@ -4197,7 +4334,8 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
       return 0;
     }
     if (p.ksplit > 1)
-      SCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4,
+      SCN_REQUIRE(workspace != nullptr && workspace_bytes >= (p.kind == 4 ? tile4_split_workspace_bytes(K, p.ksplit, n_out, Ci, Co)
+                                                                         : (size_t)p.ksplit * (size_t)n_out * (size_t)Co * 4),
                   "scn_conv_forward: workspace smaller than scn_conv_workspace_bytes()");
     SCN_REQUIRE(p.ksplit == 1 || colstats_out == nullptr || sk_state != nullptr,
                 "scn_conv_forward: a launch that splits its offsets emits column statistics only with sk_state");

@@ -403,6 +403,112 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
     assert_close(part[0], (want + res).sum(0), "column sums", scale=np.abs(want + res).sum(0).max())
 
 
+# (C_i, C_o, points per sample, extent, strided): offset splits 3-, 9- and 27-fold (submanifold) and 8-fold (strided rulebook)
+@pytest.mark.parametrize("ci,co,n,extent,strided", [(128, 128, 9000, 30, False), (512, 128, 9000, 30, False),
+                                                    (64, 192, 1200, 14, False), (128, 64, 14000, 36, True)])
+def test_tile4_split_launch_adds_its_partial_tiles_itself(gpu, ci, co, n, extent, strided):
+    """Round 5: the coarse UNet levels (< 512 tiles: the offsets of a tile split over 3 / 9 / 27 / 8 workgroups) run on
+    k_conv_tile4, whose last workgroup per (tile, column block) adds the partial tiles in slab order and emits the column
+    statistics (SPLIT).  Forward with bias, shortcut and statistics and the dInput launch with the batch-norm-backward sums:
+    against the float64 oracle (arithmetic of sparseconvnet/SCN/CPU/Convolution.cpp:114-189) and BITWISE against k_conv_tile2's
+    split launch (same slabs, same order); the control block is zero again after every launch."""
+    from occuseg_amd import SCN, _lib
+    from oracle import arith as A, rules as R
+    m, size, grid, _, _ = _setup(gpu, seed=31, n=n, batch=2, extent=extent)
+    lib0 = _lib.load()
+    e = torch.empty(0, device=gpu)
+    rng = np.random.default_rng(ci + co + n)
+    if strided:
+        cgrid, rules, _ = R.strided_rules(grid)
+        n_in, n_out, K = grid.n, cgrid.n, 8
+        fwd_plan = lib0.scn_conv_plan(8, grid.n, n_in, n_out, ci, co, 0)
+    else:
+        rules, _ = R.submanifold_rules(grid)
+        n_in = n_out = grid.n
+        K = 27
+        fwd_plan = lib0.scn_conv_plan(27, grid.n, n_in, n_out, ci, co, 0)
+    assert fwd_plan // 100 == 4 and fwd_plan % 100 > 1, fwd_plan
+    x = (rng.normal(size=(n_in, ci)) * 2 + rng.normal(size=ci)).astype(np.float32)
+    w = (rng.normal(size=(K, ci, co)) * (2.0 / ci / K) ** 0.5).astype(np.float32)
+    b = rng.normal(size=co).astype(np.float32)
+    res = rng.normal(size=(n_out, co)).astype(np.float32)
+    dy = rng.normal(size=(n_out, co)).astype(np.float32)
+    gamma, beta = rng.normal(size=ci).astype(np.float32), rng.normal(size=ci).astype(np.float32)
+    xt, wt, bt, rt, dyt, gt, bet = [_t(a, gpu) for a in (x, w, b, res, dy, gamma, beta)]
+    y, sm, si = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+    SCN.BatchNormalization_updateOutput(xt, y, sm, si, torch.zeros(ci, device=gpu), torch.ones(ci, device=gpu), gt, bet, 1e-4, 0.9, True, 0.2)
+
+    def run():
+        out, sink = torch.empty(0, device=gpu), []
+        link = SCN.BnLink(xt, sm, si, gt, bet, 0.2)
+        d_in = torch.empty(0, device=gpu)
+        if strided:
+            SCN.Convolution_updateOutput(size, size // 2, F2, F2, m, y, out, wt, bt, stats_out=sink)
+            SCN.Convolution_backward(size, size // 2, F2, F2, m, y, d_in, dyt, wt, torch.zeros(K, ci, co, device=gpu), e, _bn_link=link)
+        else:
+            SCN.SubmanifoldConvolution_updateOutput(size, F3, m, y, out, wt, bt, 1, residual=rt, stats_out=sink)
+            SCN.SubmanifoldConvolution_backward(size, F3, m, y, d_in, dyt, wt, torch.zeros(K, ci, co, device=gpu), e, 1, _bn_link=link)
+        part = link.take(d_in)
+        assert int(SCN._sk_state(gpu).view(torch.int32).abs().sum().item()) == 0
+        return out, (sink[0] if sink else None), d_in, part
+
+    got = {"product": run()}
+    splits = set()
+    try:
+        lib = _lib.use_tuning_build()
+        got["k_conv_tile4, split"] = run()
+        lib.scn_set_tuning(7, 0)
+        assert lib.scn_conv_plan(K, grid.n, n_in, n_out, ci, co, 0) == 200 + fwd_plan % 100
+        got["k_conv_tile2, split"] = run()
+        # other splits of the same launch (the workgroups a split launch aims for: tuning key 4), each bitwise against k_conv_tile2
+        for policy in (600, 9000):
+            lib.scn_set_tuning(4, policy)
+            lib.scn_set_tuning(7, 1)
+            code = lib.scn_conv_plan(K, grid.n, n_in, n_out, ci, co, 0)
+            assert code // 100 == 4
+            splits.add(code % 100)
+            a = run()
+            lib.scn_set_tuning(7, 0)
+            b_ = run()
+            assert torch.equal(a[0], b_[0]) and torch.equal(a[2], b_[2]), ("policy", policy, code)
+            got["k_conv_tile4, plan %d" % code] = a
+        lib.scn_set_tuning(4, 1500)
+        lib.scn_set_tuning(7, 1)
+    finally:
+        _lib.use_product_build()
+    splits.add(fwd_plan % 100)
+    assert splits == ({8} if strided else {27} if n_out <= 2048 else {3, 9, 27}), splits
+    ref = got["k_conv_tile2, split"]
+    for name, g in got.items():
+        if "plan" not in name:  # (another split is another summation order: against the oracle below)
+            assert torch.equal(g[0], ref[0]), (name, "forward")
+            assert torch.equal(g[2], ref[2]), (name, "dInput")
+        assert (g[1] is None) == (n_out <= 2048), (name, "column statistics")
+    yn = y.cpu().numpy()
+    want, _ = A.conv_forward(yn, w, rules, n_out, b, dtype=np.float64)
+    if not strided:
+        want = want + res
+    d_in_o, _, _ = A.conv_backward(yn, dy, w, rules, dtype=np.float64)
+    if not strided:  # (the dInput of a strided convolution writes every row once: k_conv_expand, not a split launch)
+        assert lib0.scn_conv_plan(27, grid.n, n_out, n_in, co, ci, 0) // 100 == 4
+    for name, g in got.items():
+        assert_close(g[0].cpu().numpy(), want, "%s: forward %d->%d" % (name, ci, co))
+        assert_close(g[2].cpu().numpy(), d_in_o, "%s: dInput" % name)
+    out, stats, d_in, part = got["product"]
+    if stats is not None:
+        s = stats.double().sum(0).cpu().numpy()
+        assert_close(s[0], want.sum(0), "column sums", scale=np.abs(want).sum(0).max())
+        assert_close(s[1], (want * want).sum(0), "column sums of squares")
+    if part is not None and not strided:
+        # the two reductions of the batch norm's backward pass over the oracle's dInput, with the device's mask
+        mask = np.where(yn > 0, 1.0, 0.2)
+        dprime = d_in_o * mask
+        p = part.double().sum(0).cpu().numpy()
+        mean = sm.double().cpu().numpy()
+        assert_close(p[0], dprime.sum(0), "sum d'", scale=np.abs(dprime).sum(0).max())
+        assert_close(p[1], ((x - mean) * dprime).sum(0), "sum (x - mean) d'", scale=np.abs((x - mean) * dprime).sum(0).max())
+
+
 def test_tile4_equals_tile2_bitwise_sweep(gpu):
     """300 randomised launches (clouds of varying density / extent / batch, C_i 64..384, C_o 64..256, submanifold and
     strided rulebooks in both directions, plain / transposed / reversed weights, with and without bias) through

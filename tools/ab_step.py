@@ -47,6 +47,8 @@ if os.environ.get("AB_MAIN_PRIORITY"):
     print("stream priority range", torch.cuda.Stream.priority_range())
     _main = torch.cuda.Stream(device=dev, priority=int(os.environ["AB_MAIN_PRIORITY"]))
     torch.cuda.set_stream(_main)
+for fixed in os.environ.get("AB_FIXED", "").split():  # AB_FIXED="tune7=1 DW_SIDE_STREAM=0": settings held for the whole run
+    apply(*fixed.split("="))
 name, vals = sys.argv[1].split("=")
 vals = vals.split(",")
 for _ in range(3):
