@@ -147,6 +147,19 @@ _SK_WANTED = set()   # (lists of the rulebook, output column) of the stream-K la
 _SK_MIN_TILES = 512  # (k_conv_tile4 takes launches of >= 512 tiles)
 
 
+def _prefetch_in_flight():
+    """A rulebook prefetch of this process that no InputLayer call has adopted yet and whose kernels may still be running (a
+    serving loop issues the next scene's prefetch BEFORE the current forward pass).  The static schedule of a stream-K launch
+    needs its 1,024 workgroups resident at once; scn's residency check (sk_all_resident) asks for an EMPTY chip, and with part
+    of the chip held by the prefetch stream's kernels the launch would lean on in-order dispatch to make progress (round-4
+    advisor): such a launch runs one workgroup per tile instead.  (A training step's prefetch is issued behind the backward
+    pass and adopted -- the main stream waits for its event -- before the next forward launch: never in flight here.)"""
+    for ent in _PREFETCHED.values():
+        if not ent[3].query():
+            return True
+    return False
+
+
 def _tile_passes(rb, out_col, n_out):
     lib = _lib_()
     passes = torch.empty(lib.scn_tile_passes_bytes(n_out) // 4, dtype=torch.int32, device=rb.rules.device)
@@ -157,9 +170,35 @@ def _tile_passes(rb, out_col, n_out):
 
 def stream_k_gave_up():
     """True if a stream-K launch of this process ever stopped waiting for another workgroup's partial tile (word 9 of the
-    control block; a bounded wait, so that a broken launch cannot hang the GPU): its result is then wrong.  Never observed;
-    tests and bench.py ask after their runs."""
+    control block; a bounded wait, so that a broken launch cannot hang the GPU): its result is then wrong.  Never observed.
+    The default path does not depend on anybody asking: every batch's read-back carries the words (_sk_health_words) and
+    Metadata_3.inputLayer raises."""
     return any(bool(t.view(torch.int32)[9].item()) for t in _SK_STATE.values())
+
+
+def _sk_health_words(device):
+    """word 9 of every control block on `device`, as one-element int32 tensors for the batch's read-back (torch.cat)"""
+    return [t.view(torch.int32)[9:10] for (idx, _), t in _SK_STATE.items() if idx == device.index]
+
+
+def _sk_check(words, device):
+    """`words`: the values of _sk_health_words at the batch's read-back.  A stream-K piece that gave up computed from a slab that
+    had not been published: that launch's output is wrong, and the control block is poisoned -- the late producer raises the
+    flag its reader has already reset, so every later launch on that stream (the tickets of the split launches share the block)
+    would read stale slabs without waiting.  Hard error (round-4 advisor): the blocks are zeroed behind a device-wide
+    synchronisation and the caller is told."""
+    if not any(int(w) for w in words):
+        return
+    torch.cuda.synchronize(device)
+    for (idx, _), t in _SK_STATE.items():
+        if idx == device.index:
+            t.zero_()
+    torch.cuda.synchronize(device)
+    raise RuntimeError(
+        "occuseg_amd: a stream-K launch of k_conv_tile4 stopped waiting for another workgroup's partial tile (sk_state word 9): "
+        "the output of that launch -- hence of the step it belonged to -- is wrong.  The control blocks have been reset; discard "
+        "the step.  SCN_STREAM_K=0 turns stream-K off (the persistent workgroups were not all resident: another process or a "
+        "lower-priority launch held part of the chip for over a second)")
 
 
 KEEP_NBR = False  # tests only: keep each submanifold rulebook's neighbour table (`d_global_query_result`) alive
@@ -308,7 +347,7 @@ class Metadata_3(object):
             check(lib.scn_hash_build(ptr(g.keys), g.n, ptr(g.hash_keys), ptr(g.hash_vals), cap, stream()))
         return g
 
-    def inputLayer(self, spatialSize, coords, batchSize, mode, device, normals=None):
+    def inputLayer(self, spatialSize, coords, batchSize, mode, device, normals=None, _in_prefetch=False):
         """Metadata::inputLayer (sparseconvnet/SCN/Metadata/Metadata.cpp:424-446) ->
         inputLayerRulesSimple (sparseconvnet/SCN/Metadata/IOLayersRules.h:135-202).  ``normals`` (float [P,3], one per
         input point) switches on the fork's normal-guided filters: per-site normals are averaged here
@@ -322,8 +361,9 @@ class Metadata_3(object):
         assert coords.dtype in _COORD_DTYPES, coords.dtype
         key = _size_key(spatialSize)
         _WEPOCH[0] += 1  # a new batch: packed weights are re-made from the module's weights at their next use
-        if not _IN_PREFETCH[0]:
-            _WEPOCH_AT_INPUT[0] += 1  # (a step begins: the coarse-level mark of the step before is stale)
+        in_prefetch = bool(_in_prefetch)
+        if not in_prefetch:
+            _step_begins(_norm_device(device))  # (the coarse-level mark of the step before is stale)
         pre = _PREFETCHED.pop(id(coords), None)
         if pre is not None and pre[0] is coords and pre[4] is normals \
                 and pre[1] == (key, int(mode), _norm_device(device), self.normal_guide_scale):
@@ -337,7 +377,7 @@ class Metadata_3(object):
         old_plan = _PLANS.get(key, [])
         # auto: inside a forward pass, and in a prefetch issued under torch.no_grad() (a serving loop: the same host thread
         # issues the forward pass, nothing hides a read-back); not in a prefetch beside a backward pass
-        chain = GRID_CHAIN if GRID_CHAIN != "auto" else (not _IN_PREFETCH[0] or not torch.is_grad_enabled())
+        chain = GRID_CHAIN if GRID_CHAIN != "auto" else (not in_prefetch or not torch.is_grad_enabled())
         fetch = self._chain(c, key, old_plan if PREBUILD and chain else [])
         g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P,
                                                              n_known=(lambda: fetch()[key]) if fetch is not None else None)
@@ -367,14 +407,17 @@ class Metadata_3(object):
                 except NotImplementedError:
                     break  # not buildable for THIS batch (e.g. normals now guide a strided scale): the op itself will say so
             if pending or self._grid_status:
-                # ONE device->host copy for the pair counts of all submanifold rulebooks and for the site counts the
-                # grids built without read-back found themselves
+                # ONE device->host copy for the pair counts of all submanifold rulebooks, for the site counts the
+                # grids built without read-back found themselves, and for the "gave up" words of the stream-K control blocks
                 st = self._grid_status
-                parts = [rb.counts.sum().reshape(1) for rb in pending] + [s for s, _ in st]
+                health = _sk_health_words(c.device)
+                parts = [rb.counts.sum().reshape(1) for rb in pending] + [s for s, _ in st] + health
                 totals = torch.cat(parts).cpu().tolist()
                 for rb, t in zip(pending, totals):
                     rb.total_pairs = int(t)
-                self._check_grid_status(totals[len(pending):])
+                self._check_grid_status(totals[len(pending):len(totals) - len(health)])
+                if health:
+                    _sk_check(totals[len(totals) - len(health):], c.device)
 
     def _chain(self, c, key, old_plan):
         """Site counts of every scale the previous forward pass on this input size built (its strided rulebook
@@ -387,7 +430,11 @@ class Metadata_3(object):
             return None
         lib = _lib_()
         P = c.size(0)
+        if P <= 0 or P >= (1 << 30):  # (scn_grid_chain_counts takes fewer points than scn_grid_build: per-scale read-backs then)
+            return None
         tb = lib.scn_grid_chain_temp_bytes(P, len(sizes))
+        if tb == 0:
+            return None
         temp = torch.empty(tb, dtype=torch.uint8, device=c.device)
         ev = _prof_begin("rules")
         check(lib.scn_grid_chain_counts(ptr(c), _COORD_DTYPES[c.dtype], c.size(1), P, len(sizes), ptr(temp), tb, None,
@@ -615,8 +662,19 @@ def _norm_device(device):
 
 PREFETCH_AT_COARSE_LEVELS = os.environ.get("SCN_PREFETCH_AT_COARSE", "1") != "0"  # A/B switch, see prefetch_input
 _COARSE_MARK = {}        # device index -> [event, input-layer count at which it was recorded]
-_WEPOCH_AT_INPUT = [0]   # counts InputLayer calls that built or adopted a batch
-_IN_PREFETCH = [False]
+_STEPS = {}              # device index -> InputLayer calls that built or adopted a batch there (prefetches not counted).  Per
+                         # device, and "this call is a prefetch" travels as an argument of inputLayer: as process-global flags
+                         # (round 4) one DataParallel-style thread's prefetch flipped the mode of another thread's InputLayer call
+
+
+def _step_begins(device):
+    _STEPS[device.index] = _STEPS.get(device.index, 0) + 1
+
+
+def _step_count(device):
+    return _STEPS.get(device.index, 0)
+
+
 PREFETCH_PRIORITY = int(os.environ.get("SCN_PREFETCH_PRIORITY", "-1"))  # HIP stream priority of the rule-build side stream (-1 = high)
 
 
@@ -647,14 +705,10 @@ def prefetch_input(spatialSize, coords, mode, device, wait_for_current_stream=Tr
     # where it enters the coarse levels -- launches of a few hundred workgroups that leave most of the chip's issue slots
     # idle -- and the build waits for that mark.
     mark = _COARSE_MARK.get(device.index) if PREFETCH_AT_COARSE_LEVELS else None
-    if mark is not None and mark[1] == _WEPOCH_AT_INPUT[0]:
+    if mark is not None and mark[1] == _step_count(device):
         side.wait_event(mark[0])
     with torch.cuda.stream(side):
-        _IN_PREFETCH[0] = True
-        try:
-            m.inputLayer(spatialSize, coords, 0, mode, device, normals=normals)
-        finally:
-            _IN_PREFETCH[0] = False
+        m.inputLayer(spatialSize, coords, 0, mode, device, normals=normals, _in_prefetch=True)
         done = torch.cuda.Event()
         done.record(side)
     _PREFETCHED.clear()  # one batch ahead is all a training loop needs; never keep stale grids alive
@@ -921,11 +975,11 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
         mk = _COARSE_MARK.get(inp.device.index)
         if mk is None:
             mk = _COARSE_MARK[inp.device.index] = [torch.cuda.Event(), -1]
-        if mk[1] != _WEPOCH_AT_INPUT[0]:
+        if mk[1] != _step_count(inp.device):
             mk[0].record(torch.cuda.current_stream(inp.device))
-            mk[1] = _WEPOCH_AT_INPUT[0]
+            mk[1] = _step_count(inp.device)
     passes = None
-    if kind == 4 and STREAM_K and not (STREAM_K_FWD_ONLY and w_transposed) and K > 1:
+    if kind == 4 and code % 100 == 1 and STREAM_K and not (STREAM_K_FWD_ONLY and w_transposed) and K > 1 and not _prefetch_in_flight():
         passes = rb.passes.get(out_col)
         if passes is None and (n_out + 127) // 128 >= _SK_MIN_TILES:
             _SK_WANTED.add((K, out_col))  # (from the next batch on the tables come with the rulebook)

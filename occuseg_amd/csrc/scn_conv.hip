@@ -3934,7 +3934,19 @@ static int device_cus() {
   return cus;
 }
 // the static stream-K schedule has every workgroup wait for a slab that another one publishes: all SCN_SK_SLICES workgroups must
-// be resident at once (four per CU on 256 CUs).  Checked once against the runtime's own occupancy answer; otherwise: no stream-K
+// be resident at once (four per CU on 256 CUs).  Checked once against the runtime's own occupancy answer; otherwise: no stream-K.
+// What the answer does NOT cover (round-4 advisor): it is the occupancy of an EMPTY chip.  With part of the chip held by other
+// kernels -- another stream of this process, another process -- some of the 1,024 workgroups start late, and the launch then makes
+// progress only because (a) workgroups are dispatched in launch order per XCD, (b) a workgroup's waiting piece is its LAST one
+// and the piece that feeds the next slice its FIRST, and (c) the seed of slice (XCD x, j) comes from (x, j - 1) -- an earlier
+// workgroup of the same XCD -- except for j % SK_CH == 0, where it comes from (x - 1, j + SK_CH - 1), a LATER one: that workgroup
+// becomes resident as soon as any workgroup of its XCD whose own seed is resident finishes, and such workgroups always exist
+// (the chains within an XCD resolve front to back).  The wait is bounded (~1 s, word 9 of the control block) and a give-up is a
+// hard error on the host (SCN.py: _sk_check at every batch's read-back).  The host avoids the situation where it can see it:
+// no stream-K while a rulebook prefetch of this process is in flight (SCN.py: _prefetch_in_flight), and the default keeps
+// stream-K to the forward launches, which have the chip to themselves.  The DRAWN schedule (g_conv_sk_static = 0) has no such
+// dependence -- a slice waits only for a lower slice that was drawn earlier -- and is the one to use where residency cannot be
+// assumed at all.
 static bool sk_all_resident() {
   static int ok = -1;
   if (ok < 0) {

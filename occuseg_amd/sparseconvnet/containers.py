@@ -128,9 +128,9 @@ class _JoinFunction(Function):
         g_left, g_right = g[:, :ctx.p], g[:, ctx.p:]
         join, ctx.join = ctx.join, None
         if join is not None and ctx.needs_input_grad[0]:
-            other = join.take()
+            other = join.take("join")
             if other is None:
-                join.put(g_left)
+                join.put(g_left, "join")
                 g_left = None
             else:
                 g_left = g_left + other
@@ -202,12 +202,12 @@ class _NiNFunction(Function):
         # GradJoin: the other gradient of `features` (out of the body's first batch norm), if that finished first, is added
         # inside the dInput kernel; otherwise this one is left for the batch norm's apply pass to add
         join, ctx.join = ctx.join, None
-        extra = join.take() if (join is not None and grad_input is not None) else None
+        extra = join.take("nin") if (join is not None and grad_input is not None) else None
         with SCN.dw_async(direct):
             SCN.NetworkInNetwork_backward(features, grad_input, grad_output, weight, grad_weight, grad_bias,
                                           _d_in_add=extra.contiguous() if extra is not None else None)
         if join is not None and grad_input is not None and extra is None:
-            join.put(grad_input)
+            join.put(grad_input, "nin")
             grad_input = None
         if direct:
             owner.grad_written(weight)

@@ -113,9 +113,9 @@ class _RuleConvFunction(Function):
         grad_residual = grad_output if ctx.needs_input_grad[10] else None
         join, ctx.join = ctx.join, None
         if join is not None and grad_residual is not None:
-            other = join.take()
+            other = join.take("conv")
             if other is None:
-                join.put(grad_residual)
+                join.put(grad_residual, "conv")
                 grad_residual = None
             else:
                 grad_residual = grad_residual + other

@@ -54,8 +54,8 @@ class _BatchNormFunction(Function):
         if join is not None and not join.armed:
             join = None  # nobody took the other end (no JoinTable behind the JoinConcatTable): plain path
         if join is not None and join.pending is not None:
-            extra = join.take()
-            if not (extra.shape == features.shape and (extra.is_contiguous() or SCN._row_slice(extra))):
+            extra = join.take("bn")
+            if extra is not None and not (extra.shape == features.shape and (extra.is_contiguous() or SCN._row_slice(extra))):
                 extra = extra.contiguous()
         SCN.BatchNormalization_backward(features, grad_input, out, grad_output, save_mean, save_invstd,
                                         running_mean, running_var, weight, bias, grad_weight, grad_bias,
@@ -63,7 +63,7 @@ class _BatchNormFunction(Function):
                                         _partials=partials, _d_x_add=extra)
         ctx.link = ctx.join = None
         if join is not None and extra is None:  # first of the two paths to finish: the other one adds this
-            join.put(grad_input)
+            join.put(grad_input, "bn")
             grad_input = None
         if direct:
             owner.grad_written(weight)

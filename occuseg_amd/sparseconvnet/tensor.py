@@ -21,12 +21,25 @@ class GradJoin(object):
     share one of these, created in forward.  In backward the first to finish leaves its gradient here and returns None
     to autograd; the second adds it INSIDE its own kernel (batch norm backward's apply pass, the NiN dInput's output
     tile) and returns the sum: the elementwise add kernel autograd would launch at x disappears.  Whichever order the
-    engine runs the two in, the sum is the same.  One object per forward pass: nothing survives a failed backward."""
-    __slots__ = ("pending", "armed", "left", "task")
+    engine runs the two in, the sum is the same.
+
+    What is left here is stamped with the backward pass (graph task) and the SIDE that left it, because one object lives as
+    long as its forward pass' graph and backward passes can fail, be repeated over a retained graph, or nest:
+      * same pass, other side                         -> taken (the normal case);
+      * same pass, same side                          -> RuntimeError (a gradient would be lost);
+      * another pass that COMPLETED, other side       -> taken: re-entrant backward (checkpointing) ran the first side in a
+        nested pass of its own (round 4 dropped this one silently: a summand of dL/dx was lost -- round-4 advisor);
+      * another pass, same side                       -> stale (that pass never ran the other side, or failed): replaced;
+      * another pass that has NOT completed, other side -> cannot be told apart: a failed pass being repeated over a retained
+        graph (stale: must be dropped) or an enclosing pass that is still running (must be added).  RuntimeError, never a
+        silently wrong gradient; `containers.GRAD_JOIN = False` avoids the situation."""
+    __slots__ = ("pending", "armed", "left", "task", "side", "done")
 
     def __init__(self, armed=True):
         self.pending = None
         self.task = None
+        self.side = None
+        self.done = False   # the pass that left `pending` has completed (its final callbacks ran)
         self.armed = armed  # False: created by one side only (JoinConcatTable); the other side (JoinTable) arms it in forward
         self.left = None    # JoinConcatTable: the features tensor whose two gradients meet here (JoinTable checks it is its left entry)
 
@@ -37,13 +50,46 @@ class GradJoin(object):
         except AttributeError:
             return None
 
-    def put(self, grad):
-        # (a gradient left by a backward pass that raised before the other side took it is replaced, not added twice)
-        self.pending, self.task = grad, self._task()
+    def put(self, grad, side=None):
+        task = self._task()
+        if self.pending is not None and self.task == task:
+            self.pending = None
+            raise RuntimeError("occuseg_amd GradJoin: two gradients left in one backward pass (by %r and %r) and nobody took "
+                               "the first" % (self.side, side))
+        # (whatever an EARLIER pass left is stale by now: this side would have taken it otherwise -- see take)
+        self.pending, self.task, self.side, self.done = grad, task, side, False
+        try:  # final callbacks run when the pass completes; a pass that raises skips them
+            def _completed(join=self, task=task, grad=grad):
+                if join.pending is grad and join.task == task:
+                    join.done = True
+            torch.autograd.Variable._execution_engine.queue_callback(_completed)
+        except RuntimeError:  # (not inside a backward pass: the boundary functions called by hand)
+            self.done = True
 
-    def take(self):
-        g, self.pending = self.pending, None
-        return g if self.task == self._task() else None
+    def take(self, side=None):
+        g = self.pending
+        if g is None:
+            return None
+        same_side = side is not None and side == self.side
+        if self.task == self._task():
+            if same_side:
+                self.pending = None
+                raise RuntimeError("occuseg_amd GradJoin: side %r came twice in one backward pass" % (side,))
+            self.pending = None
+            return g
+        if same_side:      # left by this very side in an earlier pass that never ran the other side: stale
+            self.pending = None
+            return None
+        if self.done:      # left by a pass that completed: a nested (re-entrant) pass ran the other side
+            self.pending = None
+            return g
+        self.pending = None
+        raise RuntimeError(
+            "occuseg_amd GradJoin: side %r finds a gradient left by side %r in ANOTHER backward pass that has not completed -- "
+            "either a failed pass is being repeated over a retained graph (the gradient is stale) or an enclosing pass is still "
+            "running (re-entrant checkpointing; the gradient belongs to this sum).  The two cannot be told apart, so nothing is "
+            "added or dropped silently: run the forward pass again, or set occuseg_amd.sparseconvnet.containers.GRAD_JOIN = False"
+            % (side, self.side))
 
 
 class SparseConvNetTensor(object):

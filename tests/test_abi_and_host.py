@@ -35,8 +35,12 @@ def test_library_exports_every_declared_symbol():
     assert lib.scn_conv_workspace_bytes(27, 177001, 177001, 177001, 128, 128, 0) == 1024 * 2 * 224 * 8 + 1024 * 128 * 64 * 4
     assert lib.scn_conv_workspace_bytes(27, 524288, 524288, 524288, 64, 64, 0) == 4096 * 120 * 8
     assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 20, 12, 0) == 0  # generic kernel: none
-    ws = lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384, 0)
-    assert ws % (2000 * 384 * 4) == 0 and ws // (2000 * 384 * 4) in (3, 9, 27)
+    # (round 5: on k_conv_tile4 too -- 16 tiles x 6 column blocks x 27 workgroups: the 27 slabs, then a pass table of one offset x six
+    #  chunks x <= 4 passes + 8 sentinels = 32 entries per workgroup)
+    assert lib.scn_conv_plan(27, 2000, 2000, 2000, 384, 384, 0) == 427
+    assert lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384, 0) == 27 * 2000 * 384 * 4 + 16 * 6 * 27 * 32 * 8
+    assert lib.scn_conv_plan(27, 7000, 7000, 7000, 256, 256, 0) == 409 and lib.scn_conv_stats_blocks(27, 7000, 7000, 7000, 256, 256, 0) == 55
+    assert lib.scn_conv_stats_blocks(27, 2000, 2000, 2000, 384, 384, 0) == 0  # (<= 2048 rows: the batch norm's one-launch form)
     # size queries are host-only arithmetic: safe without a GPU
     assert lib.scn_hash_capacity(1000) == 2048
     assert lib.scn_conv_wpack_bytes(27, 64, 64) == 27 * 64 * 64 * 4

@@ -403,6 +403,29 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
     assert_close(part[0], (want + res).sum(0), "column sums", scale=np.abs(want + res).sum(0).max())
 
 
+def test_stream_k_give_up_is_a_hard_error(gpu):
+    """round-4 advisor: a stream-K piece that stops waiting for its seed slab (a bounded wait) computes from an unpublished slab and
+    leaves the control block poisoned; nothing on the training path looked at the word that says so.  Now every batch's read-back
+    carries it: the next InputLayer call raises, behind a reset of the control blocks."""
+    from occuseg_amd import SCN
+    m, size, grid, _, coords = _setup(gpu, seed=2, n=3000)
+    m.getSubmanifoldRuleBook(size, F3)  # (a recorded request: the next InputLayer call on this size builds it up front and reads back)
+    blk = SCN._sk_state(gpu).view(torch.int32)
+    assert not SCN.stream_k_gave_up()
+    blk[9] = 1    # what k_conv_tile4 leaves when a wait gives up ...
+    blk[40] = 1   # ... and the stale "slab published" flag of the late producer
+    torch.cuda.synchronize()
+    assert SCN.stream_k_gave_up()
+    m2 = SCN.Metadata_3()
+    c = torch.from_numpy(np.ascontiguousarray(coords))
+    with pytest.raises(RuntimeError, match="stopped waiting"):
+        m2.inputLayer(size, c, 0, 4, gpu)
+    assert int(blk.abs().sum().item()) == 0 and not SCN.stream_k_gave_up()
+    m2 = SCN.Metadata_3()
+    m2.inputLayer(size, c, 0, 4, gpu)  # the next batch is fine
+    assert m2.getNActive(size) == grid.n
+
+
 # (C_i, C_o, points per sample, extent, strided): offset splits 3-, 9- and 27-fold (submanifold) and 8-fold (strided rulebook)
 @pytest.mark.parametrize("ci,co,n,extent,strided", [(128, 128, 9000, 30, False), (512, 128, 9000, 30, False),
                                                     (64, 192, 1200, 14, False), (128, 64, 14000, 36, True)])
