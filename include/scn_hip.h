@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 5
+#define SCN_ABI_VERSION 6
 #define SCN_TILE_GRANULE 32 /* output-row granule of the tile-base tables */
 #define SCN_SK_STATE_BYTES 65536 /* scn_conv_forward's sk_state */
 #define SCN_GRID_CHAIN_MAX 12     /* scales one scn_grid_chain_counts call can count */
@@ -149,6 +149,47 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
  * chunk kernels (sparseconvnet/SCN/CUDA/Convolution.cu:1059-1152) deal whole chunks in launch order. */
 size_t scn_tile_passes_bytes(int64_t n_out); /* bytes of `passes`: the prefix, then one slice table per column-block count */
 int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes, void *stream);
+
+/* ---------------------------------------------- all grids and rulebooks of a batch, one call ---
+ * What a forward pass of the UNet asks the reference's Metadata for one piece at a time -- Metadata::inputLayer, then per scale
+ * getSubmanifoldRuleBook and getRuleBook (sparseconvnet/SCN/Metadata/Metadata.cpp:424-446, :504-529, :598-625; drivers
+ * sparseconvnet/SCN/Metadata/ConvolutionRules.h:741-843, sparseconvnet/SCN/Metadata/SubmanifoldConvolutionRules.h:248-275) -- queued
+ * by ONE call into ONE caller-allocated arena, for a caller that knows the site count of every scale (scn_grid_chain_counts).
+ * Same kernels, same arrays, bit for bit, as scn_grid_build_async / scn_grid_finalize / scn_hash_build / scn_submanifold_rules
+ * / scn_strided_rules / scn_tile_bases called one by one: ~60 calls and ~120 allocations of the host per batch become two
+ * (round 5: the forward-only configuration is bound by host time, a third of it the rule build).
+ *   plan:   scale 0 = the input grid of `coords` [P, ncols]; scale l = scale l-1 coarsened by size = stride = 2.
+ *   layout: byte offsets into the arena (256-byte aligned; -1 = not built).  `small` = int32 [levels][2] grid status (N found,
+ *           error flag -- compare N with plan->N), then [levels][27] submanifold list lengths, then [levels][8] strided list
+ *           lengths: ONE device-to-host copy of 4 * levels * 37 bytes hands the host everything it needs to read.
+ *           Everything in front of `scratch` is a result; the scratch part may be freed when the stream has passed the call.
+ * scn_batch_layout_query is host-only arithmetic. */
+#define SCN_BATCH_MAX_LEVELS 12
+typedef struct {
+  int32_t levels;                          /* 1 .. SCN_BATCH_MAX_LEVELS */
+  int32_t coords_dtype, ncols;             /* of the input coordinates: see scn_grid_build */
+  int32_t reserved;
+  int64_t P;                               /* input rows */
+  int64_t N[SCN_BATCH_MAX_LEVELS];         /* active sites of every scale (> 0) */
+  int32_t sub[SCN_BATCH_MAX_LEVELS];       /* != 0: hash map + 3x3x3 submanifold rulebook + tile bases of this scale */
+  int32_t strided[SCN_BATCH_MAX_LEVELS];   /* != 0: 2/2 rulebook scale l -> l+1 + both tile-base tables (l + 1 < levels) */
+} scn_batch_plan;
+typedef struct {
+  int64_t total, scratch, small;
+  int64_t order, site_of_row, site_start;                   /* input layer: int32 [P], [P], [P+1] */
+  int64_t coords[SCN_BATCH_MAX_LEVELS];                     /* int32 [N_l][4] */
+  int64_t keys[SCN_BATCH_MAX_LEVELS];                       /* u64 [N_l] */
+  int64_t hash_keys[SCN_BATCH_MAX_LEVELS];                  /* u64 [hash_cap_l] */
+  int64_t hash_vals[SCN_BATCH_MAX_LEVELS];                  /* int32 [hash_cap_l] */
+  int64_t hash_cap[SCN_BATCH_MAX_LEVELS];                   /* (a count, not an offset) */
+  int64_t sub_rules[SCN_BATCH_MAX_LEVELS];                  /* int32 [27][N_l][2] */
+  int64_t sub_bases[SCN_BATCH_MAX_LEVELS];                  /* int32 [27][ceil(N_l / 32) + 1] */
+  int64_t str_rules[SCN_BATCH_MAX_LEVELS];                  /* int32 [8][N_l][2]: pairs (site of scale l, site of scale l+1) */
+  int64_t str_bases_fine[SCN_BATCH_MAX_LEVELS];             /* int32 [8][ceil(N_l / 32) + 1]      (out_col 0) */
+  int64_t str_bases_coarse[SCN_BATCH_MAX_LEVELS];           /* int32 [8][ceil(N_{l+1} / 32) + 1]  (out_col 1) */
+} scn_batch_layout;
+int scn_batch_layout_query(const scn_batch_plan *plan_host, scn_batch_layout *layout_host);
+int scn_batch_build(const void *coords, const scn_batch_plan *plan_host, void *arena, size_t arena_bytes, void *stream);
 
 /* ------------------------------------------------------- gather-mm-scatter ---
  * out[o,:] = (bias) + sum_k sum_{pairs of list k} in[pair.in_col,:] . Wk

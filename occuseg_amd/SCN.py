@@ -121,6 +121,19 @@ PREBUILD = True
 # 4.23 -> 4.06 ms).  "auto" (default): the chain for builds inside a forward pass or under torch.no_grad(), per-scale read-backs
 # for builds that prefetch_input runs on its side stream beside a backward pass (there the host has nothing else to issue and
 # the device time counts).
+# One C call per batch for every grid and rulebook (scn_batch_build, round 5) where the site counts of all scales are known up front
+# (the grid chain): the forward-only configuration spent a third of its host time in ~60 ctypes calls and ~120 allocations
+BATCH_BUILD = os.environ.get("SCN_BATCH_BUILD", "1") != "0"
+DEFER_PREFETCH_READBACK = os.environ.get("SCN_DEFER_PREFETCH_READBACK", "1") != "0"
+_PINNED = []  # pinned host buffers of the deferred read-backs (allocating one costs a millisecond: kept and re-used)
+
+
+def _pinned(n, dtype):
+    for i, t in enumerate(_PINNED):
+        if t.dtype == dtype and t.numel() >= n:
+            return _PINNED.pop(i)
+    return torch.empty(max(n, 1024), dtype=dtype, pin_memory=True)
+
 _GC = os.environ.get("SCN_GRID_CHAIN", "auto")
 GRID_CHAIN = True if _GC == "1" else False if _GC == "0" else "auto"
 _GRID_CHAIN_MAX = 12
@@ -295,6 +308,7 @@ class Metadata_3(object):
         self.input_site_of_row = None
         self.input_site_start = None
         self._plan = []
+        self._deferred = None     # (pinned host copy of a prefetched build's read-back, its event, what to do with it)
         self._chain_counts = {}   # spatial size -> N from the grid chain (scn_grid_chain_counts), this batch
         self._grid_status = []    # (device [N, error flag] of a grid built without read-back, the N it was built for)
 
@@ -378,14 +392,21 @@ class Metadata_3(object):
         # auto: inside a forward pass, and in a prefetch issued under torch.no_grad() (a serving loop: the same host thread
         # issues the forward pass, nothing hides a read-back); not in a prefetch beside a backward pass
         chain = GRID_CHAIN if GRID_CHAIN != "auto" else (not in_prefetch or not torch.is_grad_enabled())
-        fetch = self._chain(c, key, old_plan if PREBUILD and chain else [])
-        g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P,
-                                                             n_known=(lambda: fetch()[key]) if fetch is not None else None)
-        self.grids[key] = g
-        self.nActive[key] = g.n
+        fetch, sizes = self._chain(c, key, old_plan if PREBUILD and chain else [])
         self.input_mode = int(mode)
         self.input_P = P
-        self.input_order, self.input_site_of_row, self.input_site_start = order, site_of_row, site_start
+        batch_small = None
+        if (fetch is not None and BATCH_BUILD and normals is None and not KEEP_NBR
+                and not (PROFILE is not None and "rules" in PROFILE_KINDS)):
+            # every grid and rulebook of the chain queued by ONE call into one arena (scn_batch_build)
+            batch_small = self._batch_build(c, sizes, fetch(), old_plan)
+            g = self.grids[key]
+        else:
+            g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P,
+                                                                 n_known=(lambda: fetch()[key]) if fetch is not None else None)
+            self.grids[key] = g
+            self.nActive[key] = g.n
+            self.input_order, self.input_site_of_row, self.input_site_start = order, site_of_row, site_start
         if normals is not None:
             assert normals.dim() == 2 and normals.size(0) == P and normals.size(1) == 3, normals.shape
             pn = normals.to(device=device, dtype=torch.float32).contiguous()
@@ -401,23 +422,45 @@ class Metadata_3(object):
                 try:
                     if req[0] == "sub":
                         rb = self.getSubmanifoldRuleBook(req[1], req[2], _defer=True)
-                        pending.append(rb)
+                        if rb.total_pairs is None:  # (known already: a rulebook of the batch build, read back with `small`)
+                            pending.append(rb)
                     else:
                         self.getRuleBook(req[1], req[2], req[3], req[4], _defer=True)
                 except NotImplementedError:
                     break  # not buildable for THIS batch (e.g. normals now guide a strided scale): the op itself will say so
-            if pending or self._grid_status:
+            if pending or self._grid_status or batch_small is not None:
                 # ONE device->host copy for the pair counts of all submanifold rulebooks, for the site counts the
                 # grids built without read-back found themselves, and for the "gave up" words of the stream-K control blocks
-                st = self._grid_status
                 health = _sk_health_words(c.device)
-                parts = [rb.counts.sum().reshape(1) for rb in pending] + [s for s, _ in st] + health
-                totals = torch.cat(parts).cpu().tolist()
-                for rb, t in zip(pending, totals):
-                    rb.total_pairs = int(t)
-                self._check_grid_status(totals[len(pending):len(totals) - len(health)])
-                if health:
-                    _sk_check(totals[len(totals) - len(health):], c.device)
+                parts = [rb.counts.sum().reshape(1) for rb in pending] + [s for s, _ in self._grid_status] + health
+                if batch_small is not None:
+                    parts.append(batch_small[0])
+                flat = parts[0] if len(parts) == 1 else torch.cat(parts)
+                n_health, dev_ = len(health), c.device
+
+                def finish(totals, self=self, pending=pending, batch_small=batch_small):
+                    if batch_small is not None:
+                        self._batch_finish(totals[len(totals) - batch_small[0].numel():], batch_small[1])
+                        totals = totals[:len(totals) - batch_small[0].numel()]
+                    for rb, t in zip(pending, totals):
+                        rb.total_pairs = int(t)
+                    self._check_grid_status(totals[len(pending):len(totals) - n_health])
+                    if n_health:
+                        _sk_check(totals[len(totals) - n_health:], dev_)
+
+                if in_prefetch and batch_small is not None and DEFER_PREFETCH_READBACK:
+                    # a prefetch whose launches are all queued (site counts known from the chain): the read-back is an
+                    # asynchronous copy into pinned memory, picked up when an InputLayer call adopts the batch -- the host
+                    # thread of a serving loop goes on to issue the current forward pass instead of waiting for the side stream
+                    host = _pinned(flat.numel(), flat.dtype)
+                    host[:flat.numel()].copy_(flat, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._deferred = (host, flat.numel(), ev, finish)
+                else:
+                    finish(flat.cpu().tolist())
+        elif batch_small is not None:  # (not reachable: the batch build needs a recorded plan; kept for safety)
+            self._batch_finish(batch_small[0].cpu().tolist(), batch_small[1])
 
     def _chain(self, c, key, old_plan):
         """Site counts of every scale the previous forward pass on this input size built (its strided rulebook
@@ -427,14 +470,14 @@ class Metadata_3(object):
             if req[0] != "sub" and req[1] == sizes[-1] and req[3] == (2, 2, 2) and req[4] == (2, 2, 2):
                 sizes.append(req[2])
         if len(sizes) < 2 or len(sizes) > _GRID_CHAIN_MAX:
-            return None
+            return None, sizes
         lib = _lib_()
         P = c.size(0)
         if P <= 0 or P >= (1 << 30):  # (scn_grid_chain_counts takes fewer points than scn_grid_build: per-scale read-backs then)
-            return None
+            return None, sizes
         tb = lib.scn_grid_chain_temp_bytes(P, len(sizes))
         if tb == 0:
-            return None
+            return None, sizes
         temp = torch.empty(tb, dtype=torch.uint8, device=c.device)
         ev = _prof_begin("rules")
         check(lib.scn_grid_chain_counts(ptr(c), _COORD_DTYPES[c.dtype], c.size(1), P, len(sizes), ptr(temp), tb, None,
@@ -446,7 +489,88 @@ class Metadata_3(object):
             check(lib.scn_grid_chain_fetch(ptr(temp), P, len(sizes), n, stream()))
             self._chain_counts = {sz: int(v) for sz, v in zip(sizes, n)}
             return self._chain_counts
-        return fetch
+        return fetch, sizes
+
+    def _batch_build(self, c, sizes, counts, old_plan):
+        """scn_batch_build: the grids of the chain `sizes` (site counts known: `counts`), the 2/2 rulebooks between them and the
+        submanifold rulebooks the previous forward pass asked for, queued by one call into one arena; every array the ops read
+        is a view into it.  Returns (the `small` block to read back, what _batch_finish needs)."""
+        lib = _lib_()
+        dev = c.device
+        L = len(sizes)
+        plan = _lib.BatchPlan()
+        plan.levels, plan.coords_dtype, plan.ncols, plan.P = L, _COORD_DTYPES[c.dtype], c.size(1), c.size(0)
+        want_sub = {req[1] for req in old_plan if req[0] == "sub" and req[2] == (3, 3, 3)}
+        for l, sz in enumerate(sizes):
+            plan.N[l] = counts[sz]
+            plan.sub[l] = 1 if sz in want_sub else 0
+            plan.strided[l] = 1 if l + 1 < L else 0
+        lo = _lib.BatchLayout()
+        check(lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)))
+        arena = torch.empty(lo.total, dtype=torch.uint8, device=dev)
+        check(lib.scn_batch_build(ptr(c), ctypes.byref(plan), ptr(arena), lo.total, stream()))
+        a32, a64 = arena.view(torch.int32), arena.view(torch.int64)
+
+        def i32(off, *shape):
+            st, acc = [], 1
+            for d in reversed(shape):
+                st.append(acc)
+                acc *= d
+            return a32.as_strided(shape, tuple(reversed(st)), off >> 2)
+
+        def i64(off, n):
+            return a64.as_strided((n,), (1,), off >> 3)
+
+        P = c.size(0)
+        small = i32(lo.small, L * 37)
+        self.input_order, self.input_site_of_row = i32(lo.order, P), i32(lo.site_of_row, P)
+        self.input_site_start = i32(lo.site_start, plan.N[0] + 1)
+        subs = []
+        for l, sz in enumerate(sizes):
+            N = int(plan.N[l])
+            g = _Grid(N, i32(lo.coords[l], N, 4), i64(lo.keys[l], N))
+            self.grids[sz] = g
+            self.nActive[sz] = N
+            n_gran = (N + GRANULE - 1) // GRANULE
+            if plan.sub[l]:
+                cap = int(lo.hash_cap[l])
+                g.hash_keys, g.hash_vals, g.hash_cap = i64(lo.hash_keys[l], cap), i32(lo.hash_vals[l], cap), cap
+                rb = _RuleBook(27, N, i32(lo.sub_rules[l], 27, N, 2), small[2 * L + 27 * l:2 * L + 27 * l + 27])
+                rb.bases[1] = i32(lo.sub_bases[l], 27, n_gran + 1)
+                rb.n_rows[1] = N
+                if STREAM_K and (27, 1) in _SK_WANTED and (N + 127) // 128 >= _SK_MIN_TILES:
+                    _tile_passes(rb, 1, N)
+                self.submanifoldRuleBooks[sz + (3, 3, 3)] = rb
+                subs.append((l, rb))
+            if plan.strided[l]:
+                Nc = int(plan.N[l + 1])
+                n_gran_c = (Nc + GRANULE - 1) // GRANULE
+                o = 2 * L + 27 * L + 8 * l
+                rb = _RuleBook(8, N, i32(lo.str_rules[l], 8, N, 2), small[o:o + 8])
+                rb.bases[1], rb.n_rows[1] = i32(lo.str_bases_coarse[l], 8, n_gran_c + 1), Nc
+                rb.bases[0], rb.n_rows[0] = i32(lo.str_bases_fine[l], 8, n_gran + 1), N
+                rb.total_pairs = N  # every fine site appears in exactly one list
+                rb.unique_col = 0
+                if STREAM_K:
+                    for col, n_out in ((1, Nc), (0, N)):
+                        if (8, col) in _SK_WANTED and (n_out + 127) // 128 >= _SK_MIN_TILES:
+                            _tile_passes(rb, col, n_out)
+                self.ruleBooks[sz + (2, 2, 2, 2, 2, 2)] = rb
+        return small, (L, [int(plan.N[l]) for l in range(L)], subs)
+
+    def _batch_finish(self, small, info):
+        """the host's half of a batch build: `small` read back -- [levels][2] grid status, [levels][27] and [levels][8] list lengths"""
+        L, want, subs = info
+        for l in range(L):
+            got, err = int(small[2 * l]), int(small[2 * l + 1])
+            if err:
+                raise RuntimeError("libscn_hip: scn_batch_build: coordinate outside the 31-bit key box (0<=x<1024, 0<=y<2048, "
+                                   "0<=z<1024) or bad sample index")
+            if got != want[l]:
+                raise RuntimeError("occuseg_amd: grid of scale %d built for %d sites found %d: scn_grid_chain_counts and "
+                                   "scn_batch_build disagree" % (l, want[l], got))
+        for l, rb in subs:
+            rb.total_pairs = int(sum(small[2 * L + 27 * l:2 * L + 27 * l + 27]))
 
     def _flush_grid_status(self):
         if self._grid_status:  # (a grid built outside the replayed plan: its own read-back)
@@ -477,8 +601,19 @@ class Metadata_3(object):
             if t is not None:
                 yield t
 
+    def _complete(self):
+        """the deferred half of a prefetched build: what its read-back says (see inputLayer)"""
+        d, self._deferred = self._deferred, None
+        if d is not None:
+            host, n, ev, finish = d
+            ev.synchronize()
+            vals = host[:n].tolist()
+            _PINNED.append(host)
+            finish(vals)
+
     def _adopt(self, other, done):
         """take over a Metadata_3 that prefetch_input built on the side stream"""
+        other._complete()
         scale = self.normal_guide_scale
         self.__dict__.update(other.__dict__)
         self.normal_guide_scale = scale

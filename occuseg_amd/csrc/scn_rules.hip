@@ -904,4 +904,128 @@ int scn_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t s
   return 0;
 }
 
+// ---- one call per batch (scn_batch_build): the launches of every grid and rulebook of a UNet's forward pass, into one arena
+static int batch_layout(const scn_batch_plan *pl, scn_batch_layout *lo) {
+  SCN_REQUIRE(pl != nullptr && lo != nullptr, "scn_batch_layout_query: NULL argument");
+  const int L = pl->levels;
+  SCN_REQUIRE(L >= 1 && L <= SCN_BATCH_MAX_LEVELS, "scn_batch: levels must be 1..SCN_BATCH_MAX_LEVELS");
+  SCN_REQUIRE(pl->P > 0 && pl->P < (int64_t)1 << 31, "scn_batch: P out of range");
+  SCN_REQUIRE(pl->ncols == 3 || pl->ncols == 4, "scn_batch: ncols must be 3 or 4");
+  SCN_REQUIRE(pl->coords_dtype >= 0 && pl->coords_dtype <= 2, "scn_batch: coords_dtype must be 0 (int32), 1 (int64) or 2 (float32)");
+  for (int l = 0; l < L; ++l) {
+    SCN_REQUIRE(pl->N[l] > 0 && pl->N[l] <= (l == 0 ? pl->P : pl->N[l - 1]), "scn_batch: site counts must be positive and non-increasing");
+    SCN_REQUIRE(!pl->strided[l] || l + 1 < L, "scn_batch: a strided rulebook needs the next scale");
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return (int64_t)o; };
+  for (int l = 0; l < SCN_BATCH_MAX_LEVELS; ++l)
+    lo->coords[l] = lo->keys[l] = lo->hash_keys[l] = lo->hash_vals[l] = lo->sub_rules[l] = lo->sub_bases[l] = lo->str_rules[l] =
+        lo->str_bases_fine[l] = lo->str_bases_coarse[l] = -1, lo->hash_cap[l] = 0;
+  lo->small = take((size_t)L * (2 + 27 + 8) * 4);
+  lo->order = take((size_t)pl->P * 4);
+  lo->site_of_row = take((size_t)pl->P * 4);
+  lo->site_start = take((size_t)(pl->P + 1) * 4);
+  size_t sc_grid = 0, sc_rules = 0;  // scratch: one region for a grid build, one for a rulebook build, each the largest needed
+  for (int l = 0; l < L; ++l) {
+    const int64_t N = pl->N[l], Pl = l == 0 ? pl->P : pl->N[l - 1];
+    const int64_t n_gran = (N + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE;
+    lo->coords[l] = take((size_t)N * 16);
+    lo->keys[l] = take((size_t)N * 8);
+    const size_t gt = scn_grid_build_temp_bytes(Pl);
+    SCN_REQUIRE(gt > 0, "scn_batch: rocprim size query failed");
+    // (grid scratch: the sort's workspace, the sorted keys, and for the coarser scales order / site_of_row / site_start)
+    const size_t g = align256(gt) + align256((size_t)Pl * 8) + (l == 0 ? 0 : 2 * align256((size_t)Pl * 4) + align256((size_t)(Pl + 1) * 4));
+    if (g > sc_grid) sc_grid = g;
+    if (pl->sub[l]) {
+      lo->hash_cap[l] = scn_hash_capacity(N);
+      lo->hash_keys[l] = take((size_t)lo->hash_cap[l] * 8);
+      lo->hash_vals[l] = take((size_t)lo->hash_cap[l] * 4);
+      lo->sub_rules[l] = take((size_t)27 * N * 8);
+      lo->sub_bases[l] = take((size_t)27 * (n_gran + 1) * 4);
+      const size_t r = align256((size_t)27 * N * 4) + align256(scn_rules_temp_bytes(N, 27));
+      if (r > sc_rules) sc_rules = r;
+    }
+    if (pl->strided[l]) {
+      const int64_t n_gran_c = (pl->N[l + 1] + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE;
+      lo->str_rules[l] = take((size_t)8 * N * 8);
+      lo->str_bases_fine[l] = take((size_t)8 * (n_gran + 1) * 4);
+      lo->str_bases_coarse[l] = take((size_t)8 * (n_gran_c + 1) * 4);
+      const size_t r = align256(scn_rules_temp_bytes(N, 8));
+      if (r > sc_rules) sc_rules = r;
+    }
+  }
+  lo->scratch = (int64_t)off;
+  off += sc_grid + sc_rules;
+  lo->total = (int64_t)off;
+  return 0;
+}
+
+int scn_batch_layout_query(const scn_batch_plan *plan_host, scn_batch_layout *layout_host) { return batch_layout(plan_host, layout_host); }
+
+int scn_batch_build(const void *coords, const scn_batch_plan *pl, void *arena, size_t arena_bytes, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  scn_batch_layout lo;
+  if (int rc = batch_layout(pl, &lo)) return rc;
+  SCN_REQUIRE(coords != nullptr && arena != nullptr && arena_bytes >= (size_t)lo.total, "scn_batch_build: arena smaller than scn_batch_layout_query says");
+  char *A = (char *)arena;
+  const int L = pl->levels;
+  int32_t *small = (int32_t *)(A + lo.small);
+  // grid scratch, the same for every scale (the stream runs them one after the other)
+  size_t sc_grid = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t Pl = l == 0 ? pl->P : pl->N[l - 1];
+    const size_t g = align256(scn_grid_build_temp_bytes(Pl)) + align256((size_t)Pl * 8) +
+                     (l == 0 ? 0 : 2 * align256((size_t)Pl * 4) + align256((size_t)(Pl + 1) * 4));
+    if (g > sc_grid) sc_grid = g;
+  }
+  char *SG = A + lo.scratch, *SR = SG + sc_grid;
+  for (int l = 0; l < L; ++l) {
+    const int64_t N = pl->N[l], Pl = l == 0 ? pl->P : pl->N[l - 1];
+    // ---- the grid of scale l: from the input coordinates (l = 0) or from the site coordinates of scale l - 1, shifted by one bit
+    const size_t gt = scn_grid_build_temp_bytes(Pl);
+    char *q = SG;
+    void *temp = q; q += align256(gt);
+    uint64_t *keys_sorted = (uint64_t *)q; q += align256((size_t)Pl * 8);
+    int32_t *order, *site_of_row, *site_start;
+    if (l == 0) {
+      order = (int32_t *)(A + lo.order); site_of_row = (int32_t *)(A + lo.site_of_row); site_start = (int32_t *)(A + lo.site_start);
+    } else {
+      order = (int32_t *)q; q += align256((size_t)Pl * 4);
+      site_of_row = (int32_t *)q; q += align256((size_t)Pl * 4);
+      site_start = (int32_t *)q;
+    }
+    const void *src = l == 0 ? coords : (const void *)(A + lo.coords[l - 1]);
+    const int dt = l == 0 ? pl->coords_dtype : 0, nc = l == 0 ? pl->ncols : 4, shift = l == 0 ? 0 : 1;
+    if (int rc = grid_build_launches(src, dt, nc, shift, Pl, temp, gt, keys_sorted, order, site_of_row, site_start, small + 2 * l, stream))
+      return rc;
+    if (int rc = scn_grid_finalize(src, dt, nc, shift, Pl, N, keys_sorted, order, site_start, (int32_t *)(A + lo.coords[l]),
+                                   (uint64_t *)(A + lo.keys[l]), stream_))
+      return rc;
+    // ---- the 2/2 rulebook scale l - 1 -> l (site_of_row of this grid build = the coarse site of every finer site)
+    if (l > 0 && pl->strided[l - 1]) {
+      int32_t *rules = (int32_t *)(A + lo.str_rules[l - 1]);
+      int32_t *counts = small + 2 * L + 27 * L + 8 * (l - 1);
+      if (int rc = scn_strided_rules((const int32_t *)(A + lo.coords[l - 1]), Pl, site_of_row, rules, counts, SR, scn_rules_temp_bytes(Pl, 8), stream_))
+        return rc;
+      if (int rc = scn_tile_bases(rules, counts, 8, Pl, 1, N, (int32_t *)(A + lo.str_bases_coarse[l - 1]), stream_)) return rc;
+      if (int rc = scn_tile_bases(rules, counts, 8, Pl, 0, Pl, (int32_t *)(A + lo.str_bases_fine[l - 1]), stream_)) return rc;
+    }
+    // ---- hash map and submanifold rulebook of scale l
+    if (pl->sub[l]) {
+      uint64_t *hk = (uint64_t *)(A + lo.hash_keys[l]);
+      int32_t *hv = (int32_t *)(A + lo.hash_vals[l]);
+      if (int rc = scn_hash_build((const uint64_t *)(A + lo.keys[l]), N, hk, hv, lo.hash_cap[l], stream_)) return rc;
+      int32_t *nbr = (int32_t *)SR;
+      void *rt = SR + align256((size_t)27 * N * 4);
+      int32_t *rules = (int32_t *)(A + lo.sub_rules[l]);
+      int32_t *counts = small + 2 * L + 27 * l;
+      if (int rc = scn_submanifold_rules((const int32_t *)(A + lo.coords[l]), N, hk, hv, lo.hash_cap[l], nbr, rules, counts, rt,
+                                         scn_rules_temp_bytes(N, 27), nullptr, 0, -1, nullptr, stream_))
+        return rc;
+      if (int rc = scn_tile_bases(rules, counts, 27, N, 1, N, (int32_t *)(A + lo.sub_bases[l]), stream_)) return rc;
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"

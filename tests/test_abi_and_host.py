@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()  # raises if the .so is missing or a symbol cannot be resolved
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.scn_abi_version() == 5
+    assert lib.scn_abi_version() == 6
     # tuning / ablation entry points are not part of the product library (only of libscn_hip_tuning.so)
     assert not hasattr(lib, "scn_set_tuning") and not hasattr(lib, "scn_debug_stamps")
     assert os.path.exists(_lib.TUNING_LIB_PATH)

@@ -188,11 +188,12 @@ def _walk_levels(m, size, levels):
     for level in range(levels):
         rb = m.getSubmanifoldRuleBook(size, f3)
         g = m.grids[tuple(int(v) for v in size)]
-        out.append((g.n, g.coords.clone(), g.keys.clone(), rb.host_lists(), rb.counts.clone(), rb.total_pairs))
+        out.append((g.n, g.coords.clone(), g.keys.clone(), rb.host_lists(), rb.counts.clone(), rb.total_pairs, rb.bases[1].clone()))
         if level + 1 < levels:
             rb2 = m.getRuleBook(size, size // 2, f2, f2)
             out.append((rb2.host_lists(), rb2.counts.clone(), rb2.bases[0].clone(), rb2.bases[1].clone()))
             size = size // 2
+    out.append((m.input_order.clone(), m.input_site_of_row.clone(), m.input_site_start.clone()))
     return out
 
 
@@ -206,13 +207,15 @@ def test_grid_chain_one_read_back_same_grids(gpu, monkeypatch, dtype):
     coords = torch.from_numpy(np.ascontiguousarray(c)).to(dtype)
     size = torch.tensor([4096] * 3, dtype=torch.int64)
     lib = SCN._lib_()
-    calls = {"scn_grid_build": 0, "scn_grid_build_async": 0, "scn_grid_chain_counts": 0}
+    calls = {"scn_grid_build": 0, "scn_grid_build_async": 0, "scn_grid_chain_counts": 0, "scn_batch_build": 0,
+             "scn_submanifold_rules": 0, "scn_strided_rules": 0, "scn_tile_bases": 0, "scn_hash_build": 0}
     for name in calls:
         real = getattr(lib, name)
         monkeypatch.setattr(lib, name, lambda *a, _r=real, _n=name: (calls.__setitem__(_n, calls[_n] + 1), _r(*a))[1])
 
-    def run(chain):
+    def run(chain, batch=False):
         monkeypatch.setattr(SCN, "GRID_CHAIN", chain)
+        monkeypatch.setattr(SCN, "BATCH_BUILD", batch)
         for k in calls:
             calls[k] = 0
         m = SCN.Metadata_3()
@@ -223,27 +226,34 @@ def test_grid_chain_one_read_back_same_grids(gpu, monkeypatch, dtype):
 
     SCN._PLANS.pop((4096,) * 3, None)
     ref, n0 = run(False)               # no plan yet: one read-back per scale
-    assert n0 == {"scn_grid_build": 6, "scn_grid_build_async": 0, "scn_grid_chain_counts": 0}
+    grids = {k: n0[k] for k in ("scn_grid_build", "scn_grid_build_async", "scn_grid_chain_counts", "scn_batch_build")}
+    assert grids == {"scn_grid_build": 6, "scn_grid_build_async": 0, "scn_grid_chain_counts": 0, "scn_batch_build": 0}
+    assert n0["scn_submanifold_rules"] == 6 and n0["scn_strided_rules"] == 5 and n0["scn_hash_build"] == 6 and n0["scn_tile_bases"] == 16
     again, n1 = run(False)             # plan replayed, chain off
     assert n1 == n0
     got, n2 = run(True)                # plan replayed with the chain
-    assert n2 == {"scn_grid_build": 0, "scn_grid_build_async": 6, "scn_grid_chain_counts": 1}
+    assert n2 == dict(n0, scn_grid_build=0, scn_grid_build_async=6, scn_grid_chain_counts=1)
+    # round 5: ... and every grid and rulebook of the chain queued by ONE call into one arena (scn_batch_build)
+    one, n3 = run(True, batch=True)
+    assert n3 == dict({k: 0 for k in calls}, scn_grid_chain_counts=1, scn_batch_build=1)
     assert [r[0] for r in ref[0::2]] == [r[0] for r in got[0::2]] and ref[0][0] > ref[2][0] > ref[10][0] > 0
-    for a, b, d in zip(ref, again, got):
-        for x, y, z in zip(a, b, d):
+    for a, b, d, e in zip(ref, again, got, one):
+        for x, y, z, u in zip(a, b, d, e):
             if torch.is_tensor(x):
-                assert torch.equal(x, y) and torch.equal(x, z)
+                assert torch.equal(x, y) and torch.equal(x, z) and torch.equal(x, u)
             elif isinstance(x, list):  # the lists of a rulebook (the rows behind counts[k] are unwritten memory)
-                assert len(x) == len(y) == len(z)
-                assert all(np.array_equal(i, j) and np.array_equal(i, k) for i, j, k in zip(x, y, z))
+                assert len(x) == len(y) == len(z) == len(u)
+                assert all(np.array_equal(i, j) and np.array_equal(i, k) and np.array_equal(i, v) for i, j, k, v in zip(x, y, z, u))
             else:
-                assert x == y == z
+                assert x == y == z == u
     # the error a coordinate outside the key box raises comes from the chain now
     bad = coords.clone()
     bad[5, 1] = 2048
     monkeypatch.setattr(SCN, "GRID_CHAIN", True)
-    with pytest.raises(RuntimeError, match="key box"):
-        SCN.Metadata_3().inputLayer(size, bad, 0, 4, gpu)
+    for batch in (False, True):
+        monkeypatch.setattr(SCN, "BATCH_BUILD", batch)
+        with pytest.raises(RuntimeError, match="key box"):
+            SCN.Metadata_3().inputLayer(size, bad, 0, 4, gpu)
 
 
 def test_grid_chain_counts_abi(gpu):
