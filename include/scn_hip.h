@@ -336,13 +336,17 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
                    int64_t N, int C, void *temp, void *stream);
 /* training forward with the statistics handed over by the producing kernels: nseg segments of planes (in order, covering
  * all C), segment i = seg_ncols[i] planes with partial sums seg_partial[i] = [seg_nblk[i]][2][seg_ncols[i]] (device;
- * the three arrays themselves are HOST arrays).  Only finalize + apply run: 8 instead of 12 bytes per element. */
+ * the three arrays themselves are HOST arrays).  Only finalize + apply run: 8 instead of 12 bytes per element.
+ * state (may be NULL; here and in scn_bn_backward_ext): the stream's control block (SCN_SK_STATE_BYTES of device memory that hold
+ * ZERO between launches, shared with scn_conv_forward's sk_state: launches of one stream never overlap).  With it, more than 256
+ * partials are folded AND finalized by one launch (a ticket in word 11, zero again afterwards) instead of two; same arithmetic
+ * in the same order. */
 int scn_bn_forward_ext(const float *x, float *y, float *save_mean, float *save_invstd,
                        float *running_mean, float *running_var, const float *weight,
                        const float *bias, double eps, double momentum, double leakiness,
                        int64_t N, int C, void *temp, int nseg, const int32_t *seg_ncols_host,
                        const float *const *seg_partial_host, const int32_t *seg_nblk_host,
-                       void *stream);
+                       void *state, void *stream);
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
                     const float *save_mean, const float *save_invstd, const float *weight,
                     const float *bias, float *d_weight, float *d_bias, double leakiness, int64_t N,
@@ -356,7 +360,7 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
 int scn_bn_backward_ext(const float *x, float *d_x, const float *d_out, const float *save_mean,
                         const float *save_invstd, const float *weight, const float *bias, float *d_weight,
                         float *d_bias, double leakiness, int64_t N, int C, int flags, void *temp,
-                        const float *partial, int nblk, const float *d_x_add, int64_t ld_add, void *stream);
+                        const float *partial, int nblk, const float *d_x_add, int64_t ld_add, void *state, void *stream);
 
 /* ------------------------------------------------------ input / output ---
  * Replaces InputLayer_fp/bp (sparseconvnet/SCN/CUDA/IOLayers.cu:17-76) and the four wrappers of

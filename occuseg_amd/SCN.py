@@ -143,6 +143,9 @@ STREAM_K_FWD_ONLY = os.environ.get("SCN_STREAM_K", "fwd") == "fwd"
 # partial tiles itself (scn_conv_forward's sk_state) instead of a second launch, and emits the batch norm's statistics.
 # False: k_split_reduce as in round 3 (A/B: tools/ab_step.py SPLIT_FUSED=0,1)
 SPLIT_FUSED = os.environ.get("SCN_SPLIT_FUSED", "1") != "0"
+# the statistics a convolution hands to the batch norm next to it (one partial per 128-row tile: thousands) are folded AND finalized by
+# one launch -- a ticket in the stream's control block -- instead of two (A/B: tools/ab_step.py BN_FOLD_FUSED=0,1)
+BN_FOLD_FUSED = os.environ.get("SCN_BN_FOLD_FUSED", "1") != "0"
 _SK_STATE = {}  # (device index, stream handle) -> the zeroed control block of that stream's stream-K launches
 
 
@@ -1519,9 +1522,11 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
         ncols = (ctypes.c_int32 * nseg)(*[n for n, _ in _colstats])
         parts = (ctypes.c_void_p * nseg)(*[p.data_ptr() for _, p in _colstats])
         nblks = (ctypes.c_int32 * nseg)(*[p.size(0) for _, p in _colstats])
+        st = stream()
         check(_lib_().scn_bn_forward_ext(ptr(x), ptr(output_features), ptr(saveMean), ptr(saveInvStd), ptr(runningMean),
                                          ptr(runningVar), ptr(weight), ptr(bias), float(eps), float(momentum),
-                                         float(leakiness), N, C, ptr(temp), nseg, ncols, parts, nblks, stream()))
+                                         float(leakiness), N, C, ptr(temp), nseg, ncols, parts, nblks,
+                                         ptr(_sk_state(x.device, st)) if BN_FOLD_FUSED else None, st))
         _prof_end(ev, "bn_fwd", 0.0, 8.0 * N * C, (N, C, "ext"))  # x read once, y written
         return
     check(_lib_().scn_bn_forward(ptr(x), ptr(output_features), ptr(saveMean), ptr(saveInvStd), ptr(runningMean),
@@ -1552,11 +1557,13 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
         assert _mask_from_x
         assert _partials is None or (_partials.is_contiguous() and tuple(_partials.shape[1:]) == (2, C))
         assert _d_x_add is None or (tuple(_d_x_add.shape) == (N, C) and (_d_x_add.is_contiguous() or _row_slice(_d_x_add)))
+        st = stream()
         check(_lib_().scn_bn_backward_ext(ptr(x), ptr(d_input_features), ptr(d_output_features), ptr(saveMean),
                                           ptr(saveInvStd), ptr(weight), ptr(bias), ptr(d_weight), ptr(d_bias),
                                           float(leakiness), N, C, 2 if _accumulate else 0, ptr(temp), ptr(_partials),
                                           _partials.size(0) if _partials is not None else 0, ptr(_d_x_add),
-                                          _d_x_add.stride(0) if _d_x_add is not None else 0, stream()))
+                                          _d_x_add.stride(0) if _d_x_add is not None else 0,
+                                          ptr(_sk_state(x.device, st)) if BN_FOLD_FUSED and _partials is not None else None, st))
         _prof_end(ev, "bn_bwd", 0.0, (12.0 if _partials is not None else 20.0) * N * C + (4.0 * N * C if _d_x_add is not None else 0.0),
                   (N, C, "ext"))
         return

@@ -55,10 +55,10 @@ SIGNATURES = {
     "scn_bn_forward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_int, c_double,
                                c_int64, c_int, _P, _P]),
     "scn_bn_forward_ext": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, c_double, c_double, c_int64, c_int, _P,
-                                   c_int, ctypes.POINTER(c_int32), ctypes.POINTER(_P), ctypes.POINTER(c_int32), _P]),
+                                   c_int, ctypes.POINTER(c_int32), ctypes.POINTER(_P), ctypes.POINTER(c_int32), _P, _P]),
     "scn_bn_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P]),
     "scn_bn_backward_ext": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, c_int64, c_int, c_int, _P, _P, c_int, _P,
-                                    c_int64, _P]),
+                                    c_int64, _P, _P]),
     "scn_input_forward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_input_backward": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "scn_output_forward": (c_int, [_P, _P, _P, c_int64, c_int, _P]),

@@ -75,11 +75,17 @@ __global__ void __launch_bounds__(256) k_bn_stats(const float *x, int64_t N, int
 
 // Sum the per-block partials of 16 columns with 256 threads (16 columns x 16 partial lanes), in fp64.
 // Returns the two column sums to the threads with bl == 0.
-__device__ __forceinline__ bool bn_sum_partials(const float *partial, int nblk, int C, int &c, double &s0, double &s1) {
+// COHERENT: the partials were written by other workgroups of THIS launch (write-through stores; k_bn_fold_finalize): read them
+// with agent-scope loads -- the L2 caches of two XCDs are not coherent.  cgroup: which 16 columns (blockIdx.x in the plain kernels).
+template <bool COHERENT = false>
+__device__ __forceinline__ bool bn_sum_partials(const float *partial, int nblk, int C, int &c, double &s0, double &s1, int cgroup) {
   __shared__ double red[2][16][17];
   const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
-  c = blockIdx.x * 16 + cl;
+  c = cgroup * 16 + cl;
   double a = 0, b = 0;
+  auto ld = [](const float *q) __attribute__((always_inline)) {
+    return COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+  };
   if (c < C) {
     // up to 64 dependent fp64 adds per thread: the LOADS are independent, so eight iterations' worth are requested before
     // the first add (same summation order; the finalize kernels took 26 us of pure L2 latency per launch before)
@@ -89,8 +95,8 @@ __device__ __forceinline__ bool bn_sum_partials(const float *partial, int nblk, 
       float va[8], vb[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        va[u] = p0[(int64_t)(blk + 16 * u) * 2 * C];
-        vb[u] = p0[(int64_t)(blk + 16 * u) * 2 * C + C];
+        va[u] = ld(p0 + (int64_t)(blk + 16 * u) * 2 * C);
+        vb[u] = ld(p0 + (int64_t)(blk + 16 * u) * 2 * C + C);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -99,8 +105,8 @@ __device__ __forceinline__ bool bn_sum_partials(const float *partial, int nblk, 
       }
     }
     for (; blk < nblk; blk += 16) {
-      a += (double)p0[(int64_t)blk * 2 * C];
-      b += (double)p0[(int64_t)blk * 2 * C + C];
+      a += (double)ld(p0 + (int64_t)blk * 2 * C);
+      b += (double)ld(p0 + (int64_t)blk * 2 * C + C);
     }
   }
   red[0][bl][cl] = a;
@@ -119,15 +125,22 @@ __device__ __forceinline__ bool bn_sum_partials(const float *partial, int nblk, 
 // arithmetic of sparseconvnet/SCN/CPU/BatchNormalization.cpp:19-52 with the row sums finished in fp64.
 // The partial sums [nblk][2][Cp] may cover a SEGMENT of the planes only (col0 .. col0 + Cp): statistics handed over by
 // the kernel that produced those planes (scn_conv_forward's colstats), one finalize launch per segment.
-__global__ void __launch_bounds__(256)
-    k_bn_finalize(const float *partial, int nblk, int64_t N, int Cp, int col0, int C, float *save_mean,
-                  float *save_invstd, float *running_mean, float *running_var,
-                  const float *weight, const float *bias, float eps, float momentum,
-                  int train, float *wb) {
+__device__ __forceinline__ void bn_finalize_col(int c, double s, double ss, int64_t N, int C, float *save_mean, float *save_invstd,
+                                                float *running_mean, float *running_var, const float *weight, const float *bias,
+                                                float eps, float momentum, int train, float *wb);
+template <bool COHERENT>
+__device__ __forceinline__ void bn_finalize_group(const float *partial, int nblk, int64_t N, int Cp, int col0, int C, float *save_mean,
+                                                  float *save_invstd, float *running_mean, float *running_var,
+                                                  const float *weight, const float *bias, float eps, float momentum,
+                                                  int train, float *wb, int cgroup) {
   int cl;
   double s = 0, ss = 0;
-  if (!bn_sum_partials(partial, train ? nblk : 0, Cp, cl, s, ss)) return;
-  const int c = col0 + cl;
+  if (!bn_sum_partials<COHERENT>(partial, train ? nblk : 0, Cp, cl, s, ss, cgroup)) return;
+  bn_finalize_col(col0 + cl, s, ss, N, C, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, train, wb);
+}
+__device__ __forceinline__ void bn_finalize_col(int c, double s, double ss, int64_t N, int C, float *save_mean, float *save_invstd,
+                                                float *running_mean, float *running_var, const float *weight, const float *bias,
+                                                float eps, float momentum, int train, float *wb) {
   float mean, invstd;
   if (train) {
     const double m = s / (double)N;
@@ -147,6 +160,15 @@ __global__ void __launch_bounds__(256)
   const float w = invstd * (weight ? weight[c] : 1.f);
   wb[c] = w;
   wb[C + c] = fmaf(-mean, w, bias ? bias[c] : 0.f);
+}
+
+__global__ void __launch_bounds__(256)
+    k_bn_finalize(const float *partial, int nblk, int64_t N, int Cp, int col0, int C, float *save_mean,
+                  float *save_invstd, float *running_mean, float *running_var,
+                  const float *weight, const float *bias, float eps, float momentum,
+                  int train, float *wb) {
+  bn_finalize_group<false>(partial, nblk, N, Cp, col0, C, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum,
+                           train, wb, blockIdx.x);
 }
 
 template <int VEC>
@@ -222,13 +244,21 @@ __global__ void __launch_bounds__(256)
 }
 
 // (sparseconvnet/SCN/CPU/BatchNormalization.cpp:88-93,:103-106); coef = [gradMean | k | invstd*gamma | w | b]
-__global__ void __launch_bounds__(256)
-    k_bn_bwd_finalize(const float *partial, int nblk, int64_t N, int C, const float *save_mean, const float *save_invstd,
-                      const float *weight, const float *bias, float *d_weight, float *d_bias, float *coef,
-                      int accumulate) {
+__device__ __forceinline__ void bn_bwd_finalize_col(int c, double s, double dp, int64_t N, int C, const float *save_mean,
+                                                    const float *save_invstd, const float *weight, const float *bias, float *d_weight,
+                                                    float *d_bias, float *coef, int accumulate);
+template <bool COHERENT>
+__device__ __forceinline__ void bn_bwd_finalize_group(const float *partial, int nblk, int64_t N, int C, const float *save_mean,
+                                                      const float *save_invstd, const float *weight, const float *bias, float *d_weight,
+                                                      float *d_bias, float *coef, int accumulate, int cgroup) {
   int c;
   double s = 0, dp = 0;
-  if (!bn_sum_partials(partial, nblk, C, c, s, dp)) return;
+  if (!bn_sum_partials<COHERENT>(partial, nblk, C, c, s, dp, cgroup)) return;
+  bn_bwd_finalize_col(c, s, dp, N, C, save_mean, save_invstd, weight, bias, d_weight, d_bias, coef, accumulate);
+}
+__device__ __forceinline__ void bn_bwd_finalize_col(int c, double s, double dp, int64_t N, int C, const float *save_mean,
+                                                    const float *save_invstd, const float *weight, const float *bias, float *d_weight,
+                                                    float *d_bias, float *coef, int accumulate) {
   const float invstd = save_invstd[c];
   if (d_bias) d_bias[c] = (accumulate ? d_bias[c] : 0.f) + (float)s;
   if (d_weight) d_weight[c] = (accumulate ? d_weight[c] : 0.f) + (float)(dp * (double)invstd);
@@ -238,6 +268,13 @@ __global__ void __launch_bounds__(256)
   coef[2 * C + c] = w;
   coef[3 * C + c] = w;                                                  // forward's w ...
   coef[4 * C + c] = fmaf(-save_mean[c], w, bias ? bias[c] : 0.f);       // ... and b: y = fma(x, w, b)
+}
+
+__global__ void __launch_bounds__(256)
+    k_bn_bwd_finalize(const float *partial, int nblk, int64_t N, int C, const float *save_mean, const float *save_invstd,
+                      const float *weight, const float *bias, float *d_weight, float *d_bias, float *coef,
+                      int accumulate) {
+  bn_bwd_finalize_group<false>(partial, nblk, N, C, save_mean, save_invstd, weight, bias, d_weight, d_bias, coef, accumulate, blockIdx.x);
 }
 
 template <int VEC, bool FROM_X>
@@ -551,11 +588,92 @@ __global__ void __launch_bounds__(256) k_bn_fold(const float *__restrict__ parti
   }
 }
 
+// fold AND finalize in one launch (round 5: the fold and the finalize were two launches of 5-7 us each in front of every batch-norm
+// apply pass whose statistics come from a convolution over >= 33 k rows -- 62 launch pairs per train step).  Workgroup (bx, f) folds
+// the columns bx * 128 .. + 127 of fold f exactly as k_bn_fold does, stores them write-through and draws the ticket of its column
+// range (words of the stream's control block, zero before and after); the LAST of a range's 64 workgroups to arrive finalizes those
+// 128 columns: each thread requests the 64 folded partials of its sum at once (agent-scope loads: the L2s of two XCDs are not
+// coherent) and adds them in bn_sum_partials' order -- bit-identical to k_bn_fold + k_bn_finalize / k_bn_bwd_finalize.  (The first
+// version let ONE workgroup finalize all column groups one after the other: 16 dependent round trips for 256 planes, 0.7 ms per
+// train step SLOWER than the two launches; this one: -0.17 ms, tools/ab_step.py BN_FOLD_FUSED=0,1: 44.82 / 44.86 -> 44.65 / 44.67.)
+extern "C++" {
+struct BnFinArgs {
+  int64_t N;
+  int Cp, col0, C, accumulate;
+  float *save_mean, *save_invstd, *running_mean, *running_var;
+  const float *weight, *bias;
+  float *d_weight, *d_bias, *out;  // out: wb (forward) / coef (backward)
+  float eps, momentum;
+};
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bn_fold_finalize(const float *__restrict__ partial, int nblk, float *__restrict__ folded,
+                                                          unsigned *__restrict__ tickets, BnFinArgs a) {
+  // workgroup (bx, f): columns bx * 128 .. + 127 -- thread t: column t & 127, its sum (t < 128) or its second sum (t >= 128) -- of
+  // fold f.  The 64 folds of a column range share a ticket; the last of them to arrive finalizes those 128 columns.
+  __shared__ int last_s;
+  __shared__ double sums[2][128];
+  const int f = blockIdx.y, Cp = a.Cp, cl = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int c = blockIdx.x * 128 + cl;
+  const bool live = c < Cp;
+  const int64_t idx = (int64_t)half * Cp + c;
+  if (live) {
+    double acc = 0;
+    int b = f;
+    for (; b + 7 * BN_FOLD < nblk; b += 8 * BN_FOLD) {  // (k_bn_fold's order)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u * BN_FOLD) * 2 * Cp + idx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; b < nblk; b += BN_FOLD) acc += (double)partial[(int64_t)b * 2 * Cp + idx];
+    __hip_atomic_store(folded + (int64_t)f * 2 * Cp + idx, (float)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = t == (unsigned)BN_FOLD - 1u;
+    if (last_s) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last_s) return;
+  asm volatile("" ::: "memory");
+  // the 64 folded partials of this thread's sum, all requested at once, added in bn_sum_partials' order (16 lanes of four, then
+  // the 16 lane sums): bit-identical to k_bn_fold + k_bn_finalize / k_bn_bwd_finalize
+  double s = 0;
+  if (live) {
+    float v[BN_FOLD];
+#pragma unroll
+    for (int j = 0; j < BN_FOLD; ++j) v[j] = __hip_atomic_load(folded + (int64_t)j * 2 * Cp + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int bl = 0; bl < 16; ++bl) {
+      double lane_sum = 0;
+#pragma unroll
+      for (int j = bl; j < BN_FOLD; j += 16) lane_sum += (double)v[j];
+      s += lane_sum;
+    }
+  }
+  sums[half][cl] = s;
+  __syncthreads();
+  if (half == 0 && live) {
+    if (BWD)
+      bn_bwd_finalize_col(c, sums[0][cl], sums[1][cl], a.N, a.C, a.save_mean, a.save_invstd, a.weight, a.bias, a.d_weight, a.d_bias, a.out,
+                          a.accumulate);
+    else
+      bn_finalize_col(a.col0 + c, sums[0][cl], sums[1][cl], a.N, a.C, a.save_mean, a.save_invstd, a.running_mean, a.running_var, a.weight,
+                      a.bias, a.eps, a.momentum, 1, a.out);
+  }
+}
+}  // extern "C++"
+constexpr int BN_TICKET_WORD = 32;  // first ticket word in the control block (SCN_SK_STATE_BYTES): the words the split launches'
+                                    // tickets use -- launches of one stream never overlap and each leaves them zero
+
 static int bn_forward_impl(const float *x, float *y, float *save_mean, float *save_invstd,
                            float *running_mean, float *running_var, const float *weight,
                            const float *bias, double eps, double momentum, int train, double leakiness,
                            int64_t N, int C, void *temp, int nseg, const int32_t *seg_ncols,
-                           const float *const *seg_partial, const int32_t *seg_nblk, hipStream_t stream) {
+                           const float *const *seg_partial, const int32_t *seg_nblk, hipStream_t stream, void *state = nullptr) {
   SCN_REQUIRE(C > 0 && N >= 0, "scn_bn_forward: bad shape");
   float *partial = (float *)temp;
   float *wb = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
@@ -568,7 +686,17 @@ static int bn_forward_impl(const float *x, float *y, float *save_mean, float *sa
       SCN_REQUIRE(seg_ncols[i] > 0 && seg_nblk[i] > 0 && seg_partial[i] != nullptr, "scn_bn_forward_ext: bad segment");
       const float *pp = seg_partial[i];
       int pn = seg_nblk[i];
-      if (pn > 4 * BN_FOLD) {  // many partials: fold them 64-fold first (the workspace's partial area is free here)
+      if (pn > 4 * BN_FOLD && state != nullptr) {  // many partials: fold them 64-fold and finalize, one launch (k_bn_fold_finalize)
+        float *folded = partial + (size_t)2 * BN_FOLD * col0;
+        BnFinArgs a{N, seg_ncols[i], col0, C, 0, save_mean, save_invstd, running_mean, running_var, weight, bias, nullptr, nullptr, wb,
+                    (float)eps, (float)momentum};
+        k_bn_fold_finalize<false><<<dim3((seg_ncols[i] + 127) / 128, BN_FOLD), 256, 0, stream>>>(pp, pn, folded,
+                                                                                                  (unsigned *)state + BN_TICKET_WORD, a);
+        SCN_CHECK_LAUNCH();
+        col0 += seg_ncols[i];
+        continue;
+      }
+      if (pn > 4 * BN_FOLD) {  // ... or, without a control block, in two (the workspace's partial area is free here)
         float *folded = partial + (size_t)2 * BN_FOLD * col0;
         k_bn_fold<<<dim3((2 * seg_ncols[i] + 255) / 256, BN_FOLD), 256, 0, stream>>>(pp, pn, seg_ncols[i], folded);
         SCN_CHECK_LAUNCH();
@@ -624,10 +752,10 @@ int scn_bn_forward_ext(const float *x, float *y, float *save_mean, float *save_i
                        float *running_mean, float *running_var, const float *weight,
                        const float *bias, double eps, double momentum, double leakiness,
                        int64_t N, int C, void *temp, int nseg, const int32_t *seg_ncols_host,
-                       const float *const *seg_partial_host, const int32_t *seg_nblk_host, void *stream_) {
+                       const float *const *seg_partial_host, const int32_t *seg_nblk_host, void *state, void *stream_) {
   SCN_REQUIRE(nseg >= 1 && nseg <= 8, "scn_bn_forward_ext: 1..8 segments");
   return bn_forward_impl(x, y, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, 1,
-                         leakiness, N, C, temp, nseg, seg_ncols_host, seg_partial_host, seg_nblk_host, as_stream(stream_));
+                         leakiness, N, C, temp, nseg, seg_ncols_host, seg_partial_host, seg_nblk_host, as_stream(stream_), state);
 }
 
 int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
@@ -679,7 +807,7 @@ int scn_bn_backward(const float *x, float *d_x, const float *y, float *d_out,
 int scn_bn_backward_ext(const float *x, float *d_x, const float *d_out, const float *save_mean,
                         const float *save_invstd, const float *weight, const float *bias, float *d_weight,
                         float *d_bias, double leakiness, int64_t N, int C, int flags, void *temp,
-                        const float *partial_in, int nblk_in, const float *d_x_add, int64_t ld_add, void *stream_) {
+                        const float *partial_in, int nblk_in, const float *d_x_add, int64_t ld_add, void *state, void *stream_) {
   const int accumulate = (flags >> 1) & 1;
   hipStream_t stream = as_stream(stream_);
   SCN_REQUIRE(C > 0 && N > 0, "scn_bn_backward_ext: bad shape");
@@ -707,15 +835,24 @@ int scn_bn_backward_ext(const float *x, float *d_x, const float *d_out, const fl
     else k_bn_bwd_stats<1, true><<<grid, 256, 0, stream>>>(x, nullptr, d_out, nullptr, save_mean, save_invstd, weight, bias, N, C, leak, partial);
     SCN_CHECK_LAUNCH();
     pp = partial;
-  } else if (pn > 4 * BN_FOLD) {  // one partial per 128-row tile / 32-pair block of the producing launch: fold them first
+  } else if (pn > 4 * BN_FOLD && state != nullptr) {  // one partial per 128-row tile / 32-pair block of the producing launch: fold
+    // them 64-fold and finalize, one launch (k_bn_fold_finalize)
+    BnFinArgs a{N, C, 0, C, accumulate, const_cast<float *>(save_mean), const_cast<float *>(save_invstd), nullptr, nullptr, weight, bias,
+                d_weight, d_bias, coef, 0.f, 0.f};
+    k_bn_fold_finalize<true><<<dim3((C + 127) / 128, BN_FOLD), 256, 0, stream>>>(pp, pn, partial, (unsigned *)state + BN_TICKET_WORD, a);
+    SCN_CHECK_LAUNCH();
+    pn = 0;
+  } else if (pn > 4 * BN_FOLD) {
     k_bn_fold<<<dim3((2 * C + 255) / 256, BN_FOLD), 256, 0, stream>>>(pp, pn, C, partial);
     SCN_CHECK_LAUNCH();
     pp = partial;
     pn = BN_FOLD;
   }
-  k_bn_bwd_finalize<<<(C + 15) / 16, 256, 0, stream>>>(pp, pn, N, C, save_mean, save_invstd, weight, bias, d_weight, d_bias,
-                                                        coef, accumulate);
-  SCN_CHECK_LAUNCH();
+  if (pn > 0) {
+    k_bn_bwd_finalize<<<(C + 15) / 16, 256, 0, stream>>>(pp, pn, N, C, save_mean, save_invstd, weight, bias, d_weight, d_bias,
+                                                          coef, accumulate);
+    SCN_CHECK_LAUNCH();
+  }
   const int64_t total = N * C;
   if (v4) k_bn_bwd_apply<4, true><<<grid_for(total / 4), 256, 0, stream>>>(x, d_out, d_x, save_mean, total / 4, C, coef, leak, d_x_add, lda);
   else k_bn_bwd_apply<1, true><<<grid_for(total), 256, 0, stream>>>(x, d_out, d_x, save_mean, total, C, coef, leak, d_x_add, lda);

@@ -403,6 +403,46 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
     assert_close(part[0], (want + res).sum(0), "column sums", scale=np.abs(want + res).sum(0).max())
 
 
+def test_bn_statistics_folded_and_finalized_by_one_launch(gpu, monkeypatch):
+    """round 5: the per-tile statistics a convolution hands to the batch norm next to it (> 256 partials) are folded and finalized
+    by ONE launch (k_bn_fold_finalize: a ticket in the stream's control block, the last workgroup finalizes) instead of two:
+    forward (mean, invstd, running statistics, y) and backward (dGamma, dBeta, dX) bitwise equal to the two-launch form, the
+    control block zero afterwards."""
+    from occuseg_amd import SCN
+    ci, co = 64, 64
+    m, size, grid, _, _ = _setup(gpu, seed=11, n=72000, batch=2, extent=60)
+    N = grid.n
+    assert (N + 127) // 128 > 256
+    rng = np.random.default_rng(3)
+    x = _t(rng.normal(size=(N, ci)), gpu)
+    w = _t(rng.normal(size=(27, ci, co)) * 0.05, gpu)
+    dy = _t(rng.normal(size=(N, co)), gpu)
+    gamma, beta = _t(rng.normal(size=co), gpu), _t(rng.normal(size=co), gpu)
+    e = torch.empty(0, device=gpu)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(SCN, "BN_FOLD_FUSED", fused)
+        out, sink = torch.empty(0, device=gpu), []
+        SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x, out, w, e, 1, stats_out=sink)
+        assert sink[0].size(0) > 256
+        y, sm, si = torch.empty(0, device=gpu), torch.empty(0, device=gpu), torch.empty(0, device=gpu)
+        rm, rv = torch.zeros(co, device=gpu), torch.ones(co, device=gpu)
+        SCN.BatchNormalization_updateOutput(out, y, sm, si, rm, rv, gamma, beta, 1e-4, 0.9, True, 0.2, _colstats=[(co, sink[0])])
+        # backward: the batch norm sat in front of a convolution whose dInput launch took the two reductions
+        link = SCN.BnLink(out, sm, si, gamma, beta, 0.2)
+        d_y = torch.empty(0, device=gpu)
+        SCN.SubmanifoldConvolution_backward(size, F3, m, y, d_y, dy, w, torch.zeros(27, co, co, device=gpu), e, 1, _bn_link=link)
+        part = link.take(d_y)
+        assert part is not None and part.size(0) > 256
+        dg, db, dx = torch.zeros(co, device=gpu), torch.zeros(co, device=gpu), torch.empty(0, device=gpu)
+        SCN.BatchNormalization_backward(out, dx, y, d_y, sm, si, rm, rv, gamma, beta, dg, db, 0.2, _rewrite_d_output=False,
+                                        _mask_from_x=True, _partials=part)
+        assert int(SCN._sk_state(gpu).view(torch.int32).abs().sum().item()) == 0
+        res[fused] = (y, sm, si, rm, rv, dg, db, dx)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+
+
 def test_stream_k_give_up_is_a_hard_error(gpu):
     """round-4 advisor: a stream-K piece that stops waiting for its seed slab (a bounded wait) computes from an unpublished slab and
     leaves the control block poisoned; nothing on the training path looked at the word that says so.  Now every batch's read-back
