@@ -1108,7 +1108,7 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
                 bnb = bn_link.struct()
             else:
                 stats_out.append(cstats)
-    if w_transposed and PREFETCH_AT_COARSE_LEVELS and kind == 2:
+    if w_transposed and PREFETCH_AT_COARSE_LEVELS and (kind == 2 or (kind == 4 and code % 100 > 1)):
         # the backward pass has reached the coarse levels: the point a rulebook prefetch waits for (prefetch_input)
         mk = _COARSE_MARK.get(inp.device.index)
         if mk is None:

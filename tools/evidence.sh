@@ -54,7 +54,7 @@ GUARD_POISON=0xEF timeout 600 python3 -X faulthandler tools/guard_run.py 2> $E/g
 python3 tools/check_scratch.py > $E/check_scratch.txt 2>&1
 # the default bench line once more, now that the traffic of THESE kernel sources exists (bench.py refuses a traffic file
 # measured on other sources): this is the line that goes to profiles/rNN_bench.json
-cp $E/traffic.json profiles/r04_traffic.json
+cp $E/traffic.json profiles/r05_traffic.json
 python3 bench.py > $E/bench_final.json 2>> $E/bench.err
 # keep the merge small: raw traces stay on the box
 find $E -name "*.db" -delete

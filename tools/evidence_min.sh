@@ -12,7 +12,7 @@ cp $(find $E/stats_overlap -name "*kernel_stats.csv" | head -1) $E/kernel_stats_
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/fetch -- python3 bench.py --no-cpu-baseline --no-dw-side-stream --steps 2 --warmup 1 > /dev/null 2> $E/fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/write -- python3 bench.py --no-cpu-baseline --no-dw-side-stream --steps 2 --warmup 1 > /dev/null 2> $E/write.err
 python3 tools/pmc_traffic.py $E/fetch $E/write $E/traffic.json > $E/traffic.log 2>&1
-cp $E/traffic.json profiles/r04_traffic.json
+cp $E/traffic.json profiles/r05_traffic.json
 python3 bench.py > $E/bench.json 2> $E/bench.err
 python3 bench.py --no-cpu-baseline --steps 20 > $E/bench20.json 2>> $E/bench.err
 find $E -name "*.db" -delete
