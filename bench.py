@@ -300,6 +300,7 @@ def main():
     dw_side = bool(SCN.DW_SIDE_STREAM) and not args.no_dw_side_stream
     SCN.DW_SIDE_STREAM = dw_side
     SCN.PROFILE_KINDS = ("mm",)
+    SCN.PROFILE_FUSED.clear()
     if rank == 0:  # ~230 events per profiled step (matrix launches) + ~900 for the extra step, created now
         SCN.warm_event_pool(260 * len(range(0, args.steps, args.event_every)) + 1000)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -403,6 +404,10 @@ def main():
             k = {"launches_per_step": cnt / sampled, "ms_per_step": 1e3 * secs / sampled, "avg_ms": 1e3 * secs / cnt,
                  "algo_GBs": nbytes / secs / 1e9, "algo_bytes_per_launch": algo_pl,
                  "counted_bytes_per_launch": cb, "counted_over_algorithmic": (cb / algo_pl) if cb else None,
+                 # bytes these launches read on top of the formula because a shortcut / a batch norm's backward sums are fused
+                 # into them (SCN.PROFILE_FUSED): traffic beyond algorithmic + fused is re-reading, traffic beyond algorithmic is not
+                 "fused_extra_bytes_per_launch": SCN.PROFILE_FUSED.get(kname, 0.0) / cnt,
+                 "counted_over_algorithmic_plus_fused": (cb / (algo_pl + SCN.PROFILE_FUSED.get(kname, 0.0) / cnt)) if cb else None,
                  "hbm_bytes": "counted" if (cb and cb < algo_pl) else "algorithmic",
                  "hbm_frac": use * cnt / secs / 1e9 / HBM_PEAK_GBS}
             if k["hbm_frac"] > 1.0:  # (only without a counter file for these sources: the formula's over-count, not a rate)

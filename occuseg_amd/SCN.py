@@ -26,6 +26,10 @@ GRANULE = 32  # SCN_TILE_GRANULE
 # used by bench.py to time the dominant kernels with HIP events on the launch stream.
 PROFILE = None
 PROFILE_KINDS = ("mm", "bn", "rules", "io")  # which launches carry events: matrix kernels / batch norm / rule build / io
+# kernel name -> bytes the profiled launches read ON TOP of SURVEY 8d's formula because something is fused into them: the
+# shortcut's rows (`residual`) and, for a dInput launch that takes a batch norm's backward sums, that batch norm's x.  bench.py
+# prints them beside the algorithmic bytes: traffic above (algorithmic + fused) is re-reading, traffic above algorithmic alone is not.
+PROFILE_FUSED = {}
 
 
 _EVENT_POOL = []  # timing events created ahead of the timed region (creating one inside it costs far more than recording)
@@ -1142,6 +1146,9 @@ def _conv(inp, out, weight, bias, rb, in_col, out_col, n_out, w_transposed=False
             name = "conv_stem"  # k_conv_stem: the narrow-input layer as a GEMM on the matrix cores
         _prof_end(ev, name, 2.0 * R * Ci * Co, 4.0 * (R * Ci + n_out * Co) + 8.0 * R + 4.0 * K * Ci * Co,
                   (K, n_out, Ci, Co, int(w_transposed), in_col))
+        fused = 4.0 * n_out * Co * (int(residual is not None) + int(bnb is not None))
+        if fused:
+            PROFILE_FUSED[name] = PROFILE_FUSED.get(name, 0.0) + fused
 
 
 # ---- dWeight on a second HIP stream.  dInput and dWeight of a layer both consume dOut and nothing in backward consumes
