@@ -66,3 +66,55 @@ for rnd in range(3):
         res.setdefault(mode, []).append(e0.elapsed_time(e1) / 10)
 for mode, v in res.items():
     print("%-9s %s  min %.2f ms per step" % (mode, " ".join("%.2f" % t for t in v), min(v)))
+
+
+# ---- which PART of the build costs the step what: the step adopts a saved Metadata (no build of its own) and a partial build runs
+# beside it as pure load, where the prefetch would run (side stream, behind the backward pass' coarse-level mark)
+def load_part(part, coords):
+    side = SCN._SIDE_STREAMS.get((dev, SCN.PREFETCH_PRIORITY))
+    if side is None:
+        side = SCN._SIDE_STREAMS[(dev, SCN.PREFETCH_PRIORITY)] = torch.cuda.Stream(device=dev, priority=SCN.PREFETCH_PRIORITY)
+    mark = SCN._COARSE_MARK.get(dev.index)
+    if mark is not None and mark[1] == SCN._step_count(dev):
+        side.wait_event(mark[0])
+    size = torch.tensor([4096] * 3)
+    f3, f2 = torch.tensor([3, 3, 3]), torch.tensor([2, 2, 2])
+    with torch.cuda.stream(side):
+        plans = dict(SCN._PLANS)
+        SCN._PLANS.clear()  # (no replay: build exactly what is asked below)
+        md = SCN.Metadata_3()
+        md.inputLayer(size, coords, 0, 4, dev, _in_prefetch=True)  # grid of scale 0 (sort of the points)
+        if part in ("grids", "all"):
+            for lv in range(5):
+                md.getRuleBook(size, size // 2, f2, f2)
+                size = size // 2
+        if part in ("sub0", "all"):
+            size = torch.tensor([4096] * 3)
+            for lv in range(6 if part == "all" else 1):
+                md.getSubmanifoldRuleBook(size, f3)
+                size = size // 2
+        SCN._PLANS.clear()
+        SCN._PLANS.update(plans)
+    return md
+
+
+res2 = {}
+for rnd in range(2):
+    for part in ("none", "grid0", "grids", "sub0", "all"):
+        SCN._PREFETCHED.clear()
+        saved.clear()
+        keep = []
+        times = []
+        for it in range(14):
+            if it == 4:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+            step("reuse")
+            if part != "none":
+                keep = [load_part(part, batches[counter[0] % 2][0])]
+        e1.record()
+        torch.cuda.synchronize()
+        res2.setdefault(part, []).append(e0.elapsed_time(e1) / 10)
+for part, v in res2.items():
+    print("reuse + %-6s %s  min %.2f ms per step" % (part, " ".join("%.2f" % t for t in v), min(v)))
