@@ -163,7 +163,7 @@ int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes,
  *           error flag -- compare N with plan->N), then [levels][27] submanifold list lengths, then [levels][8] strided list
  *           lengths: ONE device-to-host copy of 4 * levels * 37 bytes hands the host everything it needs to read.
  *           Everything in front of `scratch` is a result; the scratch part may be freed when the stream has passed the call.
- * scn_batch_layout_query is host-only arithmetic. */
+ * scn_batch_layout_query launches nothing (it asks rocPRIM for the sort's workspace size, which needs a device to be present). */
 #define SCN_BATCH_MAX_LEVELS 12
 typedef struct {
   int32_t levels;                          /* 1 .. SCN_BATCH_MAX_LEVELS */

@@ -278,3 +278,46 @@ def test_grid_chain_counts_abi(gpu):
             cc[:, :3] >>= l
             assert n[l] == len(np.unique(cc, axis=0)), (P, l)
     assert lib.scn_grid_chain_temp_bytes(100, 13) == 0 and lib.scn_grid_chain_temp_bytes(0, 2) == 0
+
+
+def test_batch_layout_query(gpu):
+    """scn_batch_layout_query (ABI v6): the arena of a batch's grids and rulebooks -- offsets 256-byte aligned, disjoint, in order,
+    results in front of the scratch; bad plans are refused.  (No launch, but rocPRIM's workspace query wants a device.)"""
+    import ctypes
+    from occuseg_amd import _lib
+    lib = _lib.load()
+    plan = _lib.BatchPlan()
+    plan.levels, plan.coords_dtype, plan.ncols, plan.P = 3, 1, 4, 100000
+    for l, n in enumerate((60000, 17000, 4000)):
+        plan.N[l], plan.sub[l], plan.strided[l] = n, 1, 1 if l < 2 else 0
+    lo = _lib.BatchLayout()
+    assert lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)) == 0
+    spans = [(lo.small, 3 * 37 * 4), (lo.order, 4 * 100000), (lo.site_of_row, 4 * 100000), (lo.site_start, 4 * 100001)]
+    for l, n in enumerate((60000, 17000, 4000)):
+        g = (n + 31) // 32
+        cap = int(lo.hash_cap[l])
+        assert cap == lib.scn_hash_capacity(n)
+        spans += [(lo.coords[l], 16 * n), (lo.keys[l], 8 * n), (lo.hash_keys[l], 8 * cap), (lo.hash_vals[l], 4 * cap),
+                  (lo.sub_rules[l], 27 * n * 8), (lo.sub_bases[l], 27 * (g + 1) * 4)]
+        if l < 2:
+            gc = ((17000, 4000)[l] + 31) // 32
+            spans += [(lo.str_rules[l], 8 * n * 8), (lo.str_bases_fine[l], 8 * (g + 1) * 4), (lo.str_bases_coarse[l], 8 * (gc + 1) * 4)]
+        else:
+            assert lo.str_rules[l] == lo.str_bases_fine[l] == lo.str_bases_coarse[l] == -1
+    spans.sort()
+    for (a, na), (b, _) in zip(spans, spans[1:]):
+        assert a % 256 == 0 and a >= 0 and a + na <= b, (a, na, b)
+    assert spans[-1][0] + spans[-1][1] <= lo.scratch <= lo.total and lo.scratch % 256 == 0
+    # the scratch holds at least the level-0 grid build's workspace and the largest neighbour table
+    assert lo.total - lo.scratch >= lib.scn_grid_build_temp_bytes(100000) + 8 * 100000 + 27 * 60000 * 4
+    for l in range(3, _lib.BATCH_MAX_LEVELS):
+        assert lo.coords[l] == -1 and lo.hash_cap[l] == 0
+    # refused: no levels, site counts that grow, a strided rulebook without a next scale
+    plan.levels = 0
+    assert lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)) != 0
+    plan.levels = 3
+    plan.N[1] = 70000
+    assert lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)) != 0 and b"non-increasing" in lib.scn_last_error()
+    plan.N[1] = 17000
+    plan.strided[2] = 1
+    assert lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)) != 0
