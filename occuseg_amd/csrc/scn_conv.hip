@@ -2591,16 +2591,22 @@ template <int NB>
 __global__ void __launch_bounds__(64)
     k_conv_expand(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ Wp,
                   const float *__restrict__ bias, const float *__restrict__ residual, StatsArg colstats, const int2 *__restrict__ rules, const int32_t *__restrict__ counts,
-                  int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes, unsigned wp_bytes) {
+                  int K, int64_t stride, int in_col, int Ci, int Co, int ncb, unsigned in_bytes, unsigned wp_bytes, int nblk_xcd = 0) {
   // chunks of 32 reduction planes: 2 x (8 row + 32 weight) registers in flight + 32 accumulators keep the NB = 1 wave at
   // ~150 VGPRs = three waves per SIMD (with 64-plane chunks it needed 272: one wave per SIMD, and a launch of
   // single-chunk waves -- NiN 64 -> 128 on 600k rows -- ran at a third of the speed of the tile kernel it replaced)
   constexpr int CK = 32, NS16 = 2, COS = 4, PB = 32 * NB;
   const int lane = threadIdx.x;
   const int li = lane & 15, lq = lane >> 4;
-  // (list, block of PB pairs, plane block) of this wave: blocks are numbered list after list
-  int blk = blockIdx.x / ncb;
-  const int co0 = (blockIdx.x % ncb) * 64;
+  // (list, block of PB pairs, plane block) of this wave: blocks are numbered list after list.
+  // nblk_xcd > 0 (round 5): the ncb plane blocks of one pair block sit on ONE XCD, next to each other in its queue (workgroup b
+  // runs on XCD b % 8) -- numbered blockIdx.x / ncb, blockIdx.x % ncb they went to ncb different XCDs and every one of them fetched
+  // the block's input rows through the fabric: NiN 256 -> 128 on level 1 read its input 2.07 times, 384 -> 192 on level 2 3.2 times
+  // (profiles/r05_expand_traffic_by_kind.txt; the level-0 launches, one plane block, 1.0)
+  const int pblk = nblk_xcd > 0 ? (((int)blockIdx.x >> 3) / ncb) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x / ncb;
+  if (nblk_xcd > 0 && pblk >= nblk_xcd) return;  // (the grid is padded to whole groups of eight pair blocks)
+  int blk = pblk;
+  const int co0 = (nblk_xcd > 0 ? ((int)blockIdx.x >> 3) % ncb : (int)blockIdx.x % ncb) * 64;
   int k = 0, cnt = 0;
   for (; k < K; ++k) {
     cnt = counts[k];
@@ -2610,7 +2616,7 @@ __global__ void __launch_bounds__(64)
   }
   if (k >= K) {  // past the end of the lists: nothing to compute, but this block's statistics slot must read zero
     if (colstats.out != nullptr) {
-      const int64_t pb = blockIdx.x / ncb;
+      const int64_t pb = pblk;
       colstats.out[(pb * 2 + 0) * Co + co0 + lane] = 0.f;
       colstats.out[(pb * 2 + 1) * Co + co0 + lane] = 0.f;
     }
@@ -2693,7 +2699,7 @@ __global__ void __launch_bounds__(64)
   // column statistics of the wave's PB output rows (colstats [waves][2][Co]; waves past the end of the lists
   // wrote zeros above): sum over the 16 pairs of a group = butterfly over the 16 lanes that share lq
   if (colstats.out != nullptr) {
-    const int64_t pb = blockIdx.x / ncb;
+    const int64_t pb = pblk;
 #pragma unroll
     for (int q = 0; q < COS; ++q) {
       floatx4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
@@ -3748,6 +3754,8 @@ SCN_KNOB g_dw_direct = 0;       // tuning key 12: 1 = k_dw_direct (no LDS stagin
                                 // step is 1.8 ms SLOWER with it (50.3 against 48.4 ms, tools/ab_step.py tune12=0,1): off
 SCN_KNOB g_conv_expand_nb = 1;  // tuning key 14: blocks of 32 pairs per wave of k_conv_expand (1, 2 or 4).  Measured (round 3, 20 launches
                                 // per step): 1.81 / 1.83 / 2.21 ms -- the weight re-reads are not what bounds the kernel
+SCN_KNOB g_conv_expand_xcd = 1;  // tuning key 27: 0 = the plane blocks of a pair block of k_conv_expand numbered blockIdx.x % ncb (eight XCDs fetch the
+                                 // same rows), 1 = on one XCD
 SCN_KNOB g_conv_expand_persist = 0;  // tuning key 21: 1 = k_conv_expand_p (persistent waves, pipelined across blocks; tuning library only).  Round 4:
                                      // bit-identical, 0-17 % faster per launch in isolation (tools/ab_expand.py), 0.3 ms SLOWER per train step
                                      // (46.73 against 46.40 ms, tools/ab_step.py tune21=0,1): off
@@ -4191,6 +4199,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 23) { g_dw_fused = value; return 0; }
   if (key == 24) { g_dw_k8 = value; return 0; }
   if (key == 25) { g_dw_big = value; return 0; }
+  if (key == 27) { g_conv_expand_xcd = value; return 0; }
   if (key == 21) { g_conv_expand_persist = value; return 0; }
   if (key == 22) { g_conv_sk_static = value; return 0; }
   if (key == 20) { SCN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sk_prio_dev), &value, sizeof(int))); return 0; }
@@ -4324,9 +4333,12 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
       const int ncb = Co / 64;
       const int64_t nblk = expand_waves(n_out, K);  // every output row in exactly one pair: sum_k ceil(count_k / PB) <= this
       const unsigned in_bytes = (unsigned)((n_in - 1) * (colstats.ldi ? colstats.ldi : Ci) * 4 + Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
+      // (the plane blocks of a pair block on one XCD: the grid padded to whole groups of eight pair blocks)
+      const bool xcd = g_conv_expand_xcd && ncb > 1 && nblk < ((int64_t)1 << 27);
+      const int64_t grid_e = xcd ? (nblk + 7) / 8 * 8 * ncb : nblk * ncb;
 #define SCN_LAUNCH_EXPAND(NB_)                                                                                              \
-  k_conv_expand<NB_><<<(unsigned)(nblk * ncb), 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, \
-                                                               stride, in_col, Ci, Co, ncb, in_bytes, wp_bytes)
+  k_conv_expand<NB_><<<(unsigned)grid_e, 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, \
+                                                               stride, in_col, Ci, Co, ncb, in_bytes, wp_bytes, xcd ? (int)nblk : 0)
 #ifdef SCN_TUNING
       if (g_conv_expand_persist && expand_nb() == 1 && nblk * ncb < ((int64_t)1 << 30)) {
         // persistent waves (two per SIMD: 237 registers), pipelined across blocks
