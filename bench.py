@@ -551,7 +551,8 @@ def main():
                      "tflops": v[2] / v[1] / 1e9 if v[2] else None, "algo_GBs": v[3] / v[1] / 1e6}
                     for k, v in sorted(per_shape.items(), key=lambda kv: -kv[1][1])]
             # ... and every matrix launch of the profiled steps in issue order (which launch of a shape is the slow one)
-            seq = [{"kernel": k, "shape": list(sh) if sh else None, "ms": ms / per, "tflops": fl / ms / 1e9 if fl else None}
+            seq = [{"kernel": k, "shape": list(sh) if sh else None, "ms": ms / per, "tflops": fl / ms / 1e9 if fl else None,
+                    "bytes": nb / per}
                    for k, sh, ms, fl, nb, per in launches if fl]
             json.dump({"per_shape": rows, "in_order": seq}, open(args.dump_launches, "w"), indent=0)
         if world == 1 and not args.no_cpu_baseline:
