@@ -2603,16 +2603,71 @@ __global__ void __launch_bounds__(64)
   // runs on XCD b % 8) -- numbered blockIdx.x / ncb, blockIdx.x % ncb they went to ncb different XCDs and every one of them fetched
   // the block's input rows through the fabric: NiN 256 -> 128 on level 1 read its input 2.07 times, 384 -> 192 on level 2 3.2 times
   // (profiles/r05_expand_traffic_by_kind.txt; the level-0 launches, one plane block, 1.0)
-  const int pblk = nblk_xcd > 0 ? (((int)blockIdx.x >> 3) / ncb) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x / ncb;
-  if (nblk_xcd > 0 && pblk >= nblk_xcd) return;  // (the grid is padded to whole groups of eight pair blocks)
-  int blk = pblk;
-  const int co0 = (nblk_xcd > 0 ? ((int)blockIdx.x >> 3) % ncb : (int)blockIdx.x % ncb) * 64;
-  int k = 0, cnt = 0;
-  for (; k < K; ++k) {
-    cnt = counts[k];
-    const int nb = (cnt + PB - 1) / PB;
-    if (blk < nb) break;
-    blk -= nb;
+  // ... and (K > 1: deconvolution, strided-convolution dInput) the pair blocks of ONE XCD are consecutive in a sequence that
+  // INTERLEAVES the lists: block r of list 0, block r of list 1, ..., block r + 1 of list 0, ...  Every list is sorted by fine and
+  // by coarse site, so block r of the eight parity lists gathers the same coarse neighbourhood: numbered list after list, the
+  // up to eight children of a coarse row were fetched by eight launches' worth of blocks far apart (one fabric read per PAIR);
+  // interleaved and on one XCD they meet in its L2.  XCDs take chunks of 64 sequence positions round robin (as k_conv_tile4's
+  // tiles), the ragged end one contiguous range each.
+  int pblk;
+  int cbi;
+  if (nblk_xcd > 0) {
+    const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    const int jj = j / ncb;          // position among this XCD's pair blocks
+    cbi = j % ncb;
+    const int total = nblk_xcd, per_x = (total + 7) >> 3;
+    constexpr int CH = 64;
+    const int full = (total / (8 * CH)) * (8 * CH);
+    if (jj >= per_x) return;
+    const int b8 = jj * 8 + x;       // (this workgroup's index if the pair blocks were dealt round robin)
+    if (b8 < full) {
+      pblk = ((jj / CH) * 8 + x) * CH + jj % CH;
+    } else {
+      const int rest = total - full, j2 = jj - full / 8, q = rest >> 3, r = rest & 7;
+      if (j2 >= (x < r ? q + 1 : q)) return;
+      pblk = full + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j2;
+    }
+  } else {
+    pblk = (int)blockIdx.x / ncb;
+    cbi = (int)blockIdx.x % ncb;
+  }
+  const int co0 = cbi * 64;
+  int k = 0, cnt = 0, blk = pblk;
+  if (nblk_xcd > 0 && K > 1 && K <= 8) {
+    // sequence position pblk -> (list k, block blk of it): rounds r = 0, 1, ...; round r holds one block of every list that has
+    // more than r blocks, in list order.  before(r) = sum_k min(nb_k, r) blocks lie in front of round r.
+    int nbk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nbmax = 0;
+    for (int kk = 0; kk < K && kk < 8; ++kk) {
+      nbk[kk] = (counts[kk] + PB - 1) / PB;
+      nbmax = max(nbmax, nbk[kk]);
+    }
+    auto before = [&](int r) __attribute__((always_inline)) {
+      int t = 0;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t += min(nbk[kk], r);
+      return t;
+    };
+    if (pblk >= before(nbmax)) {
+      k = K;  // past the end of the lists
+    } else {
+      int lo = 0, hi = nbmax - 1;  // the largest r with before(r) <= pblk
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (before(mid) <= pblk) lo = mid; else hi = mid - 1;
+      }
+      int within = pblk - before(lo);
+      for (k = 0; k < K; ++k)
+        if (nbk[k] > lo && within-- == 0) break;
+      blk = lo;
+      cnt = counts[k];
+    }
+  } else {
+    for (; k < K; ++k) {
+      cnt = counts[k];
+      const int nb = (cnt + PB - 1) / PB;
+      if (blk < nb) break;
+      blk -= nb;
+    }
   }
   if (k >= K) {  // past the end of the lists: nothing to compute, but this block's statistics slot must read zero
     if (colstats.out != nullptr) {
@@ -3754,7 +3809,7 @@ SCN_KNOB g_dw_direct = 0;       // tuning key 12: 1 = k_dw_direct (no LDS stagin
                                 // step is 1.8 ms SLOWER with it (50.3 against 48.4 ms, tools/ab_step.py tune12=0,1): off
 SCN_KNOB g_conv_expand_nb = 1;  // tuning key 14: blocks of 32 pairs per wave of k_conv_expand (1, 2 or 4).  Measured (round 3, 20 launches
                                 // per step): 1.81 / 1.83 / 2.21 ms -- the weight re-reads are not what bounds the kernel
-SCN_KNOB g_conv_expand_xcd = 1;  // tuning key 27: 0 = the plane blocks of a pair block of k_conv_expand numbered blockIdx.x % ncb (eight XCDs fetch the
+SCN_KNOB g_conv_expand_xcd = 2;  // tuning key 27 (2 = also launches of ONE plane block whose rulebook has 2..8 lists: their lists interleaved): 0 = the plane blocks of a pair block of k_conv_expand numbered blockIdx.x % ncb (eight XCDs fetch the
                                  // same rows), 1 = on one XCD
 SCN_KNOB g_conv_expand_persist = 0;  // tuning key 21: 1 = k_conv_expand_p (persistent waves, pipelined across blocks; tuning library only).  Round 4:
                                      // bit-identical, 0-17 % faster per launch in isolation (tools/ab_expand.py), 0.3 ms SLOWER per train step
@@ -4334,7 +4389,7 @@ int scn_conv_forward(const float *in, float *out, const float *W, int w_transpos
       const int64_t nblk = expand_waves(n_out, K);  // every output row in exactly one pair: sum_k ceil(count_k / PB) <= this
       const unsigned in_bytes = (unsigned)((n_in - 1) * (colstats.ldi ? colstats.ldi : Ci) * 4 + Ci * 4), wp_bytes = (unsigned)((int64_t)K * Ci * Co * 4);
       // (the plane blocks of a pair block on one XCD: the grid padded to whole groups of eight pair blocks)
-      const bool xcd = g_conv_expand_xcd && ncb > 1 && nblk < ((int64_t)1 << 27);
+      const bool xcd = g_conv_expand_xcd && (ncb > 1 || (K > 1 && K <= 8 && g_conv_expand_xcd > 1)) && nblk < ((int64_t)1 << 27);
       const int64_t grid_e = xcd ? (nblk + 7) / 8 * 8 * ncb : nblk * ncb;
 #define SCN_LAUNCH_EXPAND(NB_)                                                                                              \
   k_conv_expand<NB_><<<(unsigned)grid_e, 64, 0, stream>>>(in, out, Wp, bias, residual, colstats, (const int2 *)rules, counts, K, \
