@@ -66,6 +66,73 @@ def host_cores():
     return max(1, n)
 
 
+def device_pass(net, scn, batch):
+    """One forward + backward (loss = sum of the outputs) of `net` through the HIP path on `batch`, kept for the comparison with
+    the reference's compiled CPU loops (parity_fullsize): output, every parameter gradient in module order, and the sign of
+    every batch norm's output as the device computed it (the CPU backward pass then differentiates the same piecewise-linear
+    function: tests/helpers.py device_masks).  Product code only; nothing here touches oracle/."""
+    masks, hooks = [], []
+    for mod in net.modules():
+        if isinstance(mod, scn.BatchNormalization):
+            hooks.append(mod.register_forward_hook(lambda md, inp, out: masks.append((out.features.detach() > 0).cpu().numpy())))
+    for p in net.parameters():
+        p.grad = None
+    try:
+        out = net(batch)
+        out.sum().backward()
+    finally:
+        for h in hooks:
+            h.remove()
+    torch.cuda.synchronize()
+    grads = []
+    for mod in net.modules():
+        for name, p in mod._parameters.items():
+            if p is not None:
+                grads.append(("%s.%s" % (type(mod).__name__, name), tuple(p.shape), p.grad.detach().cpu().numpy()))
+    res = {"out": out.detach().cpu().numpy(), "grads": grads, "masks": masks}
+    for p in net.parameters():
+        p.grad = None
+    return res
+
+
+def compare_passes(dev_pass, cpu_out, cpu_grads_in_order, mask_flips, mask_total):
+    """parity_fullsize: the HIP pass against the reference's compiled loops on the same batch and parameters.  `*_max_rel`
+    = max |got - want| / max |want| per tensor (the bar of north_star: 1e-4; tests/helpers.py assert_close), the worst
+    tensor named; `elementwise_rel_p99` / `_p999`: quantiles of |got - want| / |want| over the output elements with
+    |want| >= 1e-3 max |want| (elements that cancel to ~0 cannot be held to a per-element ratio)."""
+    got, want = dev_pass["out"].astype(np.float64), np.asarray(cpu_out, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(float(np.abs(want).max()), 1e-30)
+    diff = np.abs(got - want)
+    sel = np.abs(want) >= 1e-3 * scale
+    ew = np.sort((diff[sel] / np.abs(want[sel])).ravel())
+    res = {"forward_max_rel": float(diff.max()) / scale, "forward_shape": list(got.shape),
+           "elementwise_rel_p50": float(ew[len(ew) // 2]) if len(ew) else None,
+           "elementwise_rel_p99": float(ew[int(0.99 * (len(ew) - 1))]) if len(ew) else None,
+           "elementwise_rel_p999": float(ew[int(0.999 * (len(ew) - 1))]) if len(ew) else None,
+           "elementwise_rel_max": float(ew[-1]) if len(ew) else None,
+           "elementwise_over": "output elements with |want| >= 1e-3 max|want| (%d of %d)" % (int(sel.sum()), int(sel.size))}
+    worst, worst_name, per = 0.0, None, []
+    assert len(dev_pass["grads"]) == len(cpu_grads_in_order), (len(dev_pass["grads"]), len(cpu_grads_in_order))
+    for (name, shape, g), (cname, cg) in zip(dev_pass["grads"], cpu_grads_in_order):
+        assert name == cname, (name, cname)
+        cg = np.asarray(cg, np.float64).reshape(shape)
+        sc = max(float(np.abs(cg).max()), 1e-30)
+        e = float(np.abs(g.astype(np.float64) - cg).max()) / sc
+        per.append(e)
+        if e >= worst:
+            worst, worst_name = e, "%s %s (tensor %d of %d)" % (name, list(shape), len(per), len(cpu_grads_in_order))
+    per = np.sort(np.array(per))
+    res.update({"grad_max_rel": worst, "worst_tensor": worst_name, "grad_tensors": int(len(per)),
+                "grad_median_rel": float(per[len(per) // 2]),
+                "grad_masks": "the CPU backward pass ran over the device's activation masks (sign of every batch norm's output as the "
+                              "HIP forward pass computed it): %d of %d mask elements differ from the CPU forward pass' own"
+                              % (mask_flips, mask_total),
+                "mask_flips": int(mask_flips), "mask_elements": int(mask_total),
+                "tolerance": 1e-4, "ok": bool(res["forward_max_rel"] <= 1e-4 and worst <= 1e-4)})
+    return res
+
+
 def _cpu_once(scn, m, target_sites, seed):
     from occuseg_amd import scenes
     from oracle import torch_ref
@@ -95,7 +162,7 @@ def cpu_baseline_port(m, target_sites, seed, budget_s=20.0):
                       "mm + index_select/index_add_, rulebook build excluded" % (seed, n0, m, dt)}
 
 
-def cpu_baseline(m, scenes_per_gpu, target_sites, seed0, iters=1):
+def cpu_baseline(m, scenes_per_gpu, target_sites, seed0, iters=1, dev_pass=None):
     """the reference's OWN compiled CPU loops (oracle/_ref/libscn_ref.so = sparseconvnet/SCN/CPU/
     {Convolution,BatchNormalization,IOLayers}.cpp built from where they lie; oracle/ref_net.py walks the network) on the
     host cores of this box: one fwd+bwd of the same network over the SAME batch the GPU is timed on (4 scenes, seeds
@@ -114,16 +181,35 @@ def cpu_baseline(m, scenes_per_gpu, target_sites, seed0, iters=1):
     seeds = [seed0 + i for i in range(scenes_per_gpu)]
     coords, feats = scenes.batch(seeds, target_sites)
     ctx, best, groups = None, None, None
-    for _ in range(max(1, iters)):
-        _out, _g, sec, ctx = ref_net.forward_backward(net, coords, feats, threads=cores, ctx=ctx)
+    # parity_fullsize (dev_pass = the HIP path's output and gradients on this very batch with these very parameters, taken
+    # before the warm-up): the same forward + backward the clock is on, run over the device's activation masks
+    masks = None
+    if dev_pass is not None:
+        bns = [mod for mod in net.modules() if isinstance(mod, scn.BatchNormalization)]
+        assert len(bns) == len(dev_pass["masks"])
+        masks = {id(mod): mk for mod, mk in zip(bns, dev_pass["masks"])}
+    parity = None
+    for it in range(max(1, iters)):
+        _out, _g, sec, ctx = ref_net.forward_backward(net, coords, feats, threads=cores, ctx=ctx, masks=masks)
         if best is None or sec["total"] < best:
             best, groups = sec["total"], sec
+        if dev_pass is not None and it == 0:
+            order = []
+            for mod in net.modules():
+                for name, p in mod._parameters.items():
+                    if p is not None:
+                        order.append(("%s.%s" % (type(mod).__name__, name), _g[(id(mod), name)]))
+            parity = compare_passes(dev_pass, _out, order, ctx.mask_flips, ctx.mask_total)
+            parity["against"] = ("oracle/_ref: the reference's compiled CPU loops (sparseconvnet/SCN/CPU/{Convolution,BatchNormalization,"
+                                 "IOLayers}.cpp), float32, same batch (%d scenes, %d active voxels), same seed-0 parameters"
+                                 % (len(seeds), ctx.grid0.n))
+        del _out, _g
     n_all = ctx.grid0.n
-    del ctx
+    del ctx, masks
     c1, f1 = scenes.batch(seeds[:1], target_sites)
     _out, _g, sec1, ctx1 = ref_net.forward_backward(net, c1, f1, threads=1)
     n_one = ctx1.grid0.n
-    return {"value": n_all / best, "unit": "active-voxels/s", "cores": cores, "kind": "reference",
+    return {"value": n_all / best, "unit": "active-voxels/s", "cores": cores, "kind": "reference", "parity_fullsize": parity,
             "one_thread": {"value": n_one / sec1["total"], "cores": 1, "seconds": sec1["total"], "active_voxels": n_one,
                            "sample": "scene %d of the batch" % seeds[0]},
             "seconds": best, "seconds_by_group": groups, "active_voxels": n_all, "iterations": max(1, iters),
@@ -132,6 +218,102 @@ def cpu_baseline(m, scenes_per_gpu, target_sites, seed0, iters=1):
                       "rule_index_add_ per offset, BatchNormalization_Forward/BackwardPass, InputLayer passes; "
                       "oracle/_ref); one scene at 1 thread beside it; rulebook build excluded"
                       % (len(seeds), seeds[0], seeds[-1], n_all, m, best, cores)}
+
+
+def _timeit(fn, iters, warm):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def other_configs(scn, dev, which=("cfg2", "cfg5a", "cfg5b")):
+    """BASELINE.json configs[1] and configs[4] on this GPU, after the timed region (N = 1 only, a few seconds): cfg2 = ONE
+    ~150k-voxel scene through the m32 UNet, forward only (train-mode batch statistics), alone and with the next scene's rule
+    build prefetched as a serving loop would; cfg5a / cfg5b = ONE SubmanifoldConvolution 128 -> 128 over 2 M active voxels
+    (5a: Bernoulli 160^3, nu ~ 13.7; 5b: solid 126^3, nu ~ 26.6): forward, dInput, dWeight and the rulebook build, in TFLOP/s
+    (2 R C_i C_o) and algorithmic GB/s (SURVEY.md section 8d's formulas).  tools/run_configs.py prints the same dict."""
+    from occuseg_amd import SCN, _lib, scenes
+    res = {}
+    if "cfg2" in which:
+        torch.manual_seed(0)
+        coords, feats = scenes.batch([1000], 150000)
+        net = build_net(scn, 32).to(dev)
+        inp = [torch.from_numpy(coords).to(dev), torch.from_numpy(feats).to(dev), None, 1]
+        input_layer = next(m for m in net.modules() if isinstance(m, scn.InputLayer))
+        SCN._PREFETCHED.clear()
+        with torch.no_grad():
+            ms = _timeit(lambda: net(inp), 10, 3)
+            md = SCN.Metadata_3()
+            md.inputLayer(torch.tensor([4096] * 3), inp[0], 0, 4, dev)
+            n0 = md.nActive[md.inputSpatialSize]
+            del md
+
+            def fwd_pipelined():  # the NEXT scene's voxel hash + rulebooks built on the side stream beside this scene's kernels
+                out = net(inp)
+                input_layer.prefetch(inp, wait_for_current_stream=False)
+                return out
+            ms_p = _timeit(fwd_pipelined, 10, 3)
+        SCN._PREFETCHED.clear()
+        res["cfg2_m32_fwd_1scene"] = {"active_voxels": n0, "ms": ms, "voxels_per_s": n0 / ms * 1e3,
+                                      "ms_rules_prefetched": ms_p, "voxels_per_s_rules_prefetched": n0 / ms_p * 1e3}
+        del net, inp
+    f3 = torch.tensor([3, 3, 3])
+    for name, key, make in (("cfg5a_bernoulli160", "cfg5a", lambda: scenes.bernoulli_grid(160, 0.488, 7, offset=2)),
+                            ("cfg5b_solid126", "cfg5b", lambda: scenes.solid_block(126, offset=3))):
+        if key not in which:
+            continue
+        c = make()
+        md = SCN.Metadata_3()
+        size = torch.tensor([4096] * 3)
+        md.inputLayer(size, torch.from_numpy(c), 0, 4, dev)
+        t_rules = _timeit(lambda: (md.submanifoldRuleBooks.clear(), md.getSubmanifoldRuleBook(size, f3, _defer=True)), 3, 1)
+        rb = md.getSubmanifoldRuleBook(size, f3)
+        n = md.getNActive(size)
+        R = rb.total_pairs
+        x = torch.randn(n, 128, device=dev)
+        w = torch.randn(27, 128, 128, device=dev) * 0.02
+        dy = torch.randn(n, 128, device=dev)
+        out, gi, gw = torch.empty(0, device=dev), torch.empty(0, device=dev), torch.zeros(27, 128, 128, device=dev)
+        t_f = _timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n), 6, 2)
+        t_di = _timeit(lambda: SCN._conv(dy, gi, w, None, rb, 0, 1, n, True, True), 6, 2)
+        lib = _lib.load()
+        t_dw = _timeit(lambda: _lib.check(lib.scn_conv_dweight(
+            x.data_ptr(), dy.data_ptr(), gw.data_ptr(), rb.rules.data_ptr(), rb.counts.data_ptr(), None, 27, rb.stride, 0, 1,
+            n, n, 128, 128, 0, 0, None, 0, None, _lib.stream())), 6, 2)
+        flops = 2.0 * R * 128 * 128
+        fb = 4.0 * (R * 128 + n * 128) + 8.0 * R + 4.0 * 27 * 128 * 128
+        wb = 4.0 * R * 256 + 8.0 * R + 4.0 * 27 * 128 * 128
+        res[name] = {"active_voxels": n, "nu": R / n, "rulebook_build_ms": t_rules,
+                     "fwd_ms": t_f, "fwd_TFLOPs": flops / t_f / 1e9, "fwd_mfma_frac": flops / t_f / 1e9 / F32_MFMA_PEAK_TFLOPS,
+                     "fwd_algo_GBs": fb / t_f / 1e6,
+                     "dinput_ms": t_di, "dinput_TFLOPs": flops / t_di / 1e9,
+                     "dweight_ms": t_dw, "dweight_TFLOPs": flops / t_dw / 1e9, "dweight_algo_GBs": wb / t_dw / 1e6,
+                     "fwd_bwd_voxels_per_s": n / (t_f + t_di + t_dw) * 1e3}
+        del x, w, dy, out, gi, gw, rb, md
+        torch.cuda.empty_cache()
+    return res
+
+
+class _HostBatches(object):
+    """a data loader's worth of behaviour for PrefetchingLoader: n batches cycling over pinned HOST copies of the resident ones"""
+
+    def __init__(self, host_batches, first, n):
+        self.host, self.first, self.n = host_batches, first, n
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            b = self.host[(self.first + i) % len(self.host)]
+            yield {"x": [b[0], b[1], None, b[3]]}
 
 
 def measured_peaks(dev):
@@ -170,6 +352,10 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=4)
     ap.add_argument("--sites", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip parity_fullsize (the HIP pass kept for the comparison with the CPU leg)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the cfg2 / cfg5 measurements behind the timed region")
+    ap.add_argument("--host-steps", type=int, default=10,
+                    help="steps of the second, from-host timed region (inputs pinned on the host, H2D inside the clock); 0 = skip")
     ap.add_argument("--cpu-iters", type=int, default=1, help="iterations of the all-cores CPU baseline (best is reported)")
     ap.add_argument("--event-every", type=int, default=10,
                     help="time the kernels with HIP events on every n-th step of the timed region (a timed event drains "
@@ -282,6 +468,15 @@ def main():
 
     if args.no_dw_side_stream:  # (the warm-up steps too)
         SCN.DW_SIDE_STREAM = False
+    # parity_fullsize: ONE forward + backward of the HIP path on the batch the CPU leg will run (scenes 1000..), with the
+    # seed-0 parameters both sides start from, kept on the host until the reference's compiled loops have run (after the timed
+    # region).  Nothing of oracle/ is imported or loaded here.
+    dev_pass = None
+    want_parity = (world == 1 and not args.no_cpu_baseline and not args.no_parity and args.m == 64
+                   and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libscn_ref.so")))
+    if want_parity:
+        dev_pass = device_pass(net, scn, batches[0])
+        SCN._PREFETCHED.clear()
     for _ in range(args.warmup):
         step()
 
@@ -334,6 +529,51 @@ def main():
     SCN.PROFILE = None
     SCN.PROFILE_KINDS = ("mm", "bn", "rules", "io")
     barrier()
+
+    # ---- a second, shorter timed region that starts where a training loop starts: the batches PINNED ON THE HOST
+    # (occuseg_amd.data.PrefetchingLoader: coordinates + features cross PCIe on a copy stream while the step before drains, the
+    # rule build on the side stream waits for exactly those copies).  `value` stays the resident-input rate the contract asks
+    # for; this is what training pays on top (reference call pattern: examples/ScanNet/train_instance.py:345-400).
+    h2d = None
+    if world == 1 and args.host_steps > 0:
+        from occuseg_amd.data import PrefetchingLoader
+        host_b = [[b[0].cpu().pin_memory(), b[1].cpu().pin_memory(), None, b[3]] for b in batches]
+        SCN.DW_SIDE_STREAM = dw_side
+        SCN._PREFETCHED.clear()
+        n_host_warm = 2
+        loader = PrefetchingLoader(_HostBatches(host_b, 0, n_host_warm + args.host_steps), input_layer, dev)
+        loader.record_exposed = True
+
+        def step_on(x):
+            bucket.zero()
+            o = net(x)
+            o.sum().backward()
+            bucket.all_reduce_mean()
+            opt.step()
+
+        it = iter(loader)
+        for _ in range(n_host_warm):
+            step_on(next(it)["x"])
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        sites_h = 0
+        for k in range(args.host_steps):
+            step_on(next(it)["x"])
+            sites_h += n_sites[(n_host_warm + k) % len(batches)]
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - th
+        ex = sorted(e0.elapsed_time(e1) for e0, e1 in loader.exposed[n_host_warm:])
+        nbytes = sum(t.numel() * t.element_size() for t in host_b[0][:2])
+        h2d = {"ms_per_step_from_host": 1e3 * dth / args.host_steps, "value_from_host": sites_h / dth, "steps": args.host_steps,
+               "exposed_ms": ex[len(ex) // 2] if ex else None, "exposed_ms_max": ex[-1] if ex else None,
+               "bytes_per_batch": nbytes,
+               "how": "inputs pinned on the host; per step the NEXT batch's coordinates + features are copied on a copy stream "
+                      "(non-blocking) and its voxel hash + rulebooks built behind the copy on the side stream while this step's "
+                      "kernels drain (occuseg_amd.data.PrefetchingLoader); exposed_ms = median time the main stream waited for "
+                      "the copy stream"}
+        SCN._PREFETCHED.clear()
+        SCN.DW_SIDE_STREAM = False
+        del loader, it, host_b
 
     # N > 1: per rank, the time the main stream stood still for the gradient exchange (end of the backward kernels -> last
     # bucket complete; the buckets launched from inside backward overlap it) and the active voxels it processed
@@ -513,6 +753,9 @@ def main():
                        "source_hash": source_hash()},
             "roofline": roof, "kernels": kernels, "peaks_measured": peaks,
         }
+        if h2d is not None:
+            h2d["delta_ms_vs_resident"] = h2d["ms_per_step_from_host"] - res["ms_per_step"]
+            res["h2d"] = h2d
         if per_rank is not None:
             # what the first multi-GPU run has to explain about itself: how long each rank's main stream waited for the
             # gradient exchange per step (median), and how evenly the voxels fell (scenes differ by +-5 % in sites)
@@ -555,9 +798,19 @@ def main():
                     "bytes": nb / per}
                    for k, sh, ms, fl, nb, per in launches if fl]
             json.dump({"per_shape": rows, "in_order": seq}, open(args.dump_launches, "w"), indent=0)
+        if world == 1 and not args.no_configs and args.m == 64:
+            # BASELINE.json configs[1] and configs[4] in the driver's own line (the workload of `value` stays configs[2])
+            del batches[:]
+            torch.cuda.empty_cache()
+            t_cfg = time.perf_counter()
+            res["configs"] = other_configs(scn, dev)
+            res["configs"]["seconds"] = time.perf_counter() - t_cfg
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.m, args.scenes_per_gpu, args.sites, 1000, args.cpu_iters)
+            res["cpu_baseline"] = cpu_baseline(args.m, args.scenes_per_gpu, args.sites, 1000, args.cpu_iters, dev_pass=dev_pass)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            # the comparison the CPU leg makes on its way (the reference's compiled loops against the HIP pass taken before the
+            # warm-up), lifted to the top level of the line
+            res["parity_fullsize"] = res["cpu_baseline"].pop("parity_fullsize", None)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

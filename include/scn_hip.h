@@ -339,8 +339,10 @@ int scn_bn_forward(const float *x, float *y, float *save_mean, float *save_invst
  * the three arrays themselves are HOST arrays).  Only finalize + apply run: 8 instead of 12 bytes per element.
  * state (may be NULL; here and in scn_bn_backward_ext): the stream's control block (SCN_SK_STATE_BYTES of device memory that hold
  * ZERO between launches, shared with scn_conv_forward's sk_state: launches of one stream never overlap).  With it, more than 256
- * partials are folded AND finalized by one launch (a ticket in word 11, zero again afterwards) instead of two; same arithmetic
- * in the same order. */
+ * partials are folded AND finalized by one launch (tickets in words 32 .. 32 + ceil(C / 128) - 1, one per group of 128 planes,
+ * zero again afterwards: the SAME words scn_conv_forward's split launches use for their tile tickets and stream-K for its slab
+ * flags) instead of two; same arithmetic in the same order.  One stream per control block: two launches that name one block
+ * must never run at the same time, and a launch that dies after drawing tickets leaves the block unusable (zero it again). */
 int scn_bn_forward_ext(const float *x, float *y, float *save_mean, float *save_invstd,
                        float *running_mean, float *running_var, const float *weight,
                        const float *bias, double eps, double momentum, double leakiness,

@@ -1259,6 +1259,15 @@ def dw_join(device=None):
                 st[2].pop(0)
 
 
+def dw_wait_on(stream, device=None):
+    """make `stream` (not the current one) wait for every dWeight kernel queued so far: the gradient exchange of a bucket is
+    issued from a stream of its own (occuseg_amd.dp.FlatGradBucket._launch) so that the main stream does not stand still"""
+    for idx, st in _DW_STATE.items():
+        if device is None or device.index is None or device.index == idx:
+            if st[1] is not None:
+                stream.wait_event(st[1])
+
+
 def _dw_finish(idx):
     st = _DW_STATE[idx]
     if st[1] is not None:

@@ -206,6 +206,9 @@ class PrefetchingLoader(object):
     def __init__(self, loader, input_layer, device, move=()):
         self.loader, self.input_layer, self.device, self.move = loader, input_layer, torch.device(device), tuple(move)
         self._copy_stream = None
+        # record_exposed: per batch, two timed events on the main stream around its wait for the copy stream -- their distance is
+        # the time the step stood still for the host -> device copies (bench.py's `h2d.exposed_ms`)
+        self.record_exposed, self.exposed = False, []
 
     def _to_device(self, t):
         if torch.is_tensor(t) and not t.is_cuda:
@@ -232,7 +235,14 @@ class PrefetchingLoader(object):
                 for k in self.move:
                     batch[k] = self._to_device(batch[k])
                 self.input_layer.prefetch(x, wait_for_current_stream=True)
-            main.wait_stream(self._copy_stream)
+            if self.record_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                main.wait_stream(self._copy_stream)
+                e1.record(main)
+                self.exposed.append((e0, e1))
+            else:
+                main.wait_stream(self._copy_stream)
             for t in x[:3] + [batch[k] for k in self.move]:
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(main)

@@ -33,13 +33,14 @@ class GradJoin(object):
       * another pass that has NOT completed, other side -> cannot be told apart: a failed pass being repeated over a retained
         graph (stale: must be dropped) or an enclosing pass that is still running (must be added).  RuntimeError, never a
         silently wrong gradient; `containers.GRAD_JOIN = False` avoids the situation."""
-    __slots__ = ("pending", "armed", "left", "task", "side", "done")
+    __slots__ = ("pending", "armed", "left", "task", "side", "done", "token")
 
     def __init__(self, armed=True):
         self.pending = None
         self.task = None
         self.side = None
         self.done = False   # the pass that left `pending` has completed (its final callbacks ran)
+        self.token = None   # identity of the last put (the completion callback must not hold the gradient itself)
         self.armed = armed  # False: created by one side only (JoinConcatTable); the other side (JoinTable) arms it in forward
         self.left = None    # JoinConcatTable: the features tensor whose two gradients meet here (JoinTable checks it is its left entry)
 
@@ -57,10 +58,13 @@ class GradJoin(object):
             raise RuntimeError("occuseg_amd GradJoin: two gradients left in one backward pass (by %r and %r) and nobody took "
                                "the first" % (self.side, side))
         # (whatever an EARLIER pass left is stale by now: this side would have taken it otherwise -- see take)
-        self.pending, self.task, self.side, self.done = grad, task, side, False
+        tok = object()
+        self.pending, self.task, self.side, self.done, self.token = grad, task, side, False, tok
         try:  # final callbacks run when the pass completes; a pass that raises skips them
-            def _completed(join=self, task=task, grad=grad):
-                if join.pending is grad and join.task == task:
+            # (the callback names the put by a token, not by the tensor: a closure over `grad` kept every parked gradient --
+            #  ~150 MB each at level 0 of the m64 network -- alive until the whole backward pass had ended; round-5 advisor)
+            def _completed(join=self, task=task, tok=tok):
+                if join.token is tok and join.pending is not None and join.task == task:
                     join.done = True
             torch.autograd.Variable._execution_engine.queue_callback(_completed)
         except RuntimeError:  # (not inside a backward pass: the boundary functions called by hand)

@@ -21,6 +21,7 @@ class _Ctx(object):
         self.grid0, self.header, self.table, self.site_of_point = R.input_layer_rules(coords, mode=mode)
         self.grids, self.sub, self.strided = {}, {}, {}
         self.mode = mode
+        self.masks, self.mask_flips, self.mask_total = None, 0, 0
 
     def submanifold(self, size):
         if size not in self.sub:
@@ -84,9 +85,19 @@ def _run(mod, t, ctx, grads, sec):
                                              mod.eps, mod.momentum, mod.training, mod.leakiness)
         sec["bn"][0] += time.perf_counter() - t0
 
+        # ctx.masks[id(module)] (optional): the activation mask to differentiate with instead of this evaluation's own sign
+        # of y -- BatchNormalization_BackwardPass reads y only for its sign (sparseconvnet/SCN/CPU/BatchNormalization.cpp:80-83),
+        # so the mask is handed over AS y.  (An element with |y| ~ 1e-7 has a different sign in two f32 evaluations that sum
+        # in different orders; with the device's masks both backward passes differentiate the same piecewise-linear function.)
+        forced = ctx.masks.get(id(mod)) if getattr(ctx, "masks", None) else None
+        if forced is not None:
+            ctx.mask_flips += int(((y > 0) != forced).sum())
+            ctx.mask_total += int(forced.size)
+        y_sign = y if forced is None else np.where(forced, np.float32(1), np.float32(-1)).astype(np.float32)
+
         def bwd(g):
             t0 = time.perf_counter()
-            dx, _d, dw, db = REF.bn_backward(x, y, g, sm, si, w, mod.leakiness)
+            dx, _d, dw, db = REF.bn_backward(x, y_sign, g, sm, si, w, mod.leakiness)
             sec["bn"][0] += time.perf_counter() - t0
             grads[(id(mod), "weight")], grads[(id(mod), "bias")] = dw, db
             return dx
@@ -154,8 +165,9 @@ def _run(mod, t, ctx, grads, sec):
     raise NotImplementedError(type(mod))
 
 
-def forward_backward(net, coords, feats, threads=None, ctx=None):
+def forward_backward(net, coords, feats, threads=None, ctx=None, masks=None):
     """one forward + backward (loss = sum of the outputs) of ``net`` (Sequential starting with an InputLayer).
+    masks: {id(batch-norm module): bool array [N, C]} = activation masks to use in the backward pass (see _run).
     Returns (output [P, m], {(id(module), name): gradient}, seconds by group, ctx): ``seconds['total']`` is the wall
     time of the arithmetic (rulebook generation excluded: ctx can be passed in pre-built, and lists are generated
     before the clock starts)."""
@@ -181,6 +193,7 @@ def forward_backward(net, coords, feats, threads=None, ctx=None):
         ctx.submanifold(s)
     sec = {"conv": [0.0], "bn": [0.0], "nin": [0.0]}
     grads = {}
+    ctx.masks, ctx.mask_flips, ctx.mask_total = masks, 0, 0
     t0 = time.perf_counter()
     x = REF.input_forward(feats, ctx.table, mode=inp.mode)
     t = _T(x, size)

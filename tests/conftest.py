@@ -52,6 +52,13 @@ def pytest_collection_finish(session):
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out],
                                           env=e, stdout=open(log % rank, "w"), stderr=subprocess.STDOUT))
         jobs["dp"] = {"procs": procs, "out": out, "log": log}
+    if "test_rccl_world1_stream_ordering" in names:
+        out = os.path.join(tmp, "rccl1.json")
+        log = os.path.join(tmp, "rccl1.log")
+        e = dict(env, RANK="0", WORLD_SIZE="1", MASTER_PORT=str(_free_port()))
+        jobs["rccl1"] = {"procs": [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), out], env=e,
+                                                    stdout=open(log, "w"), stderr=subprocess.STDOUT, cwd=ROOT)],
+                         "out": out, "log": log}
     if "test_bench_two_ranks_code_path" in names:
         log = os.path.join(tmp, "bench2.log")
         e = dict(env, SCN_BENCH_BACKEND="gloo", SCN_BENCH_ONE_DEVICE="1")

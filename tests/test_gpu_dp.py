@@ -9,6 +9,9 @@ for them:
   * `python bench.py --gpus 2` exactly as the driver calls it (no launcher: bench.py starts torch.distributed.run on
     itself as a child process) with SCN_BENCH_BACKEND=gloo SCN_BENCH_ONE_DEVICE=1: the N > 1 branch of the bench
     (sharding, overlapped all-reduce, max-over-ranks timing, one JSON line from rank 0).
+  * ONE rank with backend "nccl" (tests/rccl_worker.py): RCCL loaded, its all-reduce kernels on the process group's stream
+    ordered against the main stream, the dWeight side stream and the rule-build prefetch stream of a real train step;
+    gradients bitwise equal to the same steps without a process group.
 RCCL over xGMI itself needs more than one GPU: only the driver's 8-GPU run exercises it.
 """
 import json
@@ -62,3 +65,18 @@ def test_bench_two_ranks_code_path(request):
     assert res["allreduce_exposed_ms"] >= 0.0 and len(res["per_rank"]["allreduce_exposed_ms"]) == 2
     assert len(res["per_rank"]["active_voxels"]) == 2 and all(v > 0 for v in res["per_rank"]["active_voxels"])
     assert abs(sum(res["per_rank"]["active_voxels"]) / max(res["per_rank"]["seconds"]) - res["value"]) < 1e-6 * res["value"]
+
+
+def test_rccl_world1_stream_ordering(request):
+    """RCCL (backend "nccl", world size 1) under the real UNet with enable_overlap(), the dWeight side stream and the rule
+    prefetch on: every bucket's all-reduce launched from inside backward on the exchange stream (the main stream is not made
+    to wait for the dWeight kernels: FlatGradBucket._launch), gradients BITWISE equal to the non-distributed steps."""
+    job = _wait(request.config._scn_jobs.get("rccl1"))
+    assert os.path.exists(job["out"]), "no verdict; log:\n%s" % open(job["log"]).read()[-3000:]
+    r = json.load(open(job["out"]))
+    assert "error" not in r, r["error"]
+    assert r["backend"] == "nccl" and r["n_buckets"] >= 3
+    assert all(r["bitwise_equal"]), r
+    assert r["each_once"] and r["complete_at_launch"], r
+    assert r["launched_in_backward"] == [r["n_buckets"]] * 3 and r["exchange_stream_launches"] == [r["n_buckets"]] * 3, r
+    assert r["ok"], r

@@ -89,3 +89,36 @@ def test_bernoulli_2m_sites_symmetry_and_checksum(gpu):
     o4 = torch.empty(0, device=gpu)
     SCN.SubmanifoldConvolution_updateOutput(size, F3, m, x1, o4, w, e, 1)
     assert torch.equal(o1, o4)
+
+
+def test_cfg2_scene_m32_against_the_references_compiled_loops(gpu):
+    """BASELINE.json configs[1] at its full size -- ONE ~150k-voxel scene through the m32 UNet -- forward AND backward
+    against the reference's own compiled CPU loops (oracle/_ref: sparseconvnet/SCN/CPU/{Convolution,BatchNormalization,
+    IOLayers}.cpp built where they lie; oracle/ref_net.py walks the network), the comparison bench.py puts into the
+    driver's line as `parity_fullsize` for configs[2].  Output and every parameter gradient within 1e-4 of the tensor's
+    magnitude; the CPU backward pass runs over the device's activation masks."""
+    from oracle import ref as REF, ref_net
+    if not REF.available():
+        pytest.skip("oracle/_ref/libscn_ref.so not built (it is built in the container that holds /root/reference and travels)")
+    import bench
+    import occuseg_amd
+    from occuseg_amd import scenes
+    scn = occuseg_amd.install()
+    torch.manual_seed(0)
+    coords, feats = scenes.batch([1000], 150000)
+    net_cpu = bench.build_net(scn, 32)
+    torch.manual_seed(0)
+    net = bench.build_net(scn, 32).to(gpu)
+    dev = bench.device_pass(net, scn, [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 1])
+    bns = [mod for mod in net_cpu.modules() if isinstance(mod, scn.BatchNormalization)]
+    assert len(bns) == len(dev["masks"]) == 33
+    masks = {id(mod): mk for mod, mk in zip(bns, dev["masks"])}
+    out, grads, _sec, ctx = ref_net.forward_backward(net_cpu, coords, feats, masks=masks)
+    assert ctx.grid0.n > 140000
+    order = [("%s.%s" % (type(mod).__name__, name), grads[(id(mod), name)])
+             for mod in net_cpu.modules() for name, p in mod._parameters.items() if p is not None]
+    res = bench.compare_passes(dev, out, order, ctx.mask_flips, ctx.mask_total)
+    print(res)
+    assert res["forward_max_rel"] <= 1e-4 and res["grad_max_rel"] <= 1e-4, res
+    assert res["mask_flips"] <= 1e-4 * res["mask_elements"], res
+    assert res["elementwise_rel_p99"] <= 1e-3, res

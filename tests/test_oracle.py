@@ -316,3 +316,45 @@ def test_reference_loops_network_matches_the_autograd_oracle():
                 assert_close(grads[(id(mod), name)], leaf.grad.numpy(), "reference-loops grad %s.%s" % (mod, name), rel=rel)
                 n += 1
         assert n == len(list(net.parameters()))
+
+
+def test_bench_parity_fullsize_machinery_on_cpu():
+    """bench.py's parity_fullsize (compare_passes + the masked backward pass of oracle/ref_net.py), exercised without a GPU:
+    the 'device pass' is the float32 torch-autograd oracle -- another float32 evaluation with another summation order,
+    which is what the HIP path is to the reference's loops.  With the device's activation masks handed to the reference's
+    BatchNormalization_BackwardPass every gradient holds the 1e-4 bar; a corrupted gradient must be caught and named."""
+    from oracle import ref as REF, ref_net, torch_ref
+    if not REF.available():
+        pytest.skip("oracle/_ref/libscn_ref.so not built (needs /root/reference)")
+    import bench
+    import occuseg_amd
+    from occuseg_amd import scenes
+    scn = occuseg_amd.install()
+    coords, feats = scenes.batch([1000, 1001], 3000)
+    torch.manual_seed(5)
+    net = bench.build_net(scn, 16)
+    out, stats = torch_ref.ref_forward(net, coords, feats, torch.float32)
+    out.sum().backward()
+    bns = [mod for mod in net.modules() if isinstance(mod, scn.BatchNormalization)]
+    dev = {"out": out.detach().numpy(), "masks": [stats["own_masks"][id(mod)].numpy() for mod in bns], "grads": []}
+    for mod in net.modules():
+        for name, p in mod._parameters.items():
+            if p is not None:
+                dev["grads"].append(("%s.%s" % (type(mod).__name__, name), tuple(p.shape),
+                                     stats["params"][id(mod)][name].grad.numpy().astype(np.float32)))
+    masks = {id(mod): mk for mod, mk in zip(bns, dev["masks"])}
+    got, grads, _sec, ctx = ref_net.forward_backward(net, coords, feats, threads=2, masks=masks)
+    order = [("%s.%s" % (type(mod).__name__, name), grads[(id(mod), name)])
+             for mod in net.modules() for name, p in mod._parameters.items() if p is not None]
+    res = bench.compare_passes(dev, got, order, ctx.mask_flips, ctx.mask_total)
+    assert res["ok"], res
+    assert res["forward_max_rel"] < 1e-4 and res["grad_max_rel"] < 1e-4 and res["grad_tensors"] == len(list(net.parameters()))
+    assert res["mask_elements"] == sum(m.size for m in dev["masks"]) and res["mask_flips"] < 1e-3 * res["mask_elements"]
+    assert res["elementwise_rel_p99"] is not None and res["elementwise_rel_p99"] < 1e-3
+    # a wrong gradient is found and named
+    name, shape, g = dev["grads"][7]
+    bad = g.copy()
+    bad.flat[0] += 10 * np.abs(g).max()
+    dev["grads"][7] = (name, shape, bad)
+    res = bench.compare_passes(dev, got, order, 0, 1)
+    assert not res["ok"] and res["worst_tensor"].startswith(name) and "tensor 8 of" in res["worst_tensor"]
