@@ -189,20 +189,40 @@ def cpu_baseline(m, scenes_per_gpu, target_sites, seed0, iters=1, dev_pass=None)
         assert len(bns) == len(dev_pass["masks"])
         masks = {id(mod): mk for mod, mk in zip(bns, dev_pass["masks"])}
     parity = None
+
+    def in_order(g):
+        return [("%s.%s" % (type(mod).__name__, name), g[(id(mod), name)])
+                for mod in net.modules() for name, p in mod._parameters.items() if p is not None]
+
     for it in range(max(1, iters)):
         _out, _g, sec, ctx = ref_net.forward_backward(net, coords, feats, threads=cores, ctx=ctx, masks=masks)
         if best is None or sec["total"] < best:
             best, groups = sec["total"], sec
         if dev_pass is not None and it == 0:
-            order = []
-            for mod in net.modules():
-                for name, p in mod._parameters.items():
-                    if p is not None:
-                        order.append(("%s.%s" % (type(mod).__name__, name), _g[(id(mod), name)]))
-            parity = compare_passes(dev_pass, _out, order, ctx.mask_flips, ctx.mask_total)
-            parity["against"] = ("oracle/_ref: the reference's compiled CPU loops (sparseconvnet/SCN/CPU/{Convolution,BatchNormalization,"
-                                 "IOLayers}.cpp), float32, same batch (%d scenes, %d active voxels), same seed-0 parameters"
-                                 % (len(seeds), ctx.grid0.n))
+            # (1) against the arithmetic the reference RUNS: its float32 loops, the pass the clock is on
+            order32 = in_order(_g)
+            p32 = compare_passes(dev_pass, _out, order32, ctx.mask_flips, ctx.mask_total)
+            # (2) against the SAME templates of the reference instantiated at double (oracle/ref_harness.cpp *_f64): at this size
+            # the float32 loops' own sequential sums over 600k rows (BatchNormalization.cpp:24-36,75-87) are ~1e-3 from that, so
+            # the 1e-4 bar of north_star can only be read against the float64 instantiation; (3) says how far (1)'s oracle is from it
+            t64 = time.perf_counter()
+            out64, g64, _s64, ctx = ref_net.forward_backward(net, coords, feats, threads=cores, ctx=ctx, masks=masks, dtype=np.float64)
+            order64 = in_order(g64)
+            p64 = compare_passes(dev_pass, out64, order64, ctx.mask_flips, ctx.mask_total)
+            ref32 = {"out": _out, "grads": [(n, tuple(np.shape(g)), np.asarray(g)) for n, g in order32]}
+            r32 = compare_passes(ref32, out64, order64, 0, 0)
+            keys = ("forward_max_rel", "grad_max_rel", "grad_median_rel", "worst_tensor", "elementwise_rel_p50", "elementwise_rel_p99",
+                    "elementwise_rel_p999", "elementwise_rel_max")
+            parity = dict(p64)
+            parity["against"] = ("oracle/_ref: the reference's CPU loops (sparseconvnet/SCN/CPU/{Convolution,BatchNormalization,IOLayers}.cpp) "
+                                 "instantiated at double, same batch (%d scenes, %d active voxels), same seed-0 parameters, the device's "
+                                 "activation masks" % (len(seeds), ctx.grid0.n))
+            parity["hip_vs_reference_f32_loops"] = {k: p32[k] for k in keys}
+            parity["reference_f32_loops_vs_their_f64_instantiation"] = {k: r32[k] for k in keys}
+            parity["note"] = ("top level = HIP against the float64 instantiation (the bar: 1e-4); the reference's own float32 loops are "
+                              "themselves further from it than the HIP path is (sequential float32 sums over %d rows)" % ctx.grid0.n)
+            parity["f64_leg_seconds"] = time.perf_counter() - t64
+            del out64, g64, order64, ref32
         del _out, _g
     n_all = ctx.grid0.n
     del ctx, masks

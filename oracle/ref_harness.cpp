@@ -31,65 +31,68 @@ template <typename T> T *OptionalTensorData(at::Tensor tensor) { return tensor.n
 #include "sparseconvnet/SCN/CPU/Convolution.cpp"
 #include "sparseconvnet/SCN/CPU/IOLayers.cpp"
 
-static at::Tensor wrap(float *p, int64_t r, int64_t c) {
-  return at::from_blob(p, {r, c}, at::TensorOptions().dtype(at::kFloat));
+template <typename T> static at::Tensor wrap(T *p, int64_t r, int64_t c) {
+  return at::from_blob(p, {r, c}, at::TensorOptions().dtype(c10::CppTypeToScalarType<T>::value));
 }
 
 extern "C" {
-
 // threads of the reference's `#pragma omp parallel for` loops (CPU/Convolution.cpp:15,26, CPU/IOLayers.cpp:16) and of at::mm
 void ref_set_threads(int n) {
   omp_set_num_threads(n);
   at::set_num_threads(n);
 }
-
-void ref_bn_forward(float *x, float *y, int32_t nPlanes, int32_t nActive, float *saveMean, float *saveInvStd,
-                    float *runningMean, float *runningVar, float *weight, float *bias, float eps, float momentum,
-                    int train, float leakiness) {
-  BatchNormalization_ForwardPass<float>(x, y, nPlanes, nPlanes, nPlanes, nActive, saveMean, saveInvStd, runningMean,
-                                        runningVar, weight, bias, eps, momentum, train != 0, leakiness);
 }
 
-void ref_bn_backward(float *x, float *dx, float *y, float *dy, int32_t nPlanes, int32_t nActive, float *saveMean,
-                     float *saveInvStd, float *runningMean, float *runningVar, float *weight, float *bias,
-                     float *d_weight, float *d_bias, float leakiness) {
-  BatchNormalization_BackwardPass<float>(x, dx, y, dy, nPlanes, nPlanes, nPlanes, nActive, saveMean, saveInvStd,
-                                         runningMean, runningVar, weight, bias, d_weight, d_bias, leakiness);
-}
+// Every entry point exists twice: T = float (the arithmetic the reference runs; suffix none) and T = double (suffix _f64) --
+// the SAME templates of the reference instantiated at double precision, i.e. the reference's own loops without their float32
+// rounding.  At 600k rows the float32 loops' sequential sums (BatchNormalization.cpp:24-36, 75-87) are themselves ~1e-3 away
+// from that; the float64 instantiation is what a 1e-4 comparison can be made against (bench.py parity_fullsize).  (One float
+// operation survives in it: invstd is computed with powf in every instantiation, BatchNormalization.cpp:40 -- ~6e-8 per batch norm.)
+#define SCN_REF_ENTRY_POINTS(T, SUFFIX)                                                                                          \
+  extern "C" {                                                                                                                   \
+  void ref_bn_forward##SUFFIX(T *x, T *y, int32_t nPlanes, int32_t nActive, T *saveMean, T *saveInvStd, T *runningMean,          \
+                              T *runningVar, T *weight, T *bias, T eps, T momentum, int train, T leakiness) {                    \
+    BatchNormalization_ForwardPass<T>(x, y, nPlanes, nPlanes, nPlanes, nActive, saveMean, saveInvStd, runningMean, runningVar,  \
+                                      weight, bias, eps, momentum, train != 0, leakiness);                                      \
+  }                                                                                                                              \
+  void ref_bn_backward##SUFFIX(T *x, T *dx, T *y, T *dy, int32_t nPlanes, int32_t nActive, T *saveMean, T *saveInvStd,           \
+                               T *runningMean, T *runningVar, T *weight, T *bias, T *d_weight, T *d_bias, T leakiness) {         \
+    BatchNormalization_BackwardPass<T>(x, dx, y, dy, nPlanes, nPlanes, nPlanes, nActive, saveMean, saveInvStd, runningMean,     \
+                                       runningVar, weight, bias, d_weight, d_bias, leakiness);                                  \
+  }                                                                                                                              \
+  /* out must be zeroed by the caller ("Assume output and d_input_features have been zero-ed", IOLayers.cpp:9) */               \
+  void ref_input_forward##SUFFIX(T *in, T *out, int32_t nRows, int32_t maxActive, int32_t nPlanes, int32_t *rules,               \
+                                 int average) {                                                                                  \
+    InputLayer_ForwardPass<T>(in, out, nRows, maxActive, nPlanes, rules, average != 0);                                          \
+  }                                                                                                                              \
+  void ref_input_backward##SUFFIX(T *d_in, T *d_out, int32_t nRows, int32_t maxActive, int32_t nPlanes, int32_t *rules,          \
+                                  int average) {                                                                                 \
+    InputLayer_BackwardPass<T>(d_in, d_out, nRows, maxActive, nPlanes, rules, average != 0);                                     \
+  }                                                                                                                              \
+  /* One kernel offset of the gather -> mm -> scatter: out[rules[2i+out_col]] += in[rules[2i+in_col]] . w (w is [Ci,Co]);       \
+     the three calls are the body of sparseconvnet/SCN/CPU/Convolution.cpp:60-68. */                                            \
+  void ref_rule_conv_offset##SUFFIX(T *in, int64_t n_in, T *out, int64_t n_out, T *w, int32_t Ci, int32_t Co, int32_t *rules,    \
+                                    int32_t nRules, int in_col) {                                                                \
+    if (!nRules) return;                                                                                                         \
+    auto input = wrap<T>(in, n_in, Ci), output = wrap<T>(out, n_out, Co), weight = wrap<T>(w, Ci, Co);                           \
+    auto input_rows = rule_index_select<T>(input, nRules, rules + in_col);                                                       \
+    auto output_rows = at::mm(input_rows, weight);                                                                               \
+    rule_index_add_<T>(output, output_rows, nRules, rules + (1 - in_col));                                                       \
+  }                                                                                                                              \
+  /* backward of one offset: dW = in_rows^T . dout_rows ; d_in[in idx] += dout_rows . w^T                                       \
+     (body of sparseconvnet/SCN/CPU/Convolution.cpp:104-109) */                                                                 \
+  void ref_rule_conv_offset_backward##SUFFIX(T *in, T *d_in, int64_t n_in, T *d_out, int64_t n_out, T *w, T *dw, int32_t Ci,     \
+                                             int32_t Co, int32_t *rules, int32_t nRules, int in_col) {                           \
+    if (!nRules) return;                                                                                                         \
+    auto input = wrap<T>(in, n_in, Ci), dinput = wrap<T>(d_in, n_in, Ci), doutput = wrap<T>(d_out, n_out, Co);                   \
+    auto weight = wrap<T>(w, Ci, Co), dweight = wrap<T>(dw, Ci, Co);                                                             \
+    auto input_rows = rule_index_select<T>(input, nRules, rules + in_col);                                                       \
+    auto d_output_rows = rule_index_select<T>(doutput, nRules, rules + (1 - in_col));                                            \
+    at::mm_out(dweight, input_rows.t(), d_output_rows);                                                                          \
+    auto d_input_rows = at::mm(d_output_rows, weight.t());                                                                       \
+    rule_index_add_<T>(dinput, d_input_rows, nRules, rules + in_col);                                                            \
+  }                                                                                                                              \
+  }
 
-// out must be zeroed by the caller ("Assume output and d_input_features have been zero-ed", IOLayers.cpp:9)
-void ref_input_forward(float *in, float *out, int32_t nRows, int32_t maxActive, int32_t nPlanes, int32_t *rules,
-                       int average) {
-  InputLayer_ForwardPass<float>(in, out, nRows, maxActive, nPlanes, rules, average != 0);
-}
-void ref_input_backward(float *d_in, float *d_out, int32_t nRows, int32_t maxActive, int32_t nPlanes,
-                        int32_t *rules, int average) {
-  InputLayer_BackwardPass<float>(d_in, d_out, nRows, maxActive, nPlanes, rules, average != 0);
-}
-
-// One kernel offset of the gather -> mm -> scatter: out[rules[2i+out_col]] += in[rules[2i+in_col]] . w
-// (w is [Ci,Co]); the three calls are the body of sparseconvnet/SCN/CPU/Convolution.cpp:60-68.
-void ref_rule_conv_offset(float *in, int64_t n_in, float *out, int64_t n_out, float *w, int32_t Ci, int32_t Co,
-                          int32_t *rules, int32_t nRules, int in_col) {
-  if (!nRules) return;
-  auto input = wrap(in, n_in, Ci), output = wrap(out, n_out, Co), weight = wrap(w, Ci, Co);
-  auto input_rows = rule_index_select<float>(input, nRules, rules + in_col);
-  auto output_rows = at::mm(input_rows, weight);
-  rule_index_add_<float>(output, output_rows, nRules, rules + (1 - in_col));
-}
-
-// backward of one offset: dW = in_rows^T . dout_rows ; d_in[in idx] += dout_rows . w^T
-// (body of sparseconvnet/SCN/CPU/Convolution.cpp:104-109)
-void ref_rule_conv_offset_backward(float *in, float *d_in, int64_t n_in, float *d_out, int64_t n_out, float *w,
-                                   float *dw, int32_t Ci, int32_t Co, int32_t *rules, int32_t nRules, int in_col) {
-  if (!nRules) return;
-  auto input = wrap(in, n_in, Ci), dinput = wrap(d_in, n_in, Ci), doutput = wrap(d_out, n_out, Co);
-  auto weight = wrap(w, Ci, Co), dweight = wrap(dw, Ci, Co);
-  auto input_rows = rule_index_select<float>(input, nRules, rules + in_col);
-  auto d_output_rows = rule_index_select<float>(doutput, nRules, rules + (1 - in_col));
-  at::mm_out(dweight, input_rows.t(), d_output_rows);
-  auto d_input_rows = at::mm(d_output_rows, weight.t());
-  rule_index_add_<float>(dinput, d_input_rows, nRules, rules + in_col);
-}
-
-}  // extern "C"
+SCN_REF_ENTRY_POINTS(float, )
+SCN_REF_ENTRY_POINTS(double, _f64)

@@ -42,7 +42,7 @@ class _T(object):
 
 
 def _w(mod, name):
-    return np.ascontiguousarray(getattr(mod, name).detach().cpu().numpy(), dtype=np.float32)
+    return np.ascontiguousarray(getattr(mod, name).detach().cpu().numpy(), dtype=REF._DT[0])
 
 
 def _conv(x, w, lists, n_out, in_col, grads, key, seconds):
@@ -93,7 +93,7 @@ def _run(mod, t, ctx, grads, sec):
         if forced is not None:
             ctx.mask_flips += int(((y > 0) != forced).sum())
             ctx.mask_total += int(forced.size)
-        y_sign = y if forced is None else np.where(forced, np.float32(1), np.float32(-1)).astype(np.float32)
+        y_sign = y if forced is None else np.where(forced, 1.0, -1.0).astype(REF._DT[0])
 
         def bwd(g):
             t0 = time.perf_counter()
@@ -147,7 +147,7 @@ def _run(mod, t, ctx, grads, sec):
         n = t.f.shape[0]
 
         def bwd(g):  # sparseconvnet/SCN/CPU/IOLayers.cpp:87-104: point gradients summed back per site
-            d = np.zeros((n, g.shape[1]), np.float32)
+            d = np.zeros((n, g.shape[1]), REF._DT[0])
             np.add.at(d, sop, g)
             return d
         return t.f[sop], bwd
@@ -165,13 +165,18 @@ def _run(mod, t, ctx, grads, sec):
     raise NotImplementedError(type(mod))
 
 
-def forward_backward(net, coords, feats, threads=None, ctx=None, masks=None):
+def forward_backward(net, coords, feats, threads=None, ctx=None, masks=None, dtype=np.float32):
     """one forward + backward (loss = sum of the outputs) of ``net`` (Sequential starting with an InputLayer).
     masks: {id(batch-norm module): bool array [N, C]} = activation masks to use in the backward pass (see _run).
+    dtype: np.float32 = the arithmetic the reference runs; np.float64 = the same templates of the reference instantiated at
+    double (oracle/ref_harness.cpp: *_f64) -- the reference's loops without their float32 rounding.
     Returns (output [P, m], {(id(module), name): gradient}, seconds by group, ctx): ``seconds['total']`` is the wall
     time of the arithmetic (rulebook generation excluded: ctx can be passed in pre-built, and lists are generated
     before the clock starts)."""
     from occuseg_amd.sparseconvnet import conv as V, io as IO
+    if np.dtype(dtype) != np.dtype(REF._DT[0]):
+        with REF.precision(dtype):
+            return forward_backward(net, coords, feats, threads, ctx, masks, dtype)
     if threads is not None:
         REF._load().ref_set_threads(int(threads))
         import torch

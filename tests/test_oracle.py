@@ -351,6 +351,18 @@ def test_bench_parity_fullsize_machinery_on_cpu():
     assert res["forward_max_rel"] < 1e-4 and res["grad_max_rel"] < 1e-4 and res["grad_tensors"] == len(list(net.parameters()))
     assert res["mask_elements"] == sum(m.size for m in dev["masks"]) and res["mask_flips"] < 1e-3 * res["mask_elements"]
     assert res["elementwise_rel_p99"] is not None and res["elementwise_rel_p99"] < 1e-3
+    # the float64 instantiation of the reference's templates (oracle/ref_harness.cpp *_f64) agrees with the float32 loops at
+    # this size, and with the float64 autograd oracle much more closely
+    got64, grads64, _sec, ctx64 = ref_net.forward_backward(net, coords, feats, threads=2, masks=masks, dtype=np.float64)
+    assert got64.dtype == np.float64 and all(g.dtype == np.float64 for g in grads64.values())
+    res64 = bench.compare_passes(dev, got64, [("%s.%s" % (type(mod).__name__, name), grads64[(id(mod), name)])
+                                              for mod in net.modules() for name, p in mod._parameters.items() if p is not None],
+                                 ctx64.mask_flips, ctx64.mask_total)
+    assert res64["ok"], res64
+    out64, stats64 = torch_ref.ref_forward(net, coords, feats, torch.float64, masks={id(mod): torch.from_numpy(mk) for mod, mk in zip(bns, dev["masks"])})
+    # (not 1e-12: the reference computes invstd with powf in EVERY instantiation, sparseconvnet/SCN/CPU/BatchNormalization.cpp:40,
+    #  so a float rounding per batch norm survives the double instantiation)
+    assert np.abs(out64.detach().numpy() - got64).max() <= 2e-6 * np.abs(got64).max()
     # a wrong gradient is found and named
     name, shape, g = dev["grads"][7]
     bad = g.copy()
