@@ -19,6 +19,7 @@
 // row sets staged in LDS, 16x16x4 MFMA with the pair index as the K dimension,
 // float atomics into dW (as the reference, sparseconvnet/SCN/CUDA/Convolution.cu:749).
 #include "scn_common.h"
+#include "tile4_loop_asm.inc"  // k_conv_tile4's pass loop in assembly (generated: tools/gen_tile4_loop.py)
 
 #include <type_traits>
 
@@ -855,7 +856,11 @@ constexpr int SK_SLICES = SCN_SK_SLICES;  // slices of the sliced part of a laun
 // `slabs_a` (= the launch's real output) and emits the column statistics.  The pieces of a tile are ADDED by its last arriver, not
 // chained as stream-K's are: the ksplit workgroups of a tile run at the same time.  Same slabs, same order as k_conv_tile2's
 // split launch: bit-identical to it.
-template <int DBG = 0, int INCOL = -1, int GT = 0, int SK = 0, int SPLIT = 0>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
+// ASM = 1 (needs GT = 1, INCOL >= 0, DBG = 0): the pass loop is the hand-written one of tile4_loop_asm.inc (tools/gen_tile4_loop.py:
+// six copies of the pass body -- three rotations of the row sets x two roles of the weight sets --, 12 vector-ALU instructions
+// per pass instead of ~26, lanes past the end of a list masked out of the loads by EXEC masks from the table) over 16-byte table
+// entries; same arithmetic in the same order, bit-identical to the C++ loop.
+template <int DBG = 0, int INCOL = -1, int GT = 0, int SK = 0, int SPLIT = 0, int ASM = 0>  // INCOL: -1 = read the argument, 0 / 1 = known at compile time (no v_cndmask per pair)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))  // (<= 256 registers: hipcc then keeps the accumulators in VGPRs, no v_accvgpr_read)
     k_conv_tile4(const float *__restrict__ in, float *__restrict__ out_a, const float *__restrict__ Wp,
                  const float *__restrict__ bias_a, const float *__restrict__ residual_a, StatsArg colstats_a, const int2 *__restrict__ rules,
@@ -883,6 +888,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   __shared__ __attribute__((aligned(8))) unsigned ptab[GT ? 1 : TMAX][2];  // {byte offset of the pass's first pair in `rules`,
                                                                   //  pairs left in the list | chunk<<8 | k<<12 | first<<20}
   static_assert(!SK || GT, "stream-K keeps its pass tables in global memory");
+  static_assert(!ASM || (GT && INCOL >= 0 && DBG == 0), "the assembly loop reads its pass table with scalar loads and knows the rulebook column");
   static_assert(!SPLIT || (GT && !SK), "the fused split launch keeps its pass tables in global memory and is not a stream-K launch");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1279,12 +1285,22 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       for (int j = 0; j < npl; ++j) {
         const unsigned e0 = first + (unsigned)j * 256u;
         const unsigned e1 = (unsigned)(c - 32 * j) | (unsigned)chn << 8 | (unsigned)tid << 12 | (j == 0 ? 1u << 20 : 0u);
-        if (GT) { if (!SK || (pos >= t_lo && pos < t_hi)) gt[pos - t_lo] = make_uint2(e0, e1); }
+        if (ASM) {
+          // 16-byte entries: + the byte offset of the phase's first weight block (wave 0's) and the lane masks of the pass' two groups
+          if (!SK || (pos >= t_lo && pos < t_hi)) {
+            const int left = c - 32 * j;
+            const unsigned m0 = left >= 16 ? 0xffffu : (1u << left) - 1u;
+            const unsigned m1 = left <= 16 ? 0u : left >= 32 ? 0xffffu : (1u << (left - 16)) - 1u;
+            const unsigned woff = (unsigned)(((tid * (Ci / 16) + chn * (CK / 16)) * (Co / 16) + co0 / 16) * 1024);
+            ((uint4 *)gt_region)[pos - t_lo] = make_uint4(e0, e1, woff, m0 | m1 << 16);
+          }
+        } else if (GT) { if (!SK || (pos >= t_lo && pos < t_hi)) gt[pos - t_lo] = make_uint2(e0, e1); }
         else { ptab[pos][0] = e0; ptab[pos][1] = e1; }
         ++pos;
       }
     if (tid < 8) {  // sentinels: empty passes
-      if (GT) gt[total + tid] = make_uint2(0u, 0u);
+      if (ASM) ((uint4 *)gt_region)[total + tid] = make_uint4(0u, 0u, 0u, 0u);
+      else if (GT) gt[total + tid] = make_uint2(0u, 0u);
       else { ptab[total + tid][0] = 0u; ptab[total + tid][1] = 0u; }
     }
     if (GT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the table is in L2 before the barrier lets anybody read it
@@ -1428,7 +1444,26 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (pf_now && tid == 0)
     pf_val = __hip_atomic_fetch_add(sk_state + (pf_which == 1 ? 0 : 16) + ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (SK) { sk_pf = pf_now ? pf_which : 0; tile_parked = tile; park_all(true); }
-  Ent E0 = entry(0);
+  if (ASM) {
+    // the whole pass loop, prologue and last pending write included (tile4_loop_asm.inc)
+    const unsigned wstep = (unsigned)(Co / 16) * 1024u, wbase = (unsigned)(w * COS) * 1024u;
+    unsigned wlane16 = (unsigned)lane * 16u, lq16_v = lq16, li8_0 = li8[0], li8_1 = li8[1];
+    if (INCOL == 0)
+      asm volatile(SCN_T4_ASM_INCOL0
+                   :
+                   : [in] "s"(in_rsrc), [wp] "s"(wp_rsrc), [ru] "s"(ru_rsrc), [gt] "s"(gt_s), [row_bytes] "s"(row_bytes), [os_u] "s"(os_u),
+                     [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v),
+                     [li8_0] "v"(li8_0), [li8_1] "v"(li8_1)
+                   : SCN_T4_ASM_CLOBBERS);
+    else
+      asm volatile(SCN_T4_ASM_INCOL1
+                   :
+                   : [in] "s"(in_rsrc), [wp] "s"(wp_rsrc), [ru] "s"(ru_rsrc), [gt] "s"(gt_s), [row_bytes] "s"(row_bytes), [os_u] "s"(os_u),
+                     [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v),
+                     [li8_0] "v"(li8_0), [li8_1] "v"(li8_1)
+                   : SCN_T4_ASM_CLOBBERS);
+  }
+  Ent E0 = ASM ? Ent{0u, 0u} : entry(0);
   if (SK && pf_now && !(rem(E0) > 0) && tid == 0) sk_slot[pf_slot] = (int)pf_val;  // (an item without passes: no prologue)
   if (rem(E0) > 0) {
     // ---- pipeline state at the top of pass p: rows(p) in rc, rows(p+1) in rm (arrived), weights(p) in wc, indices of
@@ -3816,6 +3851,7 @@ SCN_KNOB g_conv_expand_persist = 0;  // tuning key 21: 1 = k_conv_expand_p (pers
                                      // (46.73 against 46.40 ms, tools/ab_step.py tune21=0,1): off
 SCN_KNOB g_conv_stem_mfma = 1;  // tuning key 15: 0 = the C_i <= 4 stem runs k_conv_generic (scalar FMAs) instead of k_conv_stem (A/B)
 SCN_KNOB g_conv_gtab = 1;       // tuning key 13: 0 = k_conv_tile4 keeps its pass table in LDS (A/B)
+SCN_KNOB g_conv_asm = 1;        // tuning key 28: 0 = k_conv_tile4 runs hipcc's pass loop instead of the hand-written one (A/B; bit-identical)
 SCN_KNOB g_conv_sk = 1;         // tuning key 16: stream-K for the unsplit k_conv_tile4 launches (0 = one workgroup per tile, the round-3 launch)
 SCN_KNOB g_conv_sk_static = 1;      // tuning key 22: 0 = stream-K launches draw their items and slices from counters (A/B)
 SCN_KNOB g_conv_sk_min_loss = 30;   // tuning key 18: ... and only where one workgroup per tile would leave at least this many permille of the last
@@ -3965,7 +4001,8 @@ static int tile4_rows(int ksplit) { return (g_conv_tile6 == 96 && ksplit == 1) ?
 
 // entries (8 bytes each) of one workgroup's region of k_conv_tile4's global pass table: <= 4 passes per (offset, chunk), 8
 // sentinels, rounded to whole 64-byte lines (a scalar-cache line never holds entries of two workgroups)
-static int tile4_gtab_stride(int K, int Ci) { return (K * 4 * (Ci / 64) + 8 + 7) / 8 * 8; }
+// (in units of 8 bytes; the assembly loop's entries are 16 bytes: twice the units)
+static int tile4_gtab_stride(int K, int Ci) { return 2 * ((K * 4 * (Ci / 64) + 8 + 7) / 8 * 8); }
 // a split launch that adds its partial tiles itself (k_conv_tile4's SPLIT): ticket words behind the stream-K words of the control
 // block, slabs addressed with 32-bit buffer offsets
 static bool split_fused_ok(int64_t items, int64_t n_out, int Co) {
@@ -4072,12 +4109,13 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
       split_fused_ok((int64_t)ntiles * ncb, n_out, Co)) {
     unsigned long long *gtab_s = (unsigned long long *)((char *)part + tile4_split_slab_bytes(ksplit, n_out, Co));
     const int gs = tile4_gtab_stride((K + ksplit - 1) / ksplit, Ci);
-    if (in_col)
-      k_conv_tile4<0, 1, 1, 0, 1><<<grid4, 128, 0, stream>>>(in, part, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran,
-                                                             Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab_s, gs, nullptr, sk_state + SK_STATE_WORDS, out, 0, 0);
-    else
-      k_conv_tile4<0, 0, 1, 0, 1><<<grid4, 128, 0, stream>>>(in, part, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran,
-                                                             Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab_s, gs, nullptr, sk_state + SK_STATE_WORDS, out, 0, 0);
+#define SCN_LAUNCH_T4_SPLIT(IC, A)                                                                                                    \
+  k_conv_tile4<0, IC, 1, 0, 1, A><<<grid4, 128, 0, stream>>>(in, part, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, \
+                                                             n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab_s, gs, nullptr, \
+                                                             sk_state + SK_STATE_WORDS, out, 0, 0)
+    if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_SPLIT(1, 1); else SCN_LAUNCH_T4_SPLIT(0, 1); }
+    else { if (in_col) SCN_LAUNCH_T4_SPLIT(1, 0); else SCN_LAUNCH_T4_SPLIT(0, 0); }
+#undef SCN_LAUNCH_T4_SPLIT
     SCN_CHECK_LAUNCH();
     return 0;
   }
@@ -4145,22 +4183,24 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
     case 4097: SCN_LAUNCH_TILE4(4096 + 11); break;  // ... and no weight loads
     case 8192: SCN_LAUNCH_TILE4(8192); break;  // A/B: unneeded loads point out of range instead of reading offset 0
     default:
+#define SCN_LAUNCH_T4_SK(IC, A)                                                                                                       \
+  k_conv_tile4<0, IC, 1, 1, 0, A><<<sp.groups, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, \
+                                                                 n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, \
+                                                                 sk_state, slabs, sp.na_items, g_conv_sk_static)
+#define SCN_LAUNCH_T4_GT(IC, A)                                                                                                       \
+  k_conv_tile4<0, IC, 1, 0, 0, A><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col,  \
+                                                             n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride)
       SkPlan sp;
       if (gtab != nullptr && tile_passes != nullptr && sk_state != nullptr && tile4_sk_plan(K, n_out, Ci, Co, sp)) {
         float *slabs = (float *)((char *)part + sp.gtab_bytes);
-        if (in_col)
-          k_conv_tile4<0, 1, 1, 1><<<sp.groups, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
-                                                                  ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items, g_conv_sk_static);
-        else
-          k_conv_tile4<0, 0, 1, 1><<<sp.groups, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
-                                                                  ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items, g_conv_sk_static);
-      } else
-      if (gtab != nullptr && in_col)
-        k_conv_tile4<0, 1, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride);
-      else if (gtab != nullptr)
-        k_conv_tile4<0, 0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                                                 stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride);
+        if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_SK(1, 1); else SCN_LAUNCH_T4_SK(0, 1); }
+        else { if (in_col) SCN_LAUNCH_T4_SK(1, 0); else SCN_LAUNCH_T4_SK(0, 0); }
+      } else if (gtab != nullptr) {
+        if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_GT(1, 1); else SCN_LAUNCH_T4_GT(0, 1); }
+        else { if (in_col) SCN_LAUNCH_T4_GT(1, 0); else SCN_LAUNCH_T4_GT(0, 0); }
+      }
+#undef SCN_LAUNCH_T4_SK
+#undef SCN_LAUNCH_T4_GT
       else if (in_col)
         k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
                                                                               stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
@@ -4169,23 +4209,24 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
                                                                               stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
   }
 #else
+#define SCN_LAUNCH_T4_SK(IC, A)                                                                                                       \
+  k_conv_tile4<0, IC, 1, 1, 0, A><<<sp.groups, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, \
+                                                                 n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, \
+                                                                 sk_state, slabs, sp.na_items, g_conv_sk_static)
+#define SCN_LAUNCH_T4_GT(IC, A)                                                                                                       \
+  k_conv_tile4<0, IC, 1, 0, 0, A><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col,  \
+                                                             n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride)
   SkPlan sp;
   if (gtab != nullptr && tile_passes != nullptr && sk_state != nullptr && tile4_sk_plan(K, n_out, Ci, Co, sp)) {
     // stream-K: persistent workgroups, equal slices of the pass sequence (see k_conv_tile4's SK)
     float *slabs = (float *)((char *)part + sp.gtab_bytes);
-    if (in_col)
-      k_conv_tile4<0, 1, 1, 1><<<sp.groups, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
-                                                              ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items, g_conv_sk_static);
-    else
-      k_conv_tile4<0, 0, 1, 1><<<sp.groups, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K, stride, in_col, n_out, n_gran, Ci, Co,
-                                                              ntiles, ncb, in_bytes, wp_bytes, 1, gtab, gstride, tile_passes, sk_state, slabs, sp.na_items, g_conv_sk_static);
+    if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_SK(1, 1); else SCN_LAUNCH_T4_SK(0, 1); }
+    else { if (in_col) SCN_LAUNCH_T4_SK(1, 0); else SCN_LAUNCH_T4_SK(0, 0); }
   } else if (gtab != nullptr) {  // pass table in global memory, read with scalar loads (see k_conv_tile4's GT)
-    if (in_col)
-      k_conv_tile4<0, 1, 1><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                       stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride);
-    else
-      k_conv_tile4<0, 0, 1><<<grid4, 128, 0, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
-                                                       stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit, gtab, gstride);
+    if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_GT(1, 1); else SCN_LAUNCH_T4_GT(0, 1); }
+    else { if (in_col) SCN_LAUNCH_T4_GT(1, 0); else SCN_LAUNCH_T4_GT(0, 0); }
+#undef SCN_LAUNCH_T4_SK
+#undef SCN_LAUNCH_T4_GT
   } else if (in_col)
     k_conv_tile4<0, 1><<<grid4, 128, (size_t)g_conv_extra_lds, stream>>>(in, dst4, Wp, bias, residual, colstats, (const int2 *)rules, bases, K,
                                                                           stride, in_col, n_out, n_gran, Ci, Co, ntiles, ncb, in_bytes, wp_bytes, ksplit);
@@ -4245,6 +4286,7 @@ int scn_set_tuning(int key, int value) {
   if (key == 11 && (value == 0 || value == 96 || value == 128)) { g_conv_tile6 = value; return 0; }
   if (key == 12) { g_dw_direct = value; return 0; }
   if (key == 13) { g_conv_gtab = value; return 0; }
+  if (key == 28) { g_conv_asm = value; return 0; }
   if (key == 14) { g_conv_expand_nb = value; return 0; }
   if (key == 15) { g_conv_stem_mfma = value; return 0; }
   if (key == 16 && value >= 0 && value <= 3) { g_conv_sk = value; return 0; }

@@ -272,11 +272,18 @@ def test_submanifold_forward_variants(gpu, ci, co, n, extent):
             assert got == macs
             outs[variant] = out.cpu().numpy()
         lib.scn_set_tuning(0, 4)
+        # ... and k_conv_tile4 with hipcc's pass loop instead of the hand-written one (tools/gen_tile4_loop.py): bit-identical
+        lib.scn_set_tuning(28, 0)
+        out = torch.empty(0, device=gpu)
+        SCN.SubmanifoldConvolution_updateOutput(size, F3, m, xt, out, wt, bt, 1)
+        outs["c++ loop"] = out.cpu().numpy()
+        lib.scn_set_tuning(28, 1)
     finally:
         _lib.use_product_build()
     out = torch.empty(0, device=gpu)
     SCN.SubmanifoldConvolution_updateOutput(size, F3, m, xt, out, wt, bt, 1)
     assert np.array_equal(out.cpu().numpy(), outs[4])
+    assert np.array_equal(outs["c++ loop"], outs[4]), "the assembly pass loop and hipcc's differ"
     assert_close(outs[4], want, "variant 4 forward %d->%d" % (ci, co))
     assert_close(outs[2], want, "variant 2 forward %d->%d" % (ci, co))
     # same per-(offset, chunk) summation order in both kernels: bit-identical
@@ -339,7 +346,7 @@ def test_stream_k_pieces_equal_one_workgroup_per_tile(gpu, ci, co, leak):
     tiles = (N + 127) // 128
     assert lib0.scn_conv_plan(27, N, N, N, ci, co, 0) == 401 and tiles == 637  # x 2 = 1.24 rounds, x 4 = 2.49 rounds
     # the product library's own rule picks stream-K for this launch (half of the last round of workgroups would be empty)
-    gstride = (27 * 4 * (ci // 64) + 8 + 7) // 8 * 8
+    gstride = 2 * ((27 * 4 * (ci // 64) + 8 + 7) // 8 * 8)  # (8-byte units; the assembly loop's table entries are 16 bytes)
     assert lib0.scn_conv_workspace_bytes(27, N, N, N, ci, co, 0) == 1024 * 2 * gstride * 8 + 1024 * 128 * 64 * 4
     rules, _ = R.submanifold_rules(grid)
     rng = np.random.default_rng(ci + co)

@@ -165,7 +165,7 @@ def check_kernel_cfg(name, lines):
                 for dst, lno in fifo:
                     if touched & dst:
                         errors.setdefault((no, lno), "%s: line %d `%s` touches v%s, target of the load at line %d still in flight"
-                                          % (name, no + 1, s, sorted(touched & dst), lno + 1))
+                                          % (name, no + 1, s, sorted(touched & dst), (lno if lno >= 0 else -2 - lno) + 1))
             # scalar loads issued from inline asm (k_conv_tile4's pass-table entry: requested in one asm statement, picked up
             # ~430 instructions later in another): hipcc does not know the destination is not valid yet either.  Scalar loads
             # may return out of order: only lgkmcnt(0) makes them safe.
@@ -185,11 +185,13 @@ def check_kernel_cfg(name, lines):
                 if m and len(fifo) > int(m.group(1)):
                     fifo = fifo[len(fifo) - int(m.group(1)):]
             elif is_load:
-                fifo = fifo + ((frozenset(regs(ops[0])), no),)
+                # (line number negated - 2 for hipcc's own loads, e.g. spill reloads: hipcc waits for those itself)
+                fifo = fifo + ((frozenset(regs(ops[0])), no if is_asm else -2 - no),)
             elif is_store:
                 fifo = fifo + ((frozenset(), -1),)  # (no destination: where it was issued does not matter -- states merge)
-            while len(fifo) > 62 and not fifo[0][0]:
-                fifo = fifo[1:]  # (the hardware counter saturates: issue stalls until the oldest store has completed)
+            while len(fifo) > 62 and (not fifo[0][0] or fifo[0][1] < -1):
+                fifo = fifo[1:]  # (the hardware counter saturates: issue stalls until the oldest store -- or load of hipcc's own,
+                                 #  whose wait hipcc places itself -- has completed)
             if len(fifo) > 62:
                 return ["%s: more than 62 vector-memory operations outstanding at line %d" % (name, no + 1)]
             if op == "s_endpgm":
@@ -231,7 +233,10 @@ def main():
         errors += check_kernel_cfg(name, lines[st:end + 1])  # every path of the control-flow graph
         stream_k = re.search(r"k_conv_tile4ILi\d+ELin?\d+ELi\d+ELi1E", name) is not None  # (set-up branches: the linear walk
         # would see the loads of both arms of an if / else in flight at once; the path-exact walk above covers them)
-        if "k_conv_tile6" not in name and not stream_k and not re.search(r"k_conv_tile4ILi\d*[13579]ELi", name):
+        # (ASM = 1 instantiations: the pass loop is ONE asm block -- tools/gen_tile4_loop.py checks every path through it on its
+        #  own instruction list -- and the path-exact walk above has covered it again as emitted)
+        asm_loop = re.search(r"k_conv_tile4ILi\d+ELin?\d+ELi\d+ELi\d+ELi\d+ELi1E", name) is not None
+        if "k_conv_tile6" not in name and not stream_k and not asm_loop and not re.search(r"k_conv_tile4ILi\d*[13579]ELi", name):
             errors += check_kernel(name, lines[st:end + 1])  # and the older linear walk of the loop (twice), where it applies
                                                              # (the "no tile update" timing builds have another loop shape)
         n += 1
