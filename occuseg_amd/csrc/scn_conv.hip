@@ -1007,13 +1007,21 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // trip through a memory path that a CU's eight gathering waves keep full, 2-3 us -- the first version also tried the other
   // seven XCDs' counters when its own ran out, fifteen such round trips at the end of every workgroup: 8 % of a launch.
   // (Every XCD holds the same number of workgroups and is dealt the same number of items and equal slices: nothing to steal.)
+  // "this is thread 0 of the workgroup", without a vector register that lives across the assembly pass loop (see there: a copy of
+  // such a register may be made while wave 1 is masked off)
+  auto thread0 = [&]() __attribute__((always_inline)) {
+    if (!ASM) return tid == 0;
+    int l_;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+    return w == 0 && l_ == 0;
+  };
   auto sk_draw = [&](int which) __attribute__((always_inline)) {
     if (sk_pf == which) {
       sk_pf = 0;
       lds_barrier();
     } else {
       sk_pf = 0;  // (a draw of the other kind made ahead is dropped: that counter has run out)
-      if (tid == 0)
+      if (thread0())
         sk_slot[sk_par] = (int)__hip_atomic_fetch_add(sk_state + (which == 1 ? 0 : 16) + ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT);
       lds_barrier();
@@ -1119,7 +1127,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
           int t = sk_steal == 0 ? sk_draw(2) : (SK_SLICES >> 3);
           while (t >= (SK_SLICES >> 3)) {
             if (sk_steal == 0) {
-              if (tid == 0) sk_slot[sk_par] = (int)__hip_atomic_load(sk_state + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (thread0()) sk_slot[sk_par] = (int)__hip_atomic_load(sk_state + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               lds_barrier();
               const int taken = uni(sk_slot[sk_par]);
               sk_par ^= 1;
@@ -1127,12 +1135,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             if (++sk_steal >= 8) return false;
             const int xc = ((int)blockIdx.x + sk_steal) & 7;
-            if (tid == 0) sk_slot[sk_par] = (int)__hip_atomic_fetch_add(sk_state + 16 + xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (thread0()) sk_slot[sk_par] = (int)__hip_atomic_fetch_add(sk_state + 16 + xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lds_barrier();
             t = uni(sk_slot[sk_par]);
             sk_par ^= 1;
           }
-          if (tid == 0) __hip_atomic_fetch_add(sk_state + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (thread0()) __hip_atomic_fetch_add(sk_state + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           sk_s = ((t / SK_CH) * 8 + (((int)blockIdx.x + sk_steal) & 7)) * SK_CH + t % SK_CH;
         }
         sk_bounds(sk_s);
@@ -1174,7 +1182,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // (SK: everything per-lane below is derived afresh in every piece -- left loop-invariant, hipcc hoists a dozen per-lane
   //  addresses of the set-up and the epilogue out of the piece loop, finds no registers for them beside the pass loop's 220
   //  and spills them to scratch)
-  if (SK) asm volatile("" : "+v"(tid_opaque));
+  if (SK && ASM) {  // (no vector register lives across the assembly pass loop: the thread id comes from the hardware every time)
+    int l_;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+    tid_opaque = 64 * w + l_;
+  } else if (SK) asm volatile("" : "+v"(tid_opaque));
   // SK: the two waves that share a SIMD take turns at the higher issue priority, piece by piece.  Waves that the hardware deals
   // come and go, so which of a SIMD's two is the older one (the one its arbiter prefers) alternates by itself; persistent waves
   // are all the same age for the whole launch, one of each pair is preferred throughout -- and the same pass loop ran 5 %
@@ -1184,8 +1196,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     if ((((int)blockIdx.x >> 9) + gpar) & 1) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(0);
   }
-  const int tid = SK ? tid_opaque : (int)threadIdx.x;
-  const int lane = tid & 63;
+  // (not const: the ASM variant derives them afresh behind its pass loop, see there)
+  int tid = SK ? tid_opaque : (int)threadIdx.x;
+  int lane = tid & 63;
   const int li = lane & 15, lq = lane >> 4;
   const unsigned lq16 = (unsigned)(lq * 16);
   const int tile = item / ncb;
@@ -1445,23 +1458,39 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     pf_val = __hip_atomic_fetch_add(sk_state + (pf_which == 1 ? 0 : 16) + ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (SK) { sk_pf = pf_now ? pf_which : 0; tile_parked = tile; park_all(true); }
   if (ASM) {
-    // the whole pass loop, prologue and last pending write included (tile4_loop_asm.inc)
+    // the whole pass loop, prologue and last pending write included (tile4_loop_asm.inc).
+    // NO per-lane value may be live across this block or reach it from the set-up above.  The block clobbers v60..v255, so hipcc
+    // moves whatever vector value it needs later into a low register beforehand -- and it placed such a copy at the top of the
+    // block that joins the `tid < 64` table build, IN FRONT of the `s_or_b64 exec` that re-enables wave 1 (round 6, found with
+    // rocgdb: wave 1 of a stream-K workgroup kept the previous piece's register contents as its "(lane & 7) * 4" and loaded the
+    // batch-norm statistics of the epilogue from a wild address).  Hence: the lane id is taken from the hardware right here
+    // (v_mbcnt, volatile asm: nothing derived from it can be computed earlier) for the loop's operands, and again behind the
+    // block for everything the epilogue needs; scalars cross in scalar registers / v_writelane lanes, which do not depend on EXEC.
+    int l2;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
     const unsigned wstep = (unsigned)(Co / 16) * 1024u, wbase = (unsigned)(w * COS) * 1024u;
-    unsigned wlane16 = (unsigned)lane * 16u, lq16_v = lq16, li8_0 = li8[0], li8_1 = li8[1];
+    const unsigned li_2 = (unsigned)l2 & 15u, lq_2 = (unsigned)l2 >> 4;
+    unsigned wlane16 = (unsigned)l2 * 16u, lq16_v = lq_2 * 16u, li8_0 = li_2 * 8u, li8_1 = (li_2 + 16u) * 8u;
+    unsigned tile0_2 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)o_tile + ((unsigned)(32 * w) + 4u * lq_2) * 4u -
+                       (unsigned)o0 * (unsigned)(OS * 4);
     if (INCOL == 0)
       asm volatile(SCN_T4_ASM_INCOL0
                    :
                    : [in] "s"(in_rsrc), [wp] "s"(wp_rsrc), [ru] "s"(ru_rsrc), [gt] "s"(gt_s), [row_bytes] "s"(row_bytes), [os_u] "s"(os_u),
-                     [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v),
+                     [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0_2), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v),
                      [li8_0] "v"(li8_0), [li8_1] "v"(li8_1)
                    : SCN_T4_ASM_CLOBBERS);
     else
       asm volatile(SCN_T4_ASM_INCOL1
                    :
                    : [in] "s"(in_rsrc), [wp] "s"(wp_rsrc), [ru] "s"(ru_rsrc), [gt] "s"(gt_s), [row_bytes] "s"(row_bytes), [os_u] "s"(os_u),
-                     [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v),
+                     [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0_2), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v),
                      [li8_0] "v"(li8_0), [li8_1] "v"(li8_1)
                    : SCN_T4_ASM_CLOBBERS);
+    int l3;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l3));
+    lane = l3;
+    tid = 64 * w + l3;
   }
   Ent E0 = ASM ? Ent{0u, 0u} : entry(0);
   if (SK && pf_now && !(rem(E0) > 0) && tid == 0) sk_slot[pf_slot] = (int)pf_val;  // (an item without passes: no prologue)
@@ -1820,7 +1849,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   }  // pieces
   if ((DBG & 256) && lane == 0)
     for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], seg[i]);
-  if (SK && tid == 0 && na_items_a != (int)0x80000000 && !sk_static_a) {  // the last workgroup out leaves the counters as it found them (every flag was reset by its reader)
+  if (SK && thread0() && na_items_a != (int)0x80000000 && !sk_static_a) {  // the last workgroup out leaves the counters as it found them (every flag was reset by its reader)
     if (__hip_atomic_fetch_add(sk_state + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
 #pragma unroll
       for (int i = 0; i < 11; ++i)

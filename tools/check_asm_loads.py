@@ -209,6 +209,38 @@ def check_kernel_cfg(name, lines):
     return list(errors.values())
 
 
+def check_copies_under_mask(name, lines):
+    """ASM = 1 instantiations of k_conv_tile4 (the pass loop is one asm block that clobbers v60..v255): hipcc moves every vector
+    value that must survive the block into a low register, and round 6 found such a copy at the TOP of the block that joins a
+    divergent region -- in front of the `s_or_b64 exec, exec, ...` that re-enables the masked lanes, so a whole wave kept stale
+    register contents.  The kernel now keeps no per-lane value across the block; this check refuses any build in which register copies or
+    spill code -- and nothing else -- stand between a block label and the EXEC restore of that block."""
+    errors = []
+    i = 0
+    while i < len(lines):
+        if re.match(r"^\.LBB\d+_\d+:", lines[i]):
+            j = i + 1
+            pending = []
+            while j < len(lines):
+                t = lines[j].split(";")[0].strip()
+                if not t:
+                    j += 1
+                    continue
+                if re.match(r"^\.L\w+:", t) or t.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_barrier")) or "#ASM" in lines[j]:
+                    break
+                if re.match(r"s_or_b64 exec, exec,", t):
+                    for no, v in pending:
+                        errors.append("%s: line %d `%s` runs before the EXEC restore of its block (line %d)" % (name, no + 1, v, j + 1))
+                    break
+                if t.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr", "scratch_load", "scratch_store")):
+                    pending.append((j, t))  # (register copies / spill code: what the register allocator inserts at a block's top)
+                elif t.startswith(("v_", "ds_", "buffer_", "global_", "flat_")) and not t.startswith(("v_readlane", "v_writelane", "v_readfirstlane")):
+                    break               # (real work of a divergent region: its values belong to the active lanes)
+                j += 1
+        i += 1
+    return errors
+
+
 def main():
     args = [a for a in sys.argv[1:] if a != "--tuning"]
     if args:
@@ -236,6 +268,8 @@ def main():
         # (ASM = 1 instantiations: the pass loop is ONE asm block -- tools/gen_tile4_loop.py checks every path through it on its
         #  own instruction list -- and the path-exact walk above has covered it again as emitted)
         asm_loop = re.search(r"k_conv_tile4ILi\d+ELin?\d+ELi\d+ELi\d+ELi\d+ELi1E", name) is not None
+        if asm_loop:
+            errors += check_copies_under_mask(name, lines[st:end + 1])
         if "k_conv_tile6" not in name and not stream_k and not asm_loop and not re.search(r"k_conv_tile4ILi\d*[13579]ELi", name):
             errors += check_kernel(name, lines[st:end + 1])  # and the older linear walk of the loop (twice), where it applies
                                                              # (the "no tile update" timing builds have another loop shape)

@@ -30,6 +30,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "occuseg_amd", "csrc", "tile4_loop_asm.inc")
 
+DEBUG_SKIP = False
 VB = 60   # first vector register owned by the loop (v60 .. v255)
 SB = 52   # first scalar register owned by the loop (s52 .. s95)
 
@@ -220,6 +221,10 @@ class Gen(object):
                            suse=[E[i + 1] + h, E[i + 1] + h + 1])
 
     def prologue(self, L):
+        if DEBUG_SKIP:  # (debugging aid, tuning builds: leave the loop at once when the operand says so)
+            self.s_raw("s_mov_b32 %s, %%[skip]" % sr(T[0]), sdef=[T[0]])
+            self.s_raw("s_cmp_lg_u32 %s, 0" % sr(T[0]), suse=[T[0]])
+            self.branch("s_cbranch_scc1", L("END"))
         for i in range(4):
             self.emit("s_load_dwordx4 %s, %%[gt], %s" % (sr(E[i], 4), "0x%x" % (16 * i)), "smem", sdef=rng(E[i], 4))
         self.s_raw("s_movk_i32 %s, 64" % sr(TOFF), sdef=[TOFF])
