@@ -1473,20 +1473,25 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     unsigned wlane16 = (unsigned)l2 * 16u, lq16_v = lq_2 * 16u, li8_0 = li_2 * 8u, li8_1 = (li_2 + 16u) * 8u;
     unsigned tile0_2 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)o_tile + ((unsigned)(32 * w) + 4u * lq_2) * 4u -
                        (unsigned)o0 * (unsigned)(OS * 4);
-    if (INCOL == 0)
-      asm volatile(SCN_T4_ASM_INCOL0
-                   :
-                   : [in] "s"(in_rsrc), [wp] "s"(wp_rsrc), [ru] "s"(ru_rsrc), [gt] "s"(gt_s), [row_bytes] "s"(row_bytes), [os_u] "s"(os_u),
-                     [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0_2), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v),
-                     [li8_0] "v"(li8_0), [li8_1] "v"(li8_1)
-                   : SCN_T4_ASM_CLOBBERS);
-    else
-      asm volatile(SCN_T4_ASM_INCOL1
-                   :
-                   : [in] "s"(in_rsrc), [wp] "s"(wp_rsrc), [ru] "s"(ru_rsrc), [gt] "s"(gt_s), [row_bytes] "s"(row_bytes), [os_u] "s"(os_u),
-                     [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0_2), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v),
-                     [li8_0] "v"(li8_0), [li8_1] "v"(li8_1)
-                   : SCN_T4_ASM_CLOBBERS);
+#define SCN_T4_ASM_OPERANDS                                                                                                         \
+  :                                                                                                                                 \
+  : [in] "s"(in_rsrc), [wp] "s"(wp_rsrc), [ru] "s"(ru_rsrc), [gt] "s"(gt_s), [row_bytes] "s"(row_bytes), [os_u] "s"(os_u),         \
+    [wstep] "s"(wstep), [wbase] "s"(wbase), [tile0] "v"(tile0_2), [wlane16] "v"(wlane16), [lq16] "v"(lq16_v), [li8_0] "v"(li8_0),  \
+    [li8_1] "v"(li8_1)                                                                                                              \
+  : SCN_T4_ASM_CLOBBERS
+    if (ASM == 1 && INCOL == 0) asm volatile(SCN_T4_ASM_INCOL0 SCN_T4_ASM_OPERANDS);
+    else if (ASM == 1) asm volatile(SCN_T4_ASM_INCOL1 SCN_T4_ASM_OPERANDS);
+#ifdef SCN_TUNING  // timing-only ablations of the loop (tools/gen_tile4_loop.py ABLATIONS; tools/bench_conv.py --asm)
+    else if (ASM == 2) asm volatile(SCN_T4_ASM_ABL2 SCN_T4_ASM_OPERANDS);
+    else if (ASM == 3) asm volatile(SCN_T4_ASM_ABL3 SCN_T4_ASM_OPERANDS);
+    else if (ASM == 4) asm volatile(SCN_T4_ASM_ABL4 SCN_T4_ASM_OPERANDS);
+    else if (ASM == 5) asm volatile(SCN_T4_ASM_ABL5 SCN_T4_ASM_OPERANDS);
+    else if (ASM == 6) asm volatile(SCN_T4_ASM_ABL6 SCN_T4_ASM_OPERANDS);
+    else if (ASM == 7) asm volatile(SCN_T4_ASM_ABL7 SCN_T4_ASM_OPERANDS);
+    else if (ASM == 8) asm volatile(SCN_T4_ASM_ABL8 SCN_T4_ASM_OPERANDS);
+    else if (ASM == 9) asm volatile(SCN_T4_ASM_ABL9 SCN_T4_ASM_OPERANDS);
+#endif
+#undef SCN_T4_ASM_OPERANDS
     int l3;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l3));
     lane = l3;
@@ -4225,7 +4230,18 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
         if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_SK(1, 1); else SCN_LAUNCH_T4_SK(0, 1); }
         else { if (in_col) SCN_LAUNCH_T4_SK(1, 0); else SCN_LAUNCH_T4_SK(0, 0); }
       } else if (gtab != nullptr) {
-        if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_GT(1, 1); else SCN_LAUNCH_T4_GT(0, 1); }
+        if (g_conv_asm >= 2 && !in_col) {
+          switch (g_conv_asm) {
+            case 2: SCN_LAUNCH_T4_GT(0, 2); break;
+            case 3: SCN_LAUNCH_T4_GT(0, 3); break;
+            case 4: SCN_LAUNCH_T4_GT(0, 4); break;
+            case 5: SCN_LAUNCH_T4_GT(0, 5); break;
+            case 6: SCN_LAUNCH_T4_GT(0, 6); break;
+            case 7: SCN_LAUNCH_T4_GT(0, 7); break;
+            case 8: SCN_LAUNCH_T4_GT(0, 8); break;
+            default: SCN_LAUNCH_T4_GT(0, 9); break;
+          }
+        } else if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_GT(1, 1); else SCN_LAUNCH_T4_GT(0, 1); }
         else { if (in_col) SCN_LAUNCH_T4_GT(1, 0); else SCN_LAUNCH_T4_GT(0, 0); }
       }
 #undef SCN_LAUNCH_T4_SK

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--dw", action="store_true")
     ap.add_argument("--extra-lds", default="0", help="comma list: unused dynamic LDS bytes per k_conv_tile4 workgroup (occupancy probe)")
     ap.add_argument("--dw-variants", default="s0,0,s0,0")
+    ap.add_argument("--asm", default="", help="comma list of tuning key 28 values: 0 = hipcc's pass loop, 1 = the assembly loop, 2.. = "
+                                              "its timing-only ablations (tools/gen_tile4_loop.py ABLATIONS); stream-K off for these")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.use_tuning_build()
@@ -64,6 +66,16 @@ def main():
                     lib.scn_set_tuning(4, int(v) // 100000)
                     ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
                     line += "  v%s%s %.3f ms %.1f TF" % (v, "" if xl == "0" else "+%sB" % xl, ms, flops / ms / 1e9)
+                for a in [int(t) for t in args.asm.split(",") if t]:
+                    lib.scn_set_tuning(0, 4)
+                    lib.scn_set_tuning(1, 0)
+                    lib.scn_set_tuning(16, 0)
+                    lib.scn_set_tuning(28, a)
+                    ms = timeit(lambda: SCN._conv(x, out, w, None, rb, 0, 1, n))
+                    line += "  asm%d %.3f ms %.1f TF" % (a, ms, flops / ms / 1e9)
+                if args.asm:
+                    lib.scn_set_tuning(28, 1)
+                    lib.scn_set_tuning(16, 1)
                 for dv in (args.dw_variants.split(',') if args.dw else []):
                     # "s<n>": the LDS-staged k_dw_tile (tuning key 12 = 0) with ablation n; plain numbers: default kernel choice
                     lib.scn_set_tuning(12, 0 if dv.startswith("s") else 1)

@@ -98,9 +98,16 @@ def rng(b, n):
     return range(b, b + n)
 
 
+# timing-only ablations (tuning library, tools/bench_conv.py --asm): what each part of a pass costs.  Wrong results by design.
+ABLATIONS = {2: ("nowait",), 3: ("notile",), 4: ("norows",), 5: ("norows", "noidx", "now", "nowait"),
+             6: ("norows", "noidx", "now", "nowait", "notile"), 7: ("nomfma",), 8: ("nomfma", "nowait"),
+             9: ("norows", "noidx", "now", "nowait", "notile", "nopieces")}
+
+
 class Gen(object):
-    def __init__(self, incol):
+    def __init__(self, incol, flags=()):
         self.incol = incol
+        self.flags = set(flags)
         self.ins = []
 
     def emit(self, *a, **k):
@@ -138,6 +145,8 @@ class Gen(object):
 
     # ---- vector / memory
     def mfma(self, acc, a, b, zero):
+        if "nomfma" in self.flags:
+            return
         c = "0" if zero else vr(acc, 4)
         self.emit("v_mfma_f32_16x16x4_f32 %s, %s, %s, %s" % (vr(acc, 4), vr(a), vr(b), c), "mfma",
                   vdef=rng(acc, 4), vuse=[a, b] + ([] if zero else list(rng(acc, 4))))
@@ -148,26 +157,36 @@ class Gen(object):
         self.emit("v_mad_u32_u24 %s, %s, %%[os_u], %%[tile0]" % (vr(oad), vr(dst)), "valu", vdef=[oad], vuse=[dst])
 
     def load_idx(self, g, e):
+        if "noidx" in self.flags:
+            return
         self.emit("buffer_load_dwordx2 %s, %%[li8_%d], %%[ru], %s offen" % (vr(PR(g), 2), g, sr(e)), "vmem",
                   vdef=rng(PR(g), 2), suse=[e], n=2)
 
     def load_row(self, dst, g, c):
+        if "norows" in self.flags:
+            return
         off = "" if c == 0 else " offset:%d" % (64 * c)
         self.emit("buffer_load_dwordx4 %s, %s, %%[in], %s offen%s" % (vr(dst, 4), vr(OFF(g)), sr(RSO), off), "vmem",
                   vdef=rng(dst, 4), vuse=[OFF(g)], suse=[RSO], n=4)
 
     def load_w(self, dst, sp, q):
+        if "now" in self.flags:
+            return
         off = "" if q == 0 else " offset:1024"
         self.emit("buffer_load_dwordx4 %s, %%[wlane16], %%[wp], %s offen%s" % (vr(dst, 4), sr(WSO[sp]), off), "vmem",
                   vdef=rng(dst, 4), suse=[WSO[sp]], n=4)
 
     def tile_read(self, addr):
+        if "notile" in self.flags:
+            return
         for q in range(2):
             off = "" if q == 0 else " offset:64"
             self.emit("ds_read_b128 %s, %s%s" % (vr(OLD(q), 4), vr(addr), off), "ds_read", vdef=rng(OLD(q), 4), vuse=[addr])
 
     def tile_add_write(self, g, addr, m16, tmp):
         """OLD += ACC[g]; masked write back"""
+        if "notile" in self.flags:
+            return
         for q in range(2):
             for h in range(2):
                 o, a = OLD(q) + 2 * h, ACC(g, q) + 2 * h
@@ -180,6 +199,8 @@ class Gen(object):
         self.exec_all()
 
     def waitcnt(self, vm=None, lgkm=None):
+        if "nowait" in self.flags and vm == 8 and lgkm is None:
+            return
         parts = []
         if vm is not None:
             parts.append("vmcnt(%d)" % vm)
@@ -268,6 +289,13 @@ class Gen(object):
         self.label(L("B%d%d" % (r, w)))
 
         def piece(m):
+            if "nopieces" in self.flags:   # (MFMAs + loop control only; the table entry still has to come in)
+                if m == 8:
+                    self.emit("s_load_dwordx4 %s, %%[gt], %s" % (sr(E[4], 4), sr(TOFF)), "smem", sdef=rng(E[4], 4), suse=[TOFF])
+                    self.s("s_add_u32", TOFF, TOFF, "16")
+                elif m == 15:
+                    self.waitcnt(lgkm=0)
+                return
             if m == 0:      # pending group 1 of the previous pass: read its tile rows; addresses of (p+2, group 0)
                 self.tile_read(OAD(on, 1))
                 self.mads(0, OAD(on, 0))
@@ -503,6 +531,13 @@ def main():
         print("incol %d: %d instructions, %d (label, state) pairs checked, one two-group pass: %s" % (incol, len(g.ins), nstates, kinds))
         out.append("#define SCN_T4_ASM_INCOL%d \\" % incol)
         out.append(" \\\n".join('  "%s\\n\\t"' % i.text for i in g.ins))
+        out.append("")
+    for n, flags in sorted(ABLATIONS.items()):
+        g = Gen(0, flags).build()
+        out.append("#ifdef SCN_TUNING  // timing-only ablation %d: %s" % (n, " ".join(flags)))
+        out.append("#define SCN_T4_ASM_ABL%d \\" % n)
+        out.append(" \\\n".join('  "%s\\n\\t"' % i.text for i in g.ins))
+        out.append("#endif")
         out.append("")
     clob = ['"v%d"' % v for v in range(VB, V_END)] + ['"s%d"' % s for s in range(SB, S_END)] + ['"vcc"', '"scc"', '"memory"']
     out.append("#define SCN_T4_ASM_CLOBBERS " + ", ".join(clob))
