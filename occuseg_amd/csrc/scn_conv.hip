@@ -915,6 +915,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     return (void *)(size_t)((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32);
   };
+  // Wave shuffles with the lane id handed in.  HIP's __shfl* take it from v_mbcnt, which hipcc computes once at the top of the
+  // kernel and keeps: in the ASM variant that register would live across the assembly pass loop (spilled to scratch, and see the
+  // note at the loop about vector values that cross it) -- there the caller passes the lane id it took from the hardware last.
+  auto shfl_i = [](int v, int src_lane) __attribute__((always_inline)) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); };
+  auto shfl_f = [](float v, int src_lane) __attribute__((always_inline)) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+  };
   // ---- what this workgroup computes: ONE item = (tile, column block), all of its passes -- or (SK) a sequence of PIECES:
   // passes [p_lo, p_hi) of an item's table, starting from bias + residual or from slab `seed_slab`, ending in `out` (with the
   // column statistics) or in slab `out_slab`
@@ -1284,10 +1291,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     int pos = npl * nch;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(pos, o);
+      const int y = ASM ? shfl_i(pos, lane - o) : __shfl_up(pos, o);
       if (lane >= o) pos += y;
     }
-    const int total_item = __shfl(pos, 63);
+    const int total_item = ASM ? shfl_i(pos, 63) : __shfl(pos, 63);
     pos -= npl * nch;
     // (SK: the piece holds the entries [p_lo, p_hi) of the item's table, stored from index 0)
     const int t_lo = SK ? min(p_lo, total_item) : 0, t_hi = SK ? min(p_hi, total_item) : total_item;
@@ -1312,7 +1319,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         ++pos;
       }
     if (tid < 8) {  // sentinels: empty passes
-      if (ASM) ((uint4 *)gt_region)[total + tid] = make_uint4(0u, 0u, 0u, 0u);
+      if (ASM) {
+        // (a zero that hipcc cannot hoist out of the piece loop: as a loop-invariant vector it was kept in four registers across
+        //  the assembly block -- spilled to scratch)
+        const unsigned zz = (unsigned)tid >> 31;
+        ((uint4 *)gt_region)[total + tid] = make_uint4(zz, zz, zz, zz);
+      }
       else if (GT) gt[total + tid] = make_uint2(0u, 0u);
       else { ptab[total + tid][0] = 0u; ptab[total + tid][1] = 0u; }
     }
@@ -1752,7 +1764,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     float *const fin = slabs;
     const bool st_on = colstats.out != nullptr;
     floatx4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
-    StatsCols sc;
+    StatsCols sc{};  // (value-initialised: left undefined, its twelve registers became state carried from piece to piece -- spilled)
     sc.bn = false;
     if (st_on) sc.init(colstats, co_w + (lane & 7) * 4);
 #pragma unroll
@@ -1809,8 +1821,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
       for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          cs[e] += __shfl_xor(cs[e], o);
-          css[e] += __shfl_xor(css[e], o);
+          cs[e] += ASM ? shfl_f(cs[e], lane ^ o) : __shfl_xor(cs[e], o);
+          css[e] += ASM ? shfl_f(css[e], lane ^ o) : __shfl_xor(css[e], o);
         }
       if (lane < 8) {
         *(floatx4 *)(colstats.out + ((int64_t)tile_e * 2 + 0) * Co + co_w + lane * 4) = cs;
@@ -1825,7 +1837,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
   // launch inside the train step.)
   const bool stats = colstats.out != nullptr && ksplit == 1;
   floatx4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
-  StatsCols sc;
+  StatsCols sc{};  // (value-initialised: left undefined, its twelve registers became state carried from piece to piece -- spilled)
   sc.bn = false;
   if (stats) sc.init(colstats, co0 + 32 * w + (lane & 7) * 4);  // (i & 7 == lane & 7: a lane keeps its plane quad)
   for (int i = lane; i < rows * 8; i += 64) {
@@ -1839,8 +1851,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        cs[e] += __shfl_xor(cs[e], o);
-        css[e] += __shfl_xor(css[e], o);
+        cs[e] += ASM ? shfl_f(cs[e], lane ^ o) : __shfl_xor(cs[e], o);
+        css[e] += ASM ? shfl_f(css[e], lane ^ o) : __shfl_xor(css[e], o);
       }
     if (lane < 8) {
       *(floatx4 *)(colstats.out + ((int64_t)tile_e * 2 + 0) * Co + co0 + 32 * w + lane * 4) = cs;
