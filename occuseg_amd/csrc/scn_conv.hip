@@ -1279,7 +1279,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int j = 0; j < NIT; ++j) *(floatx4 *)(o_tile + ((lane >> 3) + 8 * j) * OS + 32 * w + c4) = rv[j] + bv;
     if (!SK && lane < 8) *(floatx4 *)(o_tile + M * OS + 32 * w + c4) = floatx4{0.f, 0.f, 0.f, 0.f};  // (row M: unused sink of older builds)
   }
-  if (tid < 64) {  // pass table: lane k tabulates the passes of offset k at the position given by a wave scan
+  if (w == 0) {  // pass table: lane k of wave 0 tabulates the passes of offset k at the position given by a wave scan.  (`w` is a
+    // scalar: a branch, not an EXEC mask -- hipcc placed register copies and constants that wave 1 needs later in front of the
+    // `s_or_b64 exec` that ended the `tid < 64` form of this region, see the note at the assembly pass loop)
     int s = 0, c = 0;
     // ksplit > 1 (launches with few tiles, the coarse UNet levels): this workgroup takes the offsets k == blockIdx.y
     // (mod ksplit) and writes its partial tile to slab blockIdx.y of the launcher's workspace (k_split_reduce adds them)
