@@ -33,7 +33,7 @@ import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic.json")
 
 
 def build_net(scn, m):
@@ -646,10 +646,10 @@ def main():
                 tj = json.load(open(TRAFFIC_FILE))
                 if tj.get("source_hash") == source_hash():
                     counted = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
-                    traffic_note = ("profiles/r05_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
+                    traffic_note = ("profiles/r06_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
                                     "separate passes; FETCH_SIZE x2 per the gfx950 note), same kernel sources")
                 else:
-                    traffic_note = "profiles/r05_traffic.json was measured on other kernel sources: refused"
+                    traffic_note = "profiles/r06_traffic.json was measured on other kernel sources: refused"
             except (OSError, ValueError, KeyError):
                 counted = {}
         kernels = {}

@@ -11,7 +11,7 @@ import sys
 
 
 def is_kernel(name, which):
-    split = "k_conv_tile4<0, 0, 1, 0, 1>" in name or "k_conv_tile4<0, 1, 1, 0, 1>" in name
+    split = any(t in name for t in ("k_conv_tile4<0, 0, 1, 0, 1>", "k_conv_tile4<0, 1, 1, 0, 1>", "k_conv_tile4<0, 0, 1, 0, 1,", "k_conv_tile4<0, 1, 1, 0, 1,"))
     if which == "conv_tile4":
         return "k_conv_tile4" in name and not split
     if which == "conv_tile4_split":

@@ -14,8 +14,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # (the offset-split instantiation of k_conv_tile4 -- template arguments <DBG, INCOL, GT, SK, SPLIT = 1>: the coarse levels -- is a
-#  kernel of its own in bench.py's tables)
-KERNELS = (("k_conv_tile4<0, 0, 1, 0, 1>", "conv_tile4_split"), ("k_conv_tile4<0, 1, 1, 0, 1>", "conv_tile4_split"), ("k_conv_tile4", "conv_tile4"), ("k_conv_tile2", "conv_tile2"), ("k_conv_expand", "conv_expand"),
+#  kernel of its own in bench.py's tables; since round 6 a sixth argument, ASM, follows)
+KERNELS = (("k_conv_tile4<0, 0, 1, 0, 1,", "conv_tile4_split"), ("k_conv_tile4<0, 1, 1, 0, 1,", "conv_tile4_split"), ("k_conv_tile4<0, 0, 1, 0, 1>", "conv_tile4_split"), ("k_conv_tile4<0, 1, 1, 0, 1>", "conv_tile4_split"), ("k_conv_tile4", "conv_tile4"), ("k_conv_tile2", "conv_tile2"), ("k_conv_expand", "conv_expand"),
            ("k_conv_tile<", "conv_tile_fallback"), ("k_conv_generic", "conv_generic"), ("k_conv_stem", "conv_stem"), ("k_dw_stem", "dw_stem"), ("k_dw_tile", "dw_tile"),
            ("k_bn_", "bn"), ("k_dw_narrow", "dw_narrow"))
 
