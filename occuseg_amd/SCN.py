@@ -890,6 +890,35 @@ def weights_changed():
     _WEPOCH[0] += 1
 
 
+# Forward scopes (round 6): every container of the operator API brackets its forward with forward_enter / forward_exit, and the
+# OUTERMOST one starts a new weight epoch -- whatever was written into a weight tensor since the last forward sweep, by any
+# means (a write through `.data` moves no version counter and fires no hook), is seen by the next sweep, as in the reference,
+# which reads the module's weights on every call (sparseconvnet/SCN/CUDA/Convolution.cpp:105-162).  A convolution called
+# directly, outside any container, re-packs its own weights (weight_touched).  Cost: none beyond what a forward pass already
+# paid -- the epoch moved at its InputLayer call anyway, and epochs that move with no lookup in between cost nothing.
+_FWD_DEPTH = [0]
+
+
+def forward_enter():
+    if _FWD_DEPTH[0] == 0:
+        _WEPOCH[0] += 1
+    _FWD_DEPTH[0] += 1
+
+
+def forward_exit():
+    _FWD_DEPTH[0] -= 1
+
+
+def weight_touched(weight):
+    """the packed copies of THIS weight tensor are re-made at their next use (one small launch each)"""
+    base = weight._base if weight._base is not None else weight
+    for t in (False, True):
+        for r in (False, True):
+            ent = _WPACK.get((id(base), weight.data_ptr(), t, r))
+            if ent is not None:
+                ent.version = -1
+
+
 def invalidate_weight_cache():
     _WPACK.clear()
     _WTABLE.clear()

@@ -13,7 +13,26 @@ from . import counters
 from .tensor import GradJoin, SparseConvNetTensor, apply_function, like_empty, optionalTensor
 
 
+def _scoped(fn):
+    """bracket a container's forward with SCN.forward_enter / forward_exit: the outermost container of a forward sweep starts
+    a new weight epoch (SCN.py, "Forward scopes")"""
+    def forward(self, *args, **kwargs):
+        SCN.forward_enter()
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            SCN.forward_exit()
+    forward.__doc__ = fn.__doc__
+    return forward
+
+
 class Sequential(torch.nn.Sequential):
+    @_scoped
+    def forward(self, input):
+        for module in self._modules.values():
+            input = module(input)
+        return input
+
     def add(self, module):
         self._modules[str(len(self._modules))] = module
         return self
@@ -42,6 +61,7 @@ def _like(first, features):
 class ConcatTable(Sequential):
     """apply every child to the same input, return the list of results"""
 
+    @_scoped
     def forward(self, input):
         return [child(input) for child in self._modules.values()]
 
@@ -55,6 +75,7 @@ class ResidualConcatTable(ConcatTable):
     shortcut is handed to that last convolution, which adds it inside its kernel (the output tile starts from the
     shortcut's rows).  Returns a one-element list, so the AddTable that follows has nothing left to add."""
 
+    @_scoped
     def forward(self, input):
         from .conv import SubmanifoldConvolution
         children = list(self._modules.values())
@@ -91,6 +112,7 @@ class JoinConcatTable(ConcatTable):
     gradient -- can be added inside the batch norm's apply pass instead of by an autograd add kernel: a GradJoin is handed
     to the batch norm and offered (un-armed) to whoever consumes the table; a JoinTable arms it."""
 
+    @_scoped
     def forward(self, input):
         from .norm import BatchNormalization
         children = list(self._modules.values())
@@ -227,6 +249,8 @@ class NetworkInNetwork(Module):
 
     def forward(self, input, join=None):
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, input.features.shape)
+        if SCN._FWD_DEPTH[0] == 0:  # called directly, outside any container's forward (see SCN.py, "Forward scopes")
+            SCN.weight_touched(self.weight)
         return _like(input, apply_function(_NiNFunction, input.features, self.weight, optionalTensor(self, "bias"), join))
 
     def input_spatial_size(self, out_size):

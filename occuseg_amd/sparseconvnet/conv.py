@@ -157,6 +157,8 @@ class _RuleConv(Module):
         inside the convolution kernel; ``join``: see tensor.GradJoin (the residual is the block's input)"""
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, self.nOut, input)
         assert residual is None or self.kind == "submanifold"
+        if SCN._FWD_DEPTH[0] == 0:  # called directly, outside any container's forward: its weights may have been written since
+            SCN.weight_touched(self.weight)
         out_size = self.output_spatial_size(input.spatial_size)
         output = SparseConvNetTensor(metadata=input.metadata, spatial_size=out_size)
         # training: the kernel also emits the column statistics of its result (taken from the output tile while it is in

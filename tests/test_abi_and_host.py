@@ -28,17 +28,17 @@ def test_library_exports_every_declared_symbol():
     assert not hasattr(lib, "scn_set_tuning") and not hasattr(lib, "scn_debug_stamps")
     assert os.path.exists(_lib.TUNING_LIB_PATH)
     # big launches (k_conv_tile4) keep one pass table per workgroup in the workspace (116 entries -> 120: whole 64-byte lines,
-    # x 8 bytes); as stream-K launches -- 4688 tiles are 4.58 rounds of 1024 resident workgroups, 1383 tiles x 2 column blocks 2.70:
+    # x 16 bytes since round 6: the assembly pass loop's entries carry the weight offset and the lane masks); as stream-K launches -- 4688 tiles are 4.58 rounds of 1024 resident workgroups, 1383 tiles x 2 column blocks 2.70:
     # both would leave more than 3 % of the last round empty -- two pass tables per persistent workgroup + one 128 x 64 fp32 slab
     # per slice; 4096 tiles are whole rounds: one workgroup per tile.  A coarse level (few tiles) splits its offsets 9- or 27-fold
-    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64, 0) == 1024 * 2 * 120 * 8 + 1024 * 128 * 64 * 4
-    assert lib.scn_conv_workspace_bytes(27, 177001, 177001, 177001, 128, 128, 0) == 1024 * 2 * 224 * 8 + 1024 * 128 * 64 * 4
-    assert lib.scn_conv_workspace_bytes(27, 524288, 524288, 524288, 64, 64, 0) == 4096 * 120 * 8
+    assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 64, 64, 0) == 1024 * 2 * 120 * 16 + 1024 * 128 * 64 * 4
+    assert lib.scn_conv_workspace_bytes(27, 177001, 177001, 177001, 128, 128, 0) == 1024 * 2 * 224 * 16 + 1024 * 128 * 64 * 4
+    assert lib.scn_conv_workspace_bytes(27, 524288, 524288, 524288, 64, 64, 0) == 4096 * 120 * 16
     assert lib.scn_conv_workspace_bytes(27, 600000, 600000, 600000, 20, 12, 0) == 0  # generic kernel: none
     # (round 5: on k_conv_tile4 too -- 16 tiles x 6 column blocks x 27 workgroups: the 27 slabs, then a pass table of one offset x six
     #  chunks x <= 4 passes + 8 sentinels = 32 entries per workgroup)
     assert lib.scn_conv_plan(27, 2000, 2000, 2000, 384, 384, 0) == 427
-    assert lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384, 0) == 27 * 2000 * 384 * 4 + 16 * 6 * 27 * 32 * 8
+    assert lib.scn_conv_workspace_bytes(27, 2000, 2000, 2000, 384, 384, 0) == 27 * 2000 * 384 * 4 + 16 * 6 * 27 * 32 * 16
     assert lib.scn_conv_plan(27, 7000, 7000, 7000, 256, 256, 0) == 409 and lib.scn_conv_stats_blocks(27, 7000, 7000, 7000, 256, 256, 0) == 55
     assert lib.scn_conv_stats_blocks(27, 2000, 2000, 2000, 384, 384, 0) == 0  # (<= 2048 rows: the batch norm's one-launch form)
     # size queries are host-only arithmetic: safe without a GPU
@@ -198,3 +198,34 @@ def test_size_keys_are_cached_per_tensor_and_version():
     t[2] = 4096
     assert SCN._size_key(t) == (4096, 4096, 4096)
     assert SCN._size_key([3, 3, 3]) == (3, 3, 3) and SCN._size_key(torch.tensor([2, 2, 2]) // 2) == (1, 1, 1)
+
+
+def test_forward_scopes_start_one_weight_epoch_per_sweep():
+    """SCN.py "Forward scopes": the OUTERMOST container of a forward sweep starts a new weight epoch (so that a write through
+    `.data` between two sweeps over the same built input is seen, as in the reference, which reads the weights on every
+    call), nested containers do not, and an exception inside a container leaves the depth where it was."""
+    import occuseg_amd
+    from occuseg_amd import SCN
+    scn = occuseg_amd.install()
+    seen = []
+
+    class Probe(scn.Identity):
+        def forward(self, input):
+            seen.append((SCN._FWD_DEPTH[0], SCN._WEPOCH[0]))
+            return input
+
+    class Boom(scn.Identity):
+        def forward(self, input):
+            raise ValueError("boom")
+
+    net = scn.Sequential().add(Probe()).add(scn.Sequential().add(Probe()).add(scn.ConcatTable().add(Probe()).add(Probe())))
+    e0 = SCN._WEPOCH[0]
+    assert SCN._FWD_DEPTH[0] == 0
+    net("x")
+    assert [d for d, _ in seen] == [1, 2, 3, 3] and {e for _, e in seen} == {e0 + 1} and SCN._FWD_DEPTH[0] == 0
+    net("x")
+    assert seen[-1][1] == e0 + 2  # the next sweep: the next epoch
+    bad = scn.Sequential().add(scn.Sequential().add(Boom()))
+    with pytest.raises(ValueError):
+        bad("x")
+    assert SCN._FWD_DEPTH[0] == 0 and SCN._WEPOCH[0] == e0 + 3

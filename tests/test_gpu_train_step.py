@@ -110,12 +110,15 @@ def test_reused_input_tensor_and_manual_sgd(gpu):
             finally:
                 SCN.WPACK_CACHE = True
         assert torch.equal(got, want), step
-    # and without any signal at all the documented call does it
+    # and without any signal at all -- a write through `.data` between two forward sweeps over the SAME built input, under
+    # no_grad, no optimizer, no backward, no InputLayer call (rounds 3-5: "call SCN.invalidate_weight_cache() yourself") -- the
+    # next sweep sees the new weights by construction: the outermost container of a sweep starts a weight epoch, a convolution
+    # called outside any container re-packs its own weights (SCN.py "Forward scopes"; the reference reads the module's
+    # weights on every call, sparseconvnet/SCN/CUDA/Convolution.cpp:105-162)
     with torch.no_grad():
         before = run(x0)
         for p in net.parameters():
             p.data.mul_(1.5)
-        SCN.invalidate_weight_cache()
         after = run(x0)
         SCN.WPACK_CACHE = False
         try:
