@@ -430,6 +430,8 @@ def check(gen):
         while pc < len(ins):
             i = ins[pc]
             steps += 1
+            if len(errors) > 200:
+                break
             if i.kind == "label":
                 k = (pc, st.key())
                 if k in seen:
@@ -495,6 +497,8 @@ def check(gen):
                 errors.append("end of the loop with operations in flight")
         if steps > 20_000_000:
             errors.append("checker did not converge")
+            break
+        if len(errors) > 200:  # (a broken program: every trip round the loop adds states; the first errors say it all)
             break
     # every label reached?
     reached = {pc for pc, _ in seen}
