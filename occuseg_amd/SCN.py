@@ -221,6 +221,47 @@ def _sk_check(words, device):
         "lower-priority launch held part of the chip for over a second)")
 
 
+# The tickets of the split launches, of the batch norm's fold and of the deterministic dWeight share their control blocks with
+# stream-K's flags, and every launch must leave its block ZERO.  Word 9 (above) only tells of a stream-K wait that gave up; a
+# launch that died after drawing tickets leaves other words behind, and every later launch on that stream would then sum
+# incomplete slabs or never finalize -- silently (round-5 advisor).  check_control_blocks is the cheap sentinel: at a point
+# where the CURRENT stream has no launch in flight on its own block (the start of a train step: FlatGradBucket.zero()), "is any
+# byte of this stream's blocks non-zero" is computed on the device, copied to pinned memory without waiting, and LOOKED AT by
+# the next call -- one step late, no host synchronisation, two tiny launches per step.
+_BLOCK_CHECKS = {}  # device index -> (pinned flag tensor, event) of the check queued by the previous call
+
+
+def check_control_blocks(device=None):
+    device = _norm_device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    prev = _BLOCK_CHECKS.pop(device.index, None)
+    if prev is not None:
+        host, ev = prev
+        ev.synchronize()  # (queued a whole step ago: long done)
+        bad = bool(host[0].item())
+        _PINNED.append(host)
+        if bad:
+            torch.cuda.synchronize(device)
+            for (idx, _), t in list(_SK_STATE.items()) + list(_DW_TICKETS.items()):
+                if idx == device.index:
+                    t.zero_()
+            torch.cuda.synchronize(device)
+            raise RuntimeError(
+                "occuseg_amd: a control block (tickets of the split / batch-norm / dWeight launches, stream-K flags) did not return "
+                "to zero: a launch on that stream died or was aborted half way, and every later launch that draws tickets from the "
+                "block would have summed incomplete partial results.  The blocks have been reset; discard the last step.")
+    # (every block of the device: the caller has joined the dWeight side stream -- FlatGradBucket.zero() calls dw_join() first --
+    #  and no other stream of this process runs launches that draw tickets)
+    mine = [t for (idx, _), t in list(_SK_STATE.items()) + list(_DW_TICKETS.items()) if idx == device.index]
+    if not mine:
+        return
+    flag = torch.stack([t.any() for t in mine]).any().to(torch.uint8).reshape(1)
+    host = _pinned(1, torch.uint8)
+    host[:1].copy_(flag, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _BLOCK_CHECKS[device.index] = (host, ev)
+
+
 KEEP_NBR = False  # tests only: keep each submanifold rulebook's neighbour table (`d_global_query_result`) alive
 _COORD_DTYPES = {torch.int32: 0, torch.int64: 1, torch.float32: 2}  # scn_grid_build coords_dtype
 

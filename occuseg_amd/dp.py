@@ -19,6 +19,7 @@ Use ``bucket.zero()`` instead of ``optimizer.zero_grad()``: the default ``set_to
 detaches every ``.grad`` from the flat buffer (``zero()`` / ``all_reduce_mean()`` re-attach
 and say so if that happened).
 """
+import os
 import warnings
 
 import torch
@@ -65,6 +66,8 @@ class FlatGradBucket(object):
         self.launch_log = []  # (bucket, frozenset of parameter indices reported so far) per launch, for tests
         self.join_log = []    # per launch inside backward: ("exchange-stream", bucket) -- the main stream was NOT made to wait
         self.always_exchange = False  # tests: run the collective in a world of ONE rank too (RCCL's stream ordering on one GPU)
+        # zero(): the kernels' ticket blocks are back at zero (SCN.check_control_blocks; SCN_BLOCK_CHECK=0 turns it off for A/Bs)
+        self.check_control_blocks = os.environ.get("SCN_BLOCK_CHECK", "1") != "0"
         self._xstream = None  # the stream the collectives are issued from (see _launch)
         self._attach()
         # this object owns the (zeroed) gradient buffers of exactly these parameters: the convolutions and batch
@@ -191,6 +194,10 @@ class FlatGradBucket(object):
         # autograd skipped its final callbacks): the buffer they accumulate into is not zeroed under them
         SCN.dw_join()
         SCN.weights_changed()  # a new step: packed weights are re-made from the parameters at their next use
+        if self.flat.is_cuda and self.check_control_blocks:
+            # the tickets every split / batch-norm / dWeight launch of the last step drew must all be back at zero (looked at one
+            # step late, without waiting: SCN.check_control_blocks)
+            SCN.check_control_blocks(self.flat.device)
         self.flat.zero_()
         if self._attach():
             warnings.warn("FlatGradBucket: some .grad tensors had been detached from the flat buffer "

@@ -205,3 +205,40 @@ def test_deterministic_mode_train_steps_are_bitwise_equal(gpu):
             assert_close(g1.cpu().numpy(), g0.cpu().numpy(), "deterministic against atomic gradients", rel=1e-5)
     finally:
         SCN.DETERMINISTIC_DW = True
+
+
+def test_poisoned_ticket_word_is_a_hard_error(gpu):
+    """The tickets of the split launches, of the batch norm's fold and of the deterministic dWeight share the stream's control
+    blocks with stream-K's flags and rely on every launch leaving them ZERO; a launch that dies after drawing tickets would make
+    every later one sum incomplete partial results, silently (round-5 advisor).  FlatGradBucket.zero() looks at the blocks at
+    every step boundary (one step late, without waiting for the device): a poisoned word raises and the blocks are reset."""
+    import occuseg_amd
+    from occuseg_amd import SCN, dp, scenes
+    scn = occuseg_amd.install()
+    torch.manual_seed(3)
+    coords, feats = scenes.batch([1000], target_sites=6000)
+    net = _net(scn, 16, 3).to(gpu)
+    batch = [torch.from_numpy(coords).to(gpu), torch.from_numpy(feats).to(gpu), None, 1]
+    bucket = dp.FlatGradBucket(net.parameters())
+    try:
+        for _ in range(3):  # healthy steps: nothing raised, tickets back at zero
+            bucket.zero()
+            net(batch).sum().backward()
+            bucket.all_reduce_mean()
+        block = SCN._sk_state(gpu)
+        torch.cuda.synchronize()
+        assert int(block.view(torch.int32).abs().sum().item()) == 0
+        block.view(torch.int32)[40] = 1  # a ticket word that some launch "left behind"
+        bucket.zero()                    # queues the check that sees it ...
+        with pytest.raises(RuntimeError, match="control block"):
+            bucket.zero()                # ... and the next step boundary raises
+        torch.cuda.synchronize()
+        assert int(block.view(torch.int32).abs().sum().item()) == 0  # reset
+        bucket.zero()
+        net(batch).sum().backward()      # and training goes on
+        bucket.all_reduce_mean()
+        bucket.zero()
+        bucket.zero()
+    finally:
+        bucket.close()
+        SCN._BLOCK_CHECKS.clear()
