@@ -48,7 +48,7 @@ def source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "occuseg_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h", ".inc")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -26,7 +26,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True, tuning=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, "scn_common.h"), os.path.join(HERE, "..", "include", "scn_hip.h"),
-               os.path.join(CSRC, "tile4_loop_asm.inc")]
+               os.path.join(CSRC, "tile4_loop_asm.inc"), os.path.join(CSRC, "tile4_loop_asm_tuning.inc")]
     # k_conv_tile4's pass loop in assembly is GENERATED (tools/gen_tile4_loop.py, which also proves on its own instruction list
     # that no instruction touches a register with a load in flight): the committed file must be what the generator writes
     gen = [sys.executable, os.path.join(HERE, "..", "tools", "gen_tile4_loop.py"), "--check"]

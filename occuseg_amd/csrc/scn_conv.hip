@@ -20,6 +20,9 @@
 // float atomics into dW (as the reference, sparseconvnet/SCN/CUDA/Convolution.cu:749).
 #include "scn_common.h"
 #include "tile4_loop_asm.inc"  // k_conv_tile4's pass loop in assembly (generated: tools/gen_tile4_loop.py)
+#ifdef SCN_TUNING
+#include "tile4_loop_asm_tuning.inc"  // ... and its timing-only ablations
+#endif
 
 #include <type_traits>
 
@@ -1501,8 +1504,6 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     else if (ASM == 4) asm volatile(SCN_T4_ASM_ABL4 SCN_T4_ASM_OPERANDS);
     else if (ASM == 5) asm volatile(SCN_T4_ASM_ABL5 SCN_T4_ASM_OPERANDS);
     else if (ASM == 6) asm volatile(SCN_T4_ASM_ABL6 SCN_T4_ASM_OPERANDS);
-    else if (ASM == 7) asm volatile(SCN_T4_ASM_ABL7 SCN_T4_ASM_OPERANDS);
-    else if (ASM == 8) asm volatile(SCN_T4_ASM_ABL8 SCN_T4_ASM_OPERANDS);
     else if (ASM == 9) asm volatile(SCN_T4_ASM_ABL9 SCN_T4_ASM_OPERANDS);
 #endif
 #undef SCN_T4_ASM_OPERANDS
@@ -3892,8 +3893,7 @@ SCN_KNOB g_dw_direct = 0;       // tuning key 12: 1 = k_dw_direct (no LDS stagin
                                 // step is 1.8 ms SLOWER with it (50.3 against 48.4 ms, tools/ab_step.py tune12=0,1): off
 SCN_KNOB g_conv_expand_nb = 1;  // tuning key 14: blocks of 32 pairs per wave of k_conv_expand (1, 2 or 4).  Measured (round 3, 20 launches
                                 // per step): 1.81 / 1.83 / 2.21 ms -- the weight re-reads are not what bounds the kernel
-SCN_KNOB g_conv_expand_xcd = 2;  // tuning key 27 (2 = also launches of ONE plane block whose rulebook has 2..8 lists: their lists interleaved): 0 = the plane blocks of a pair block of k_conv_expand numbered blockIdx.x % ncb (eight XCDs fetch the
-                                 // same rows), 1 = on one XCD
+SCN_KNOB g_conv_expand_xcd = 2;  // tuning key 27: 0 = the plane blocks of a pair block of k_conv_expand numbered blockIdx.x % ncb (eight XCDs fetch the same rows); 1 = launches of more than one plane block use the XCD-aware numbering -- and with it, where the rulebook has 2..8 lists, the interleaved list order (which changes the order of the column-statistics partials: A/Bs of 1 against 2 differ in that too); 2 = launches of ONE plane block whose rulebook has 2..8 lists as well
 SCN_KNOB g_conv_expand_persist = 0;  // tuning key 21: 1 = k_conv_expand_p (persistent waves, pipelined across blocks; tuning library only).  Round 4:
                                      // bit-identical, 0-17 % faster per launch in isolation (tools/ab_expand.py), 0.3 ms SLOWER per train step
                                      // (46.73 against 46.40 ms, tools/ab_step.py tune21=0,1): off
@@ -4251,8 +4251,6 @@ static int launch_tile4(const float *in, float *out, const float *Wp, const floa
             case 4: SCN_LAUNCH_T4_GT(0, 4); break;
             case 5: SCN_LAUNCH_T4_GT(0, 5); break;
             case 6: SCN_LAUNCH_T4_GT(0, 6); break;
-            case 7: SCN_LAUNCH_T4_GT(0, 7); break;
-            case 8: SCN_LAUNCH_T4_GT(0, 8); break;
             default: SCN_LAUNCH_T4_GT(0, 9); break;
           }
         } else if (g_conv_asm) { if (in_col) SCN_LAUNCH_T4_GT(1, 1); else SCN_LAUNCH_T4_GT(0, 1); }

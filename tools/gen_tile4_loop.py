@@ -29,6 +29,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "occuseg_amd", "csrc", "tile4_loop_asm.inc")
+OUT_TUNING = os.path.join(ROOT, "occuseg_amd", "csrc", "tile4_loop_asm_tuning.inc")  # the timing-only ablations (-DSCN_TUNING)
 
 DEBUG_SKIP = False
 VB = 60   # first vector register owned by the loop (v60 .. v255)
@@ -100,7 +101,7 @@ def rng(b, n):
 
 # timing-only ablations (tuning library, tools/bench_conv.py --asm): what each part of a pass costs.  Wrong results by design.
 ABLATIONS = {2: ("nowait",), 3: ("notile",), 4: ("norows",), 5: ("norows", "noidx", "now", "nowait"),
-             6: ("norows", "noidx", "now", "nowait", "notile"), 7: ("nomfma",), 8: ("nomfma", "nowait"),
+             6: ("norows", "noidx", "now", "nowait", "notile"),
              9: ("norows", "noidx", "now", "nowait", "notile", "nopieces")}
 
 
@@ -536,13 +537,14 @@ def main():
         out.append("#define SCN_T4_ASM_INCOL%d \\" % incol)
         out.append(" \\\n".join('  "%s\\n\\t"' % i.text for i in g.ins))
         out.append("")
+    tun = ["// GENERATED by tools/gen_tile4_loop.py -- do not edit.  Timing-only ablations of k_conv_tile4's assembly pass loop (wrong",
+           "// results by design): only libscn_hip_tuning.so (-DSCN_TUNING) holds them; tools/bench_conv.py --asm 2,3,4,5,6,9.", ""]
     for n, flags in sorted(ABLATIONS.items()):
         g = Gen(0, flags).build()
-        out.append("#ifdef SCN_TUNING  // timing-only ablation %d: %s" % (n, " ".join(flags)))
-        out.append("#define SCN_T4_ASM_ABL%d \\" % n)
-        out.append(" \\\n".join('  "%s\\n\\t"' % i.text for i in g.ins))
-        out.append("#endif")
-        out.append("")
+        tun.append("// ablation %d: %s" % (n, " ".join(flags)))
+        tun.append("#define SCN_T4_ASM_ABL%d \\" % n)
+        tun.append(" \\\n".join('  "%s\\n\\t"' % i.text for i in g.ins))
+        tun.append("")
     clob = ['"v%d"' % v for v in range(VB, V_END)] + ['"s%d"' % s for s in range(SB, S_END)] + ['"vcc"', '"scc"', '"memory"']
     out.append("#define SCN_T4_ASM_CLOBBERS " + ", ".join(clob))
     out.append("")
@@ -552,13 +554,15 @@ def main():
         print("%d errors" % len(total_err))
         return 1
     if "--check" in sys.argv:
-        old = open(OUT).read() if os.path.exists(OUT) else ""
-        if old != "\n".join(out):
-            print("tile4_loop_asm.inc is not what the generator writes: run python tools/gen_tile4_loop.py")
-            return 1
+        for path, text in ((OUT, out), (OUT_TUNING, tun)):
+            old = open(path).read() if os.path.exists(path) else ""
+            if old != "\n".join(text):
+                print("%s is not what the generator writes: run python tools/gen_tile4_loop.py" % os.path.basename(path))
+                return 1
         return 0
     open(OUT, "w").write("\n".join(out))
-    print("wrote", OUT)
+    open(OUT_TUNING, "w").write("\n".join(tun))
+    print("wrote", OUT, "and", OUT_TUNING)
     return 0
 
 
