@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 6
+#define SCN_ABI_VERSION 7
 #define SCN_TILE_GRANULE 32 /* output-row granule of the tile-base tables */
 #define SCN_SK_STATE_BYTES 65536 /* scn_conv_forward's sk_state */
 #define SCN_GRID_CHAIN_MAX 12     /* scales one scn_grid_chain_counts call can count */
@@ -168,7 +168,7 @@ int scn_tile_passes(const int32_t *bases, int K, int64_t n_out, int32_t *passes,
 typedef struct {
   int32_t levels;                          /* 1 .. SCN_BATCH_MAX_LEVELS */
   int32_t coords_dtype, ncols;             /* of the input coordinates: see scn_grid_build */
-  int32_t reserved;
+  int32_t flags;                           /* bit 0: layout for scn_batch_build_occ (no hash maps, no sort workspace) */
   int64_t P;                               /* input rows */
   int64_t N[SCN_BATCH_MAX_LEVELS];         /* active sites of every scale (> 0) */
   int32_t sub[SCN_BATCH_MAX_LEVELS];       /* != 0: hash map + 3x3x3 submanifold rulebook + tile bases of this scale */
@@ -190,6 +190,47 @@ typedef struct {
 } scn_batch_layout;
 int scn_batch_layout_query(const scn_batch_plan *plan_host, scn_batch_layout *layout_host);
 int scn_batch_build(const void *coords, const scn_batch_plan *plan_host, void *arena, size_t arena_bytes, void *stream);
+
+/* ------------------------------- the same batch from OCCUPANCY BITMAPS: no sort, no hash map (round 6) ---
+ * The reference numbers the sites of a grid by sorting voxel keys and finds neighbours through a hash table
+ * (sparseconvnet/SCN/CUDA/CUDPPWrapper.cu:72-119,210-229; extra/cudpp/src/cudpp_hash/hash_multivalue.cpp:45-110;
+ * sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:45-114).  The site number of a voxel is its RANK among the occupied voxels in
+ * key order (sample, z, y, x) -- and that is a prefix sum of population counts over a bitmap of the batch's bounding box laid
+ * out in exactly that order.  One 64-bit word per 32 voxels of an x row: low half = occupancy bits, high half = the number of
+ * occupied voxels in front of the word (all scales counted through: subtract the scale's first word's).  Then
+ *   site of a voxel       = one 8-byte load + one popcount           (was: hash probes)
+ *   the three neighbours (x-1, x, x+1) of a row = the same load      (was: 1-3 probes)
+ *   the coarser scale     = OR of 2x2x2 bits, set by the same launch that sets the bits of scale 0 (was: a sort per scale)
+ *   site_of_row / order   = rank of every input row, a counting pass and a sort of the (short) per-site segments (was: the sort)
+ * Same arrays, bit for bit, as scn_batch_build.  Two read-backs per batch: the bounding box, then the site counts.
+ *   scn_occ_bounds   min / max of the coordinates (one launch, one synchronisation); minmax_host = xmin ymin zmin bmin xmax ymax zmax bmax;
+ *                    error 3 for coordinates outside the key box, as scn_grid_build
+ *   scn_occ_plan     host only: the box (origin aligned to 2^(levels-1) so that scale l is scale 0 shifted), word counts and the
+ *                    layout of the buffer; box->bytes = 0 when the box needs more than SCN_OCC_MAX_WORDS words (use scn_batch_build)
+ *   scn_occ_chain    bits of every scale + prefix sums into `occ` (box->bytes bytes); n_sites_host (may be NULL: queued only) = the
+ *                    site count of every scale after ONE synchronisation (scn_occ_fetch reads them later)
+ *   scn_batch_build_occ   as scn_batch_build with a layout from a plan whose flags bit 0 is set; `small` [2 l + 1] bit 1 of scale
+ *                    0 set = a voxel holds more than SCN_OCC_SEGMENT_MAX input rows: `order` is NOT sorted inside such sites (the
+ *                    caller sorts (site_of_row, row) itself or builds the batch with scn_batch_build) */
+#define SCN_OCC_MAX_WORDS ((int64_t)1 << 27)
+#define SCN_OCC_SEGMENT_MAX 64
+typedef struct {
+  int32_t levels, nb;                         /* scales; samples (bmax - bmin + 1) */
+  int32_t origin[4];                          /* x, y, z, sample of bit 0 at scale 0 */
+  int32_t n[SCN_BATCH_MAX_LEVELS][3];         /* voxels per axis (x, y, z) of the box at every scale */
+  int32_t wx[SCN_BATCH_MAX_LEVELS];           /* words per x row */
+  int64_t woff[SCN_BATCH_MAX_LEVELS + 1];     /* first word of every scale; [levels] = all words */
+  int64_t blocks;                             /* 1024-word blocks of the prefix sum */
+  int64_t off_info, off_blk, off_words, bytes; /* byte offsets into `occ`; its size */
+} scn_occ_box;
+int scn_occ_bounds(const void *coords, int coords_dtype, int ncols, int64_t P, int32_t *scratch_dev /* 64 bytes */,
+                   int32_t *minmax_host /* [8] */, void *stream);
+int scn_occ_plan(const int32_t *minmax, int levels, scn_occ_box *box);
+int scn_occ_chain(const void *coords, int coords_dtype, int ncols, int64_t P, const scn_occ_box *box, void *occ, size_t occ_bytes,
+                  int32_t *n_sites_host, void *stream);
+int scn_occ_fetch(const void *occ, const scn_occ_box *box, int32_t *n_sites_host, void *stream);
+int scn_batch_build_occ(const void *coords, const scn_batch_plan *plan_host, const scn_occ_box *box, void *occ, void *arena,
+                        size_t arena_bytes, void *stream);
 
 /* ------------------------------------------------------- gather-mm-scatter ---
  * out[o,:] = (bias) + sum_k sum_{pairs of list k} in[pair.in_col,:] . Wk

@@ -128,6 +128,13 @@ PREBUILD = True
 # One C call per batch for every grid and rulebook (scn_batch_build, round 5) where the site counts of all scales are known up front
 # (the grid chain): the forward-only configuration spent a third of its host time in ~60 ctypes calls and ~120 allocations
 BATCH_BUILD = os.environ.get("SCN_BATCH_BUILD", "1") != "0"
+# The batch build from occupancy bitmaps (scn_batch_build_occ: no sort, no hash map; include/scn_hip.h).  "auto": when the batch's
+# bounding box is no larger than OCC_WORDS_PER_ROW 64-bit words per input row (a compact cloud; a handful of far-apart points would
+# pay for memsets and prefix sums over an empty box), True: whenever the box fits SCN_OCC_MAX_WORDS, False: never.
+_OB = os.environ.get("SCN_OCC_BUILD", "auto")
+OCC_BUILD = True if _OB == "1" else False if _OB == "0" else "auto"
+OCC_WORDS_PER_ROW = 64
+OCC_STATS = {"built": 0, "too_large": 0, "order_repaired": 0}  # since import (tests, tools)
 DEFER_PREFETCH_READBACK = os.environ.get("SCN_DEFER_PREFETCH_READBACK", "1") != "0"
 _PINNED = []  # pinned host buffers of the deferred read-backs (allocating one costs a millisecond: kept and re-used)
 
@@ -358,6 +365,7 @@ class Metadata_3(object):
         self._plan = []
         self._deferred = None     # (pinned host copy of a prefetched build's read-back, its event, what to do with it)
         self._chain_counts = {}   # spatial size -> N from the grid chain (scn_grid_chain_counts), this batch
+        self._occ = None          # (scn_occ_box, buffer) between scn_occ_chain and scn_batch_build_occ
         self._grid_status = []    # (device [N, error flag] of a grid built without read-back, the N it was built for)
 
     def setNormalGuideScale(self, s):
@@ -440,12 +448,13 @@ class Metadata_3(object):
         # auto: inside a forward pass, and in a prefetch issued under torch.no_grad() (a serving loop: the same host thread
         # issues the forward pass, nothing hides a read-back); not in a prefetch beside a backward pass
         chain = GRID_CHAIN if GRID_CHAIN != "auto" else (not in_prefetch or not torch.is_grad_enabled())
-        fetch, sizes = self._chain(c, key, old_plan if PREBUILD and chain else [])
+        batchable = (BATCH_BUILD and normals is None and not KEEP_NBR and not (PROFILE is not None and "rules" in PROFILE_KINDS))
+        fetch, sizes = self._chain(c, key, old_plan if PREBUILD and (chain or (OCC_BUILD and batchable)) else [],
+                                   occ=OCC_BUILD if batchable else False, hashed=chain)
         self.input_mode = int(mode)
         self.input_P = P
         batch_small = None
-        if (fetch is not None and BATCH_BUILD and normals is None and not KEEP_NBR
-                and not (PROFILE is not None and "rules" in PROFILE_KINDS)):
+        if fetch is not None and batchable:
             # every grid and rulebook of the chain queued by ONE call into one arena (scn_batch_build)
             batch_small = self._batch_build(c, sizes, fetch(), old_plan)
             g = self.grids[key]
@@ -510,18 +519,42 @@ class Metadata_3(object):
         elif batch_small is not None:  # (not reachable: the batch build needs a recorded plan; kept for safety)
             self._batch_finish(batch_small[0].cpu().tolist(), batch_small[1])
 
-    def _chain(self, c, key, old_plan):
+    def _chain(self, c, key, old_plan, occ=False, hashed=True):
         """Site counts of every scale the previous forward pass on this input size built (its strided rulebook
-        requests chain down from the input size) with ONE read-back: scn_grid_chain_counts."""
+        requests chain down from the input size): from the occupancy bitmaps of the batch's bounding box (scn_occ_bounds +
+        scn_occ_chain: two read-backs, and the bitmaps are what scn_batch_build_occ then builds everything from), or with ONE
+        read-back from hash sets (scn_grid_chain_counts)."""
         sizes = [key]
         for req in old_plan:
             if req[0] != "sub" and req[1] == sizes[-1] and req[3] == (2, 2, 2) and req[4] == (2, 2, 2):
                 sizes.append(req[2])
+        self._occ = None
         if len(sizes) < 2 or len(sizes) > _GRID_CHAIN_MAX:
             return None, sizes
         lib = _lib_()
         P = c.size(0)
         if P <= 0 or P >= (1 << 30):  # (scn_grid_chain_counts takes fewer points than scn_grid_build: per-scale read-backs then)
+            return None, sizes
+        if occ:
+            mm = (ctypes.c_int32 * 8)()
+            scratch = torch.empty(16, dtype=torch.int32, device=c.device)
+            check(lib.scn_occ_bounds(ptr(c), _COORD_DTYPES[c.dtype], c.size(1), P, ptr(scratch), mm, stream()))
+            box = _lib.OccBox()
+            check(lib.scn_occ_plan(mm, len(sizes), ctypes.byref(box)))
+            if box.bytes > 0 and (occ is True or box.woff[len(sizes)] <= max(1 << 20, OCC_WORDS_PER_ROW * P)):
+                buf = torch.empty(box.bytes, dtype=torch.uint8, device=c.device)
+                check(lib.scn_occ_chain(ptr(c), _COORD_DTYPES[c.dtype], c.size(1), P, ctypes.byref(box), ptr(buf), box.bytes,
+                                        None, stream()))
+                self._occ = (box, buf)
+
+                def fetch_occ():
+                    n = (ctypes.c_int32 * len(sizes))()
+                    check(lib.scn_occ_fetch(ptr(buf), ctypes.byref(box), n, stream()))
+                    self._chain_counts = {sz: int(v) for sz, v in zip(sizes, n)}
+                    return self._chain_counts
+                return fetch_occ, sizes
+            OCC_STATS["too_large"] += 1
+        if not hashed:
             return None, sizes
         tb = lib.scn_grid_chain_temp_bytes(P, len(sizes))
         if tb == 0:
@@ -554,9 +587,16 @@ class Metadata_3(object):
             plan.sub[l] = 1 if sz in want_sub else 0
             plan.strided[l] = 1 if l + 1 < L else 0
         lo = _lib.BatchLayout()
+        plan.flags = 1 if self._occ is not None else 0
         check(lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)))
         arena = torch.empty(lo.total, dtype=torch.uint8, device=dev)
-        check(lib.scn_batch_build(ptr(c), ctypes.byref(plan), ptr(arena), lo.total, stream()))
+        if self._occ is not None:
+            box, buf = self._occ
+            check(lib.scn_batch_build_occ(ptr(c), ctypes.byref(plan), ctypes.byref(box), ptr(buf), ptr(arena), lo.total, stream()))
+            self._occ = None  # (the bitmaps are scratch of the build; the stream has the launches that read them)
+            OCC_STATS["built"] += 1
+        else:
+            check(lib.scn_batch_build(ptr(c), ctypes.byref(plan), ptr(arena), lo.total, stream()))
         a32, a64 = arena.view(torch.int32), arena.view(torch.int64)
 
         def i32(off, *shape):
@@ -582,7 +622,8 @@ class Metadata_3(object):
             n_gran = (N + GRANULE - 1) // GRANULE
             if plan.sub[l]:
                 cap = int(lo.hash_cap[l])
-                g.hash_keys, g.hash_vals, g.hash_cap = i64(lo.hash_keys[l], cap), i32(lo.hash_vals[l], cap), cap
+                if cap:  # (a build from occupancy bitmaps has no hash maps: _hash() makes one when something asks)
+                    g.hash_keys, g.hash_vals, g.hash_cap = i64(lo.hash_keys[l], cap), i32(lo.hash_vals[l], cap), cap
                 rb = _RuleBook(27, N, i32(lo.sub_rules[l], 27, N, 2), small[2 * L + 27 * l:2 * L + 27 * l + 27])
                 rb.bases[1] = i32(lo.sub_bases[l], 27, n_gran + 1)
                 rb.n_rows[1] = N
@@ -611,6 +652,15 @@ class Metadata_3(object):
         L, want, subs = info
         for l in range(L):
             got, err = int(small[2 * l]), int(small[2 * l + 1])
+            if err == 2:
+                # scn_batch_build_occ: a voxel holds more than SCN_OCC_SEGMENT_MAX input rows and its rows in `order` are in the
+                # order the atomics handed out.  Rare (a degenerate cloud): sort (site, row) here.  The build has finished (this
+                # runs behind its read-back); the copy is queued on the current stream, which consumes `order` from here on.
+                P = self.input_P
+                k = (self.input_site_of_row.to(torch.int64) << 32) | torch.arange(P, dtype=torch.int64, device=self.input_order.device)
+                self.input_order.copy_((torch.sort(k).values & 0xFFFFFFFF).to(torch.int32))
+                OCC_STATS["order_repaired"] += 1
+                err = 0
             if err:
                 raise RuntimeError("libscn_hip: scn_batch_build: coordinate outside the 31-bit key box (0<=x<1024, 0<=y<2048, "
                                    "0<=z<1024) or bad sample index")

@@ -35,6 +35,11 @@ SIGNATURES = {
     "scn_tile_bases": (c_int, [_P, _P, c_int, c_int64, c_int, c_int64, _P, _P]),
     "scn_batch_layout_query": (c_int, [_P, _P]),
     "scn_batch_build": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "scn_occ_bounds": (c_int, [_P, c_int, c_int, c_int64, _P, ctypes.POINTER(c_int32), _P]),
+    "scn_occ_plan": (c_int, [ctypes.POINTER(c_int32), c_int, _P]),
+    "scn_occ_chain": (c_int, [_P, c_int, c_int, c_int64, _P, _P, c_size_t, ctypes.POINTER(c_int32), _P]),
+    "scn_occ_fetch": (c_int, [_P, _P, ctypes.POINTER(c_int32), _P]),
+    "scn_batch_build_occ": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P]),
     "scn_tile_passes_bytes": (c_size_t, [c_int64]),
     "scn_tile_passes": (c_int, [_P, c_int, c_int64, _P, _P]),
     "scn_conv_wpack_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -81,7 +86,7 @@ TUNING_SIGNATURES = {
     "scn_peak_read": (c_int, [_P, _P, c_int64, c_int, ctypes.POINTER(c_double), _P]),
 }
 TUNING_LIB_PATH = os.path.join(_HERE, "libscn_hip_tuning.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 SK_STATE_BYTES = 65536  # SCN_SK_STATE_BYTES
 GRID_CHAIN_MAX = 12     # SCN_GRID_CHAIN_MAX
 DW_STATE_BYTES = 1048576  # SCN_DW_STATE_BYTES
@@ -94,7 +99,7 @@ BATCH_MAX_LEVELS = 12  # SCN_BATCH_MAX_LEVELS
 
 class BatchPlan(ctypes.Structure):
     """scn_batch_plan of include/scn_hip.h"""
-    _fields_ = [("levels", c_int32), ("coords_dtype", c_int32), ("ncols", c_int32), ("reserved", c_int32), ("P", c_int64),
+    _fields_ = [("levels", c_int32), ("coords_dtype", c_int32), ("ncols", c_int32), ("flags", c_int32), ("P", c_int64),
                 ("N", c_int64 * BATCH_MAX_LEVELS), ("sub", c_int32 * BATCH_MAX_LEVELS), ("strided", c_int32 * BATCH_MAX_LEVELS)]
 
 
@@ -104,6 +109,13 @@ class BatchLayout(ctypes.Structure):
                 ("site_start", c_int64)] + [(n, c_int64 * BATCH_MAX_LEVELS) for n in (
                     "coords", "keys", "hash_keys", "hash_vals", "hash_cap", "sub_rules", "sub_bases", "str_rules", "str_bases_fine",
                     "str_bases_coarse")]
+
+
+class OccBox(ctypes.Structure):
+    """scn_occ_box of include/scn_hip.h"""
+    _fields_ = [("levels", c_int32), ("nb", c_int32), ("origin", c_int32 * 4), ("n", (c_int32 * 3) * BATCH_MAX_LEVELS),
+                ("wx", c_int32 * BATCH_MAX_LEVELS), ("woff", c_int64 * (BATCH_MAX_LEVELS + 1)), ("blocks", c_int64),
+                ("off_info", c_int64), ("off_blk", c_int64), ("off_words", c_int64), ("bytes", c_int64)]
 
 
 class BnBwdStats(ctypes.Structure):

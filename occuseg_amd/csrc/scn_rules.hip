@@ -576,6 +576,344 @@ __global__ void k_input_table(const int32_t *order, const int32_t *site_start, i
   }
 }
 
+
+// ------------------------------------------------ occupancy bitmaps (round 6) ---
+// include/scn_hip.h, "the same batch from OCCUPANCY BITMAPS".  The table the kernels read lies at byte 0 of the buffer (written by
+// k_occ_header from its by-value argument: no host-to-device copy whose source could go out of scope), the counters behind it.
+struct OccDev {
+  int32_t levels, nb, ox, oy, oz, ob, pad0, pad1;
+  int32_t nx[SCN_BATCH_MAX_LEVELS], ny[SCN_BATCH_MAX_LEVELS], nz[SCN_BATCH_MAX_LEVELS], wx[SCN_BATCH_MAX_LEVELS];
+  int64_t woff[SCN_BATCH_MAX_LEVELS + 1];
+};
+struct OccOut {  // where k_occ_sites writes: byte offsets into the arena
+  int64_t coords[SCN_BATCH_MAX_LEVELS], keys[SCN_BATCH_MAX_LEVELS];
+};
+constexpr int OCC_HDR_OUT = 512;      // byte offset of OccOut in the buffer
+constexpr int OCC_INFO_START = 0;     // info[0 .. levels]: occupied voxels in front of every scale's first word ([levels] = all)
+constexpr int OCC_INFO_OVERFLOW = 32;  // info[32]: != 0 = a voxel with more than SCN_OCC_SEGMENT_MAX input rows
+static_assert(sizeof(OccDev) <= OCC_HDR_OUT && sizeof(OccOut) <= 512, "occupancy header");
+
+__global__ void k_occ_header(OccDev d, OccDev *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = d;
+}
+__global__ void k_occ_out(OccOut d, OccOut *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = d;
+}
+
+// mm[0..3] = max of (-x, -y, -z, -b), mm[4..7] = max of (x, y, z, b), mm[8] |= 1 for a coordinate outside the key box; all nine
+// start as 0x80808080 (one memset)
+template <int DT>
+__global__ void __launch_bounds__(256) k_occ_bounds(const void *coords_, int ncols, int64_t P, int *mm) {
+  int lo[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN}, hi[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+  bool bad = false;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+    int64_t x, y, z, b;
+    read_coords<DT>(coords_, p, ncols, x, y, z, b);
+    if (x < 0 || x >= 1024 || y < 0 || y >= 2048 || z < 0 || z >= 1024 || b < 0 || b >= 65536) {
+      bad = true;
+      continue;
+    }
+    const int v[4] = {(int)x, (int)y, (int)z, (int)b};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      lo[a] = max(lo[a], -v[a]);
+      hi[a] = max(hi[a], v[a]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = max(lo[a], __shfl_down(lo[a], off));
+      hi[a] = max(hi[a], __shfl_down(hi[a], off));
+    }
+    if (lane_id() == 0) {
+      if (lo[a] != INT_MIN) atomicMax(mm + a, lo[a]);
+      if (hi[a] != INT_MIN) atomicMax(mm + 4 + a, hi[a]);
+    }
+  }
+  if (__ballot(bad) != 0 && lane_id() == 0) atomicOr(mm + 8, 1);
+}
+
+__device__ __forceinline__ int64_t occ_word_index(const OccDev *__restrict__ d, int l, int rx, int ry, int rz, int rb) {
+  return d->woff[l] + (((int64_t)rb * d->nz[l] + rz) * d->ny[l] + ry) * d->wx[l] + (rx >> 5);
+}
+
+// Bits of every scale: row p sets its bit at scale 0, 1, ... and stops at the first scale where the bit was set already (whoever
+// set it goes on): P + N_0 + N_1 + ... atomics in all.
+template <int DT>
+__global__ void __launch_bounds__(256) k_occ_set(const void *coords_, int ncols, int64_t P, const uint64_t *__restrict__ buf, uint64_t *words) {
+  const OccDev *__restrict__ d = (const OccDev *)buf;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool live = p < P;
+  int rx = 0, ry = 0, rz = 0, rb = 0;
+  if (live) {
+    int64_t x, y, z, b;
+    read_coords<DT>(coords_, p, ncols, x, y, z, b);
+    rx = (int)x - d->ox; ry = (int)y - d->oy; rz = (int)z - d->oz; rb = (int)b - d->ob;
+    // (scn_occ_bounds has seen every row: inside the box.  Anything else -- a coords tensor changed in between -- is dropped.)
+    live = rx >= 0 && rx < d->nx[0] && ry >= 0 && ry < d->ny[0] && rz >= 0 && rz < d->nz[0] && rb >= 0 && rb < d->nb;
+  }
+  uint32_t *w32 = (uint32_t *)words;
+  const int levels = d->levels;
+  for (int l = 0; l < levels; ++l) {
+    if (live) {
+      const int64_t w = occ_word_index(d, l, rx >> l, ry >> l, rz >> l, rb);
+      const uint32_t bit = 1u << ((rx >> l) & 31);
+      const uint32_t old = atomicOr(w32 + 2 * w, bit);  // (little endian: the low half of word w)
+      if (old & bit) live = false;
+    }
+    if (__ballot(live) == 0) break;  // (wave-uniform)
+  }
+}
+
+// population counts of 1024-word blocks (thread t: words 4 t .. 4 t + 3)
+__global__ void __launch_bounds__(256) k_occ_count(const uint64_t *__restrict__ words, int *__restrict__ blk) {
+  __shared__ int wt[4];
+  const ulonglong2 *q = (const ulonglong2 *)(words + ((int64_t)blockIdx.x * 1024 + threadIdx.x * 4));
+  const ulonglong2 a = q[0], b = q[1];
+  int c = __popc((uint32_t)a.x) + __popc((uint32_t)a.y) + __popc((uint32_t)b.x) + __popc((uint32_t)b.y);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if (lane_id() == 0) wt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
+}
+
+// exclusive scan of one int per thread over a 256-thread block (wave scans + four LDS entries)
+__device__ __forceinline__ int block_excl_scan256(int v, int *wt, int &total) {
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(x, off);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wt[w] = x;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) base += i < w ? wt[i] : 0;
+  total = wt[0] + wt[1] + wt[2] + wt[3];
+  __syncthreads();
+  return base + x - v;
+}
+
+// high halves = occupied voxels in front of the word; info[l] = in front of scale l's first word
+__global__ void __launch_bounds__(256) k_occ_base(const uint64_t *__restrict__ buf, uint64_t *__restrict__ words, const int *__restrict__ blk,
+                                                  int *__restrict__ info) {
+  __shared__ int wt[4];
+  const OccDev *__restrict__ d = (const OccDev *)buf;
+  const int64_t w0 = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+  ulonglong2 *q = (ulonglong2 *)(words + w0);
+  ulonglong2 a = q[0], b = q[1];
+  const int c0 = __popc((uint32_t)a.x), c1 = __popc((uint32_t)a.y), c2 = __popc((uint32_t)b.x), c3 = __popc((uint32_t)b.y);
+  int total;
+  const int e = blk[blockIdx.x] + block_excl_scan256(c0 + c1 + c2 + c3, wt, total);
+  const uint32_t p0 = (uint32_t)e, p1 = p0 + c0, p2 = p1 + c1, p3 = p2 + c2;
+  a.x = (a.x & 0xFFFFFFFFull) | ((uint64_t)p0 << 32);
+  a.y = (a.y & 0xFFFFFFFFull) | ((uint64_t)p1 << 32);
+  b.x = (b.x & 0xFFFFFFFFull) | ((uint64_t)p2 << 32);
+  b.y = (b.y & 0xFFFFFFFFull) | ((uint64_t)p3 << 32);
+  q[0] = a;
+  q[1] = b;
+  const int levels = d->levels;
+  for (int l = 1; l < levels; ++l) {  // (info[0] = 0 and info[levels] = the total come from the memset and the scan)
+    const int64_t t = d->woff[l] - w0;
+    if (t >= 0 && t < 4) info[OCC_INFO_START + l] = t == 0 ? p0 : t == 1 ? p1 : t == 2 ? p2 : p3;
+  }
+}
+
+// coordinates and keys of every site of every scale: one thread per word
+__global__ void __launch_bounds__(256) k_occ_sites(const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words, int64_t W,
+                                                   const int *__restrict__ info, char *__restrict__ arena) {
+  const OccDev *__restrict__ d = (const OccDev *)buf;
+  const OccOut *__restrict__ out = (const OccOut *)((const char *)buf + OCC_HDR_OUT);
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= W) return;
+  const uint64_t word = words[w];
+  uint32_t bits = (uint32_t)word;
+  if (bits == 0) return;
+  int l = 0;
+  const int levels = d->levels;
+  while (l + 1 < levels && w >= d->woff[l + 1]) ++l;
+  if (out->coords[l] < 0) return;  // (a scale the plan does not reach)
+  const int64_t wi = w - d->woff[l];
+  const int wx = d->wx[l], ny = d->ny[l], nz = d->nz[l];
+  const int xw = (int)(wi % wx);
+  const int64_t row = wi / wx;
+  const int ry = (int)(row % ny), rz = (int)((row / ny) % nz), rb = (int)(row / ((int64_t)ny * nz));
+  const int y = (d->oy >> l) + ry, z = (d->oz >> l) + rz, b = d->ob + rb, x0 = (d->ox >> l) + xw * 32;
+  int r = (int)(word >> 32) - info[OCC_INFO_START + l];
+  int4 *coords = (int4 *)(arena + out->coords[l]);
+  uint64_t *keys = (uint64_t *)(arena + out->keys[l]);
+  while (bits) {
+    const int i = __builtin_ctz(bits);
+    bits &= bits - 1;
+    coords[r] = make_int4(x0 + i, y, z, b);
+    keys[r] = voxel_key(x0 + i, y, z, b);
+    ++r;
+  }
+}
+
+// rank of voxel (rx, ry, rz, rb) -- relative to the box, at scale l -- whose bit is known to be set
+__device__ __forceinline__ int occ_rank(const OccDev *__restrict__ d, const uint64_t *__restrict__ words, const int *__restrict__ info,
+                                        int l, int rx, int ry, int rz, int rb) {
+  const uint64_t word = words[occ_word_index(d, l, rx, ry, rz, rb)];
+  return (int)(word >> 32) + __popc((uint32_t)word & ((1u << (rx & 31)) - 1u)) - info[OCC_INFO_START + l];
+}
+
+// input layer: the site of every input row, and its arrival number among the rows of its site
+template <int DT>
+__global__ void __launch_bounds__(256) k_occ_rows(const void *coords_, int ncols, int64_t P, const uint64_t *__restrict__ buf,
+                                                  const uint64_t *__restrict__ words, const int *__restrict__ info,
+                                                  int32_t *__restrict__ site_of_row, int32_t *__restrict__ slot, int *cnt) {
+  const OccDev *__restrict__ d = (const OccDev *)buf;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  int64_t x, y, z, b;
+  read_coords<DT>(coords_, p, ncols, x, y, z, b);
+  const int rx = (int)x - d->ox, ry = (int)y - d->oy, rz = (int)z - d->oz, rb = (int)b - d->ob;
+  if (rx < 0 || rx >= d->nx[0] || ry < 0 || ry >= d->ny[0] || rz < 0 || rz >= d->nz[0] || rb < 0 || rb >= d->nb) return;  // (see k_occ_set)
+  const int s = occ_rank(d, words, info, 0, rx, ry, rz, rb);
+  site_of_row[p] = s;
+  slot[p] = atomicAdd(cnt + s, 1);
+}
+
+__global__ void __launch_bounds__(256) k_sum256(const int *__restrict__ v, int64_t n, int *__restrict__ blk) {
+  __shared__ int wt[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int c = i < n ? v[i] : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if (lane_id() == 0) wt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
+}
+
+// site_start[i] = rows in front of site i; site_start[n] = P
+__global__ void __launch_bounds__(256) k_starts256(const int *__restrict__ cnt, int64_t n, const int *__restrict__ blk,
+                                                   int32_t *__restrict__ site_start, int P) {
+  __shared__ int wt[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int total;
+  const int e = blk[blockIdx.x] + block_excl_scan256(i < n ? cnt[i] : 0, wt, total);
+  if (i < n) site_start[i] = e;
+  if (i == n) site_start[n] = P;
+}
+
+__global__ void __launch_bounds__(256) k_occ_order(const int32_t *__restrict__ site_of_row, const int32_t *__restrict__ slot,
+                                                   const int32_t *__restrict__ site_start, int64_t P, int32_t *__restrict__ order) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < P) order[site_start[site_of_row[p]] + slot[p]] = (int32_t)p;
+}
+
+// the rows of a site in ascending order (the atomics above hand out arrival numbers in any order): insertion sort of the short
+// segments; a longer one raises the flag (include/scn_hip.h: the caller's business)
+__global__ void __launch_bounds__(256) k_occ_order_sort(const int32_t *__restrict__ site_start, int64_t N, int32_t *__restrict__ order,
+                                                        int *__restrict__ info) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= N) return;
+  const int q0 = site_start[s], n = site_start[s + 1] - q0;
+  if (n < 2) return;
+  if (n > SCN_OCC_SEGMENT_MAX) {
+    info[OCC_INFO_OVERFLOW] = 1;
+    return;
+  }
+  int32_t *o = order + q0;
+  for (int i = 1; i < n; ++i) {
+    const int32_t key = o[i];
+    int j = i - 1;
+    while (j >= 0 && o[j] > key) {
+      o[j + 1] = o[j];
+      --j;
+    }
+    o[j + 1] = key;
+  }
+}
+
+// small[2 l] = sites of scale l, small[2 l + 1] = flags (bit 1 at scale 0: a site's segment was not sorted)
+__global__ void k_occ_small(const int *__restrict__ info, int levels, int32_t *__restrict__ small) {
+  const int l = threadIdx.x;
+  if (l >= levels) return;
+  small[2 * l] = info[OCC_INFO_START + l + 1] - info[OCC_INFO_START + l];
+  small[2 * l + 1] = (l == 0 && info[OCC_INFO_OVERFLOW]) ? 2 : 0;
+}
+
+// the 27 neighbours of every site of scale l from the bitmap: one word per (y + dy, z + dz) row holds x - 1, x, x + 1 (two words
+// when the site sits at a word's edge), and their ranks are consecutive.  Output as k_sub_probe.
+__global__ void __launch_bounds__(256)
+    k_sub_probe_occ(const int4 *__restrict__ coords, int64_t N, const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words,
+                    const int *__restrict__ info, int l, int32_t *__restrict__ nbr, int *__restrict__ blk_cnt, int nblk) {
+  __shared__ int wcnt[4][27];
+  const OccDev *__restrict__ d = (const OccDev *)buf;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = o < N;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int nx = d->nx[l], ny = d->ny[l], nz = d->nz[l], wx = d->wx[l], ls = info[OCC_INFO_START + l];
+  const uint64_t *__restrict__ lw = words + d->woff[l];
+  int rx = 0, ry = 0, rz = 0, rb = 0;
+  if (valid) {
+    const int4 c = coords[o];
+    rx = c.x - (d->ox >> l); ry = c.y - (d->oy >> l); rz = c.z - (d->oz >> l); rb = c.w - d->ob;
+  }
+  const int p = rx & 31, wc = rx >> 5;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    // k = (dx+1)*9 + (dy+1)*3 + (dz+1): sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:61-74; r = (dy+1)*3 + (dz+1)
+    const int dy = r / 3 - 1, dz = r % 3 - 1;
+    int i[3] = {-1, -1, -1};
+    const int y = ry + dy, z = rz + dz;
+    if (valid && y >= 0 && y < ny && z >= 0 && z < nz) {
+      const uint64_t *row = lw + (((int64_t)rb * nz + z) * ny + y) * wx;
+      const uint64_t wd = row[wc];
+      const uint32_t bits = (uint32_t)wd;
+      const int base = (int)(wd >> 32) - ls;
+      const int below = __popc(bits & ((1u << p) - 1u));  // occupied voxels of this word in front of x
+      if ((bits >> p) & 1u) i[1] = base + below;
+      if (p > 0) {
+        if ((bits >> (p - 1)) & 1u) i[0] = base + below - 1;
+      } else if (wc > 0) {
+        const uint64_t wp = row[wc - 1];
+        if ((uint32_t)wp >> 31) i[0] = (int)(wp >> 32) - ls + __popc((uint32_t)wp & 0x7FFFFFFFu);
+      }
+      if (p < 31) {
+        if ((bits >> (p + 1)) & 1u) i[2] = base + below + (int)((bits >> p) & 1u);
+      } else if (wc + 1 < wx) {
+        const uint64_t wn = row[wc + 1];
+        if ((uint32_t)wn & 1u) i[2] = (int)(wn >> 32) - ls;
+      }
+    }
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd) {
+      const int k = dd * 9 + r;
+      const int v = i[dd];
+      if (valid) nbr[(int64_t)k * N + o] = v;
+      const unsigned long long m = __ballot(v >= 0);
+      if (lane == 0) wcnt[w][k] = __popcll(m);
+    }
+  }
+  (void)nx;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int k = threadIdx.x;
+    blk_cnt[(int64_t)k * nblk + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+  }
+}
+
+// the coarse site of every site of scale l (its voxel halved, looked up at scale l + 1)
+__global__ void __launch_bounds__(256)
+    k_occ_coarse_of_fine(const int4 *__restrict__ coords, int64_t N, const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words,
+                         const int *__restrict__ info, int l, int32_t *__restrict__ coarse_of_fine) {
+  const OccDev *__restrict__ d = (const OccDev *)buf;
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= N) return;
+  const int4 c = coords[f];
+  const int l1 = l + 1;
+  coarse_of_fine[f] = occ_rank(d, words, info, l1, (c.x >> 1) - (d->ox >> l1), (c.y >> 1) - (d->oy >> l1), (c.z >> 1) - (d->oz >> l1),
+                               c.w - d->ob);
+}
+
 static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
   int64_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -926,20 +1264,27 @@ static int batch_layout(const scn_batch_plan *pl, scn_batch_layout *lo) {
   lo->site_of_row = take((size_t)pl->P * 4);
   lo->site_start = take((size_t)(pl->P + 1) * 4);
   size_t sc_grid = 0, sc_rules = 0;  // scratch: one region for a grid build, one for a rulebook build, each the largest needed
+  const bool occ = (pl->flags & 1) != 0;  // scn_batch_build_occ: no sort, no hash maps
+  if (occ)  // (the input layer's arrival numbers, per-site counts and their block sums)
+    sc_grid = align256((size_t)pl->P * 4) + align256((size_t)(pl->N[0] + 1) * 4) + align256((size_t)((pl->N[0] + 1 + 255) / 256 + 1) * 4);
   for (int l = 0; l < L; ++l) {
     const int64_t N = pl->N[l], Pl = l == 0 ? pl->P : pl->N[l - 1];
     const int64_t n_gran = (N + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE;
     lo->coords[l] = take((size_t)N * 16);
     lo->keys[l] = take((size_t)N * 8);
-    const size_t gt = scn_grid_build_temp_bytes(Pl);
-    SCN_REQUIRE(gt > 0, "scn_batch: rocprim size query failed");
-    // (grid scratch: the sort's workspace, the sorted keys, and for the coarser scales order / site_of_row / site_start)
-    const size_t g = align256(gt) + align256((size_t)Pl * 8) + (l == 0 ? 0 : 2 * align256((size_t)Pl * 4) + align256((size_t)(Pl + 1) * 4));
-    if (g > sc_grid) sc_grid = g;
+    if (!occ) {
+      const size_t gt = scn_grid_build_temp_bytes(Pl);
+      SCN_REQUIRE(gt > 0, "scn_batch: rocprim size query failed");
+      // (grid scratch: the sort's workspace, the sorted keys, and for the coarser scales order / site_of_row / site_start)
+      const size_t g = align256(gt) + align256((size_t)Pl * 8) + (l == 0 ? 0 : 2 * align256((size_t)Pl * 4) + align256((size_t)(Pl + 1) * 4));
+      if (g > sc_grid) sc_grid = g;
+    }
     if (pl->sub[l]) {
-      lo->hash_cap[l] = scn_hash_capacity(N);
-      lo->hash_keys[l] = take((size_t)lo->hash_cap[l] * 8);
-      lo->hash_vals[l] = take((size_t)lo->hash_cap[l] * 4);
+      if (!occ) {
+        lo->hash_cap[l] = scn_hash_capacity(N);
+        lo->hash_keys[l] = take((size_t)lo->hash_cap[l] * 8);
+        lo->hash_vals[l] = take((size_t)lo->hash_cap[l] * 4);
+      }
       lo->sub_rules[l] = take((size_t)27 * N * 8);
       lo->sub_bases[l] = take((size_t)27 * (n_gran + 1) * 4);
       const size_t r = align256((size_t)27 * N * 4) + align256(scn_rules_temp_bytes(N, 27));
@@ -950,7 +1295,7 @@ static int batch_layout(const scn_batch_plan *pl, scn_batch_layout *lo) {
       lo->str_rules[l] = take((size_t)8 * N * 8);
       lo->str_bases_fine[l] = take((size_t)8 * (n_gran + 1) * 4);
       lo->str_bases_coarse[l] = take((size_t)8 * (n_gran_c + 1) * 4);
-      const size_t r = align256(scn_rules_temp_bytes(N, 8));
+      const size_t r = (occ ? align256((size_t)N * 4) : 0) + align256(scn_rules_temp_bytes(N, 8));  // (occ: + the coarse site of every site)
       if (r > sc_rules) sc_rules = r;
     }
   }
@@ -965,6 +1310,7 @@ int scn_batch_layout_query(const scn_batch_plan *plan_host, scn_batch_layout *la
 int scn_batch_build(const void *coords, const scn_batch_plan *pl, void *arena, size_t arena_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   scn_batch_layout lo;
+  SCN_REQUIRE(pl != nullptr && !(pl->flags & 1), "scn_batch_build: a plan with flags bit 0 is for scn_batch_build_occ");
   if (int rc = batch_layout(pl, &lo)) return rc;
   SCN_REQUIRE(coords != nullptr && arena != nullptr && arena_bytes >= (size_t)lo.total, "scn_batch_build: arena smaller than scn_batch_layout_query says");
   char *A = (char *)arena;
@@ -1022,6 +1368,196 @@ int scn_batch_build(const void *coords, const scn_batch_plan *pl, void *arena, s
       if (int rc = scn_submanifold_rules((const int32_t *)(A + lo.coords[l]), N, hk, hv, lo.hash_cap[l], nbr, rules, counts, rt,
                                          scn_rules_temp_bytes(N, 27), nullptr, 0, -1, nullptr, stream_))
         return rc;
+      if (int rc = scn_tile_bases(rules, counts, 27, N, 1, N, (int32_t *)(A + lo.sub_bases[l]), stream_)) return rc;
+    }
+  }
+  return 0;
+}
+
+// ---- occupancy bitmaps (include/scn_hip.h) ----
+int scn_occ_bounds(const void *coords, int coords_dtype, int ncols, int64_t P, int32_t *scratch_dev, int32_t *minmax_host,
+                   void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(P > 0 && P < (int64_t)1 << 31, "scn_occ_bounds: P out of range");
+  SCN_REQUIRE(ncols == 3 || ncols == 4, "scn_occ_bounds: ncols must be 3 or 4");
+  SCN_REQUIRE(coords_dtype >= 0 && coords_dtype <= 2, "scn_occ_bounds: coords_dtype must be 0 (int32), 1 (int64) or 2 (float32)");
+  SCN_REQUIRE(scratch_dev != nullptr && minmax_host != nullptr, "scn_occ_bounds: NULL argument");
+  SCN_CHECK_HIP(hipMemsetAsync(scratch_dev, 0x80, 36, stream));
+  const int g = grid_for(P, 256, 2048);
+  if (coords_dtype == 1) k_occ_bounds<1><<<g, 256, 0, stream>>>(coords, ncols, P, scratch_dev);
+  else if (coords_dtype == 0) k_occ_bounds<0><<<g, 256, 0, stream>>>(coords, ncols, P, scratch_dev);
+  else k_occ_bounds<2><<<g, 256, 0, stream>>>(coords, ncols, P, scratch_dev);
+  SCN_CHECK_LAUNCH();
+  int32_t h[9];
+  SCN_CHECK_HIP(hipMemcpyAsync(h, scratch_dev, 36, hipMemcpyDeviceToHost, stream));
+  SCN_CHECK_HIP(hipStreamSynchronize(stream));
+  if (h[8] != (int32_t)0x80808080 || h[4] == (int32_t)0x80808080)
+    return fail(3, "scn_occ_bounds: coordinate outside the 31-bit key box (0<=x<1024, 0<=y<2048, 0<=z<1024) or bad sample index%s", "");
+  for (int a = 0; a < 4; ++a) {
+    minmax_host[a] = -h[a];
+    minmax_host[4 + a] = h[4 + a];
+  }
+  return 0;
+}
+
+int scn_occ_plan(const int32_t *mm, int levels, scn_occ_box *box) {
+  SCN_REQUIRE(mm != nullptr && box != nullptr, "scn_occ_plan: NULL argument");
+  SCN_REQUIRE(levels >= 1 && levels <= SCN_BATCH_MAX_LEVELS, "scn_occ_plan: levels must be 1..SCN_BATCH_MAX_LEVELS");
+  for (int a = 0; a < 4; ++a) SCN_REQUIRE(mm[a] >= 0 && mm[4 + a] >= mm[a], "scn_occ_plan: bad bounds");
+  memset(box, 0, sizeof(*box));
+  box->levels = levels;
+  const int align = 1 << (levels - 1);
+  for (int a = 0; a < 3; ++a) box->origin[a] = mm[a] & ~(align - 1);
+  box->origin[3] = mm[3];
+  box->nb = mm[7] - mm[3] + 1;
+  int64_t W = 0;
+  for (int l = 0; l < levels; ++l) {
+    for (int a = 0; a < 3; ++a) box->n[l][a] = ((mm[4 + a] - box->origin[a]) >> l) + 1;
+    box->wx[l] = (box->n[l][0] + 31) / 32;
+    box->woff[l] = W;
+    W += (int64_t)box->nb * box->n[l][2] * box->n[l][1] * box->wx[l];
+    if (W > SCN_OCC_MAX_WORDS) {
+      box->bytes = 0;  // (too large: the caller builds with scn_batch_build)
+      return 0;
+    }
+  }
+  box->woff[levels] = W;
+  box->blocks = (W + 1023) / 1024;
+  box->off_info = 1024;
+  box->off_blk = 2048;
+  box->off_words = (int64_t)align256((size_t)2048 + (size_t)(box->blocks + 1) * 4);
+  box->bytes = box->off_words + box->blocks * 1024 * 8;
+  return 0;
+}
+
+static OccDev occ_dev(const scn_occ_box *box) {
+  OccDev d;
+  memset(&d, 0, sizeof(d));
+  d.levels = box->levels; d.nb = box->nb;
+  d.ox = box->origin[0]; d.oy = box->origin[1]; d.oz = box->origin[2]; d.ob = box->origin[3];
+  for (int l = 0; l < box->levels; ++l) {
+    d.nx[l] = box->n[l][0]; d.ny[l] = box->n[l][1]; d.nz[l] = box->n[l][2]; d.wx[l] = box->wx[l];
+  }
+  for (int l = 0; l <= box->levels; ++l) d.woff[l] = box->woff[l];
+  return d;
+}
+
+int scn_occ_chain(const void *coords, int coords_dtype, int ncols, int64_t P, const scn_occ_box *box, void *occ, size_t occ_bytes,
+                  int32_t *n_sites_host, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(box != nullptr && box->bytes > 0 && occ != nullptr && occ_bytes >= (size_t)box->bytes, "scn_occ_chain: buffer smaller than scn_occ_plan says");
+  SCN_REQUIRE(P > 0 && P < (int64_t)1 << 31, "scn_occ_chain: P out of range");
+  SCN_REQUIRE(ncols == 3 || ncols == 4, "scn_occ_chain: ncols must be 3 or 4");
+  SCN_REQUIRE(coords_dtype >= 0 && coords_dtype <= 2, "scn_occ_chain: coords_dtype must be 0 (int32), 1 (int64) or 2 (float32)");
+  char *B = (char *)occ;
+  uint64_t *buf = (uint64_t *)B, *words = (uint64_t *)(B + box->off_words);
+  int *info = (int *)(B + box->off_info), *blk = (int *)(B + box->off_blk);
+  // (the counters and everything behind them: the block sums are written before they are read, but one memset is one launch)
+  SCN_CHECK_HIP(hipMemsetAsync(B + box->off_info, 0, (size_t)(box->bytes - box->off_info), stream));
+  k_occ_header<<<1, 64, 0, stream>>>(occ_dev(box), (OccDev *)B);
+  SCN_CHECK_LAUNCH();
+  const int nblk = (int)((P + 255) / 256);
+  if (coords_dtype == 1) k_occ_set<1><<<nblk, 256, 0, stream>>>(coords, ncols, P, buf, words);
+  else if (coords_dtype == 0) k_occ_set<0><<<nblk, 256, 0, stream>>>(coords, ncols, P, buf, words);
+  else k_occ_set<2><<<nblk, 256, 0, stream>>>(coords, ncols, P, buf, words);
+  SCN_CHECK_LAUNCH();
+  k_occ_count<<<(int)box->blocks, 256, 0, stream>>>(words, blk);
+  SCN_CHECK_LAUNCH();
+  k_excl_scan_rows<<<1, 1024, 0, stream>>>(blk, (int)box->blocks, info + OCC_INFO_START + box->levels);
+  SCN_CHECK_LAUNCH();
+  k_occ_base<<<(int)box->blocks, 256, 0, stream>>>(buf, words, blk, info);
+  SCN_CHECK_LAUNCH();
+  if (n_sites_host == nullptr) return 0;
+  return scn_occ_fetch(occ, box, n_sites_host, stream_);
+}
+
+int scn_occ_fetch(const void *occ, const scn_occ_box *box, int32_t *n_sites_host, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  SCN_REQUIRE(occ != nullptr && box != nullptr && box->bytes > 0 && n_sites_host != nullptr, "scn_occ_fetch: bad arguments");
+  int h[SCN_BATCH_MAX_LEVELS + 1];
+  SCN_CHECK_HIP(hipMemcpyAsync(h, (const char *)occ + box->off_info, 4 * (box->levels + 1), hipMemcpyDeviceToHost, stream));
+  SCN_CHECK_HIP(hipStreamSynchronize(stream));
+  for (int l = 0; l < box->levels; ++l) n_sites_host[l] = h[l + 1] - h[l];
+  return 0;
+}
+
+int scn_batch_build_occ(const void *coords, const scn_batch_plan *pl, const scn_occ_box *box, void *occ, void *arena,
+                        size_t arena_bytes, void *stream_) {
+  hipStream_t stream = as_stream(stream_);
+  scn_batch_layout lo;
+  SCN_REQUIRE(pl != nullptr && (pl->flags & 1), "scn_batch_build_occ: the plan's flags bit 0 must be set");
+  if (int rc = batch_layout(pl, &lo)) return rc;
+  SCN_REQUIRE(coords != nullptr && arena != nullptr && arena_bytes >= (size_t)lo.total, "scn_batch_build_occ: arena smaller than scn_batch_layout_query says");
+  SCN_REQUIRE(box != nullptr && box->bytes > 0 && occ != nullptr && box->levels >= pl->levels, "scn_batch_build_occ: the box must cover the plan's scales");
+  char *A = (char *)arena, *B = (char *)occ;
+  const uint64_t *buf = (const uint64_t *)B, *words = (const uint64_t *)(B + box->off_words);
+  int *info = (int *)(B + box->off_info);
+  const int L = pl->levels;
+  const int64_t P = pl->P, N0 = pl->N[0];
+  int32_t *small = (int32_t *)(A + lo.small);
+  // ---- sites of every scale
+  OccOut out;
+  for (int l = 0; l < SCN_BATCH_MAX_LEVELS; ++l) out.coords[l] = out.keys[l] = -1;
+  for (int l = 0; l < L; ++l) { out.coords[l] = lo.coords[l]; out.keys[l] = lo.keys[l]; }
+  k_occ_out<<<1, 64, 0, stream>>>(out, (OccOut *)(B + OCC_HDR_OUT));
+  SCN_CHECK_LAUNCH();
+  const int64_t W = box->woff[box->levels];
+  k_occ_sites<<<(int)((W + 255) / 256), 256, 0, stream>>>(buf, words, W, info, A);
+  SCN_CHECK_LAUNCH();
+  // ---- input layer: site_of_row, site_start, order
+  char *S = A + lo.scratch;
+  int32_t *slot = (int32_t *)S; S += align256((size_t)P * 4);
+  int *cnt = (int *)S; S += align256((size_t)(N0 + 1) * 4);
+  const int nb0 = (int)((N0 + 1 + 255) / 256);
+  int *blk = (int *)S; S += align256((size_t)(nb0 + 1) * 4);
+  char *SR = S;
+  int32_t *site_of_row = (int32_t *)(A + lo.site_of_row), *site_start = (int32_t *)(A + lo.site_start), *order = (int32_t *)(A + lo.order);
+  SCN_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)(N0 + 1) * 4, stream));
+  const int nbp = (int)((P + 255) / 256);
+  if (pl->coords_dtype == 1) k_occ_rows<1><<<nbp, 256, 0, stream>>>(coords, pl->ncols, P, buf, words, info, site_of_row, slot, cnt);
+  else if (pl->coords_dtype == 0) k_occ_rows<0><<<nbp, 256, 0, stream>>>(coords, pl->ncols, P, buf, words, info, site_of_row, slot, cnt);
+  else k_occ_rows<2><<<nbp, 256, 0, stream>>>(coords, pl->ncols, P, buf, words, info, site_of_row, slot, cnt);
+  SCN_CHECK_LAUNCH();
+  k_sum256<<<nb0, 256, 0, stream>>>(cnt, N0, blk);
+  SCN_CHECK_LAUNCH();
+  k_excl_scan_rows<<<1, 1024, 0, stream>>>(blk, nb0, blk + nb0);
+  SCN_CHECK_LAUNCH();
+  k_starts256<<<nb0, 256, 0, stream>>>(cnt, N0, blk, site_start, (int)P);
+  SCN_CHECK_LAUNCH();
+  k_occ_order<<<nbp, 256, 0, stream>>>(site_of_row, slot, site_start, P, order);
+  SCN_CHECK_LAUNCH();
+  k_occ_order_sort<<<(int)((N0 + 255) / 256), 256, 0, stream>>>(site_start, N0, order, info);
+  SCN_CHECK_LAUNCH();
+  k_occ_small<<<1, 64, 0, stream>>>(info, L, small);
+  SCN_CHECK_LAUNCH();
+  // ---- rulebooks
+  for (int l = 0; l < L; ++l) {
+    const int64_t N = pl->N[l];
+    const int4 *cl = (const int4 *)(A + lo.coords[l]);
+    if (pl->strided[l]) {
+      const int64_t Nc = pl->N[l + 1];
+      int32_t *cof = (int32_t *)SR;
+      void *rt = SR + align256((size_t)N * 4);
+      k_occ_coarse_of_fine<<<(int)((N + 255) / 256), 256, 0, stream>>>(cl, N, buf, words, info, l, cof);
+      SCN_CHECK_LAUNCH();
+      int32_t *rules = (int32_t *)(A + lo.str_rules[l]);
+      int32_t *counts = small + 2 * L + 27 * L + 8 * l;
+      if (int rc = scn_strided_rules((const int32_t *)cl, N, cof, rules, counts, rt, scn_rules_temp_bytes(N, 8), stream_)) return rc;
+      if (int rc = scn_tile_bases(rules, counts, 8, N, 1, Nc, (int32_t *)(A + lo.str_bases_coarse[l]), stream_)) return rc;
+      if (int rc = scn_tile_bases(rules, counts, 8, N, 0, N, (int32_t *)(A + lo.str_bases_fine[l]), stream_)) return rc;
+    }
+    if (pl->sub[l]) {
+      int32_t *nbr = (int32_t *)SR;
+      int *blk_cnt = (int *)(SR + align256((size_t)27 * N * 4));
+      int32_t *rules = (int32_t *)(A + lo.sub_rules[l]);
+      int32_t *counts = small + 2 * L + 27 * l;
+      const int nblk = (int)((N + 255) / 256);
+      k_sub_probe_occ<<<nblk, 256, 0, stream>>>(cl, N, buf, words, info, l, nbr, blk_cnt, nblk);
+      SCN_CHECK_LAUNCH();
+      k_excl_scan_rows<<<27, 1024, 0, stream>>>(blk_cnt, nblk, counts);
+      SCN_CHECK_LAUNCH();
+      k_rules_fill<27><<<nblk, 256, 0, stream>>>(nbr, N, blk_cnt, nblk, (int2 *)rules);
+      SCN_CHECK_LAUNCH();
       if (int rc = scn_tile_bases(rules, counts, 27, N, 1, N, (int32_t *)(A + lo.sub_bases[l]), stream_)) return rc;
     }
   }

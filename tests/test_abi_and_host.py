@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()  # raises if the .so is missing or a symbol cannot be resolved
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.scn_abi_version() == 6
+    assert lib.scn_abi_version() == 7
     # tuning / ablation entry points are not part of the product library (only of libscn_hip_tuning.so)
     assert not hasattr(lib, "scn_set_tuning") and not hasattr(lib, "scn_debug_stamps")
     assert os.path.exists(_lib.TUNING_LIB_PATH)
@@ -46,6 +46,42 @@ def test_library_exports_every_declared_symbol():
     assert lib.scn_conv_wpack_bytes(27, 64, 64) == 27 * 64 * 64 * 4
     assert lib.scn_bn_temp_bytes(64) > 2 * 64 * 4
     assert lib.scn_rules_temp_bytes(1000, 27) >= 27 * 4 * 4
+
+
+def test_occupancy_box_plan_is_host_arithmetic():
+    """scn_occ_plan (round 6): the bounding box of a batch as bitmaps -- origin aligned to the coarsest scale (scale l = scale 0
+    shifted by l), extents halved per scale, one 64-bit word per 32 voxels of an x row, scales one behind the other; a box beyond
+    SCN_OCC_MAX_WORDS is refused by size 0, not by an error; an occupancy layout of a batch has neither hash maps nor a sort's
+    workspace"""
+    import ctypes
+    from occuseg_amd import _lib
+    lib = _lib.load()
+    mm = (ctypes.c_int32 * 8)(37, 1001, 515, 2, 126, 1090, 604, 4)
+    box = _lib.OccBox()
+    assert lib.scn_occ_plan(mm, 4, ctypes.byref(box)) == 0
+    assert list(box.origin) == [32, 1000, 512, 2] and box.nb == 3 and box.levels == 4
+    W = 0
+    for l in range(4):
+        n = [((mm[4 + a] - box.origin[a]) >> l) + 1 for a in range(3)]
+        assert list(box.n[l]) == n and box.wx[l] == (n[0] + 31) // 32 and box.woff[l] == W
+        W += 3 * n[2] * n[1] * box.wx[l]
+    assert box.woff[4] == W and box.blocks == (W + 1023) // 1024
+    assert box.off_info == 1024 and box.off_blk == 2048 and box.off_words % 256 == 0 and box.off_words >= 2048 + 4 * (box.blocks + 1)
+    assert box.bytes == box.off_words + box.blocks * 1024 * 8
+    big = (ctypes.c_int32 * 8)(0, 0, 0, 0, 1023, 2047, 1023, 7)
+    assert lib.scn_occ_plan(big, 6, ctypes.byref(box)) == 0 and box.bytes == 0
+    assert lib.scn_occ_plan(mm, 0, ctypes.byref(box)) != 0 and lib.scn_occ_plan(mm, 13, ctypes.byref(box)) != 0
+    bad = (ctypes.c_int32 * 8)(5, 5, 5, 0, 4, 9, 9, 0)
+    assert lib.scn_occ_plan(bad, 2, ctypes.byref(box)) != 0
+    plan = _lib.BatchPlan()
+    plan.levels, plan.coords_dtype, plan.ncols, plan.P, plan.flags = 2, 0, 4, 50000, 1
+    for l, n in enumerate((30000, 9000)):
+        plan.N[l], plan.sub[l], plan.strided[l] = n, 1, 1 if l == 0 else 0
+    lo = _lib.BatchLayout()
+    assert lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)) == 0
+    assert all(lo.hash_cap[l] == 0 and lo.hash_keys[l] == -1 and lo.hash_vals[l] == -1 for l in range(2))
+    # scratch: arrival numbers [P], per-site counts, block sums; the larger of the two rulebook scratches behind them
+    assert lo.total - lo.scratch >= 4 * 50000 + 4 * 30001 + 27 * 30000 * 4
 
 
 def test_product_path_has_no_cpu_fallback_and_never_imports_the_oracle():

@@ -208,14 +208,16 @@ def test_grid_chain_one_read_back_same_grids(gpu, monkeypatch, dtype):
     size = torch.tensor([4096] * 3, dtype=torch.int64)
     lib = SCN._lib_()
     calls = {"scn_grid_build": 0, "scn_grid_build_async": 0, "scn_grid_chain_counts": 0, "scn_batch_build": 0,
-             "scn_submanifold_rules": 0, "scn_strided_rules": 0, "scn_tile_bases": 0, "scn_hash_build": 0}
+             "scn_submanifold_rules": 0, "scn_strided_rules": 0, "scn_tile_bases": 0, "scn_hash_build": 0,
+             "scn_occ_bounds": 0, "scn_occ_chain": 0, "scn_batch_build_occ": 0}
     for name in calls:
         real = getattr(lib, name)
         monkeypatch.setattr(lib, name, lambda *a, _r=real, _n=name: (calls.__setitem__(_n, calls[_n] + 1), _r(*a))[1])
 
-    def run(chain, batch=False):
+    def run(chain, batch=False, occ=False):
         monkeypatch.setattr(SCN, "GRID_CHAIN", chain)
         monkeypatch.setattr(SCN, "BATCH_BUILD", batch)
+        monkeypatch.setattr(SCN, "OCC_BUILD", occ)
         for k in calls:
             calls[k] = 0
         m = SCN.Metadata_3()
@@ -236,24 +238,141 @@ def test_grid_chain_one_read_back_same_grids(gpu, monkeypatch, dtype):
     # round 5: ... and every grid and rulebook of the chain queued by ONE call into one arena (scn_batch_build)
     one, n3 = run(True, batch=True)
     assert n3 == dict({k: 0 for k in calls}, scn_grid_chain_counts=1, scn_batch_build=1)
+    # round 6: ... from occupancy bitmaps of the batch's bounding box: no sort, no hash map, with the chain switch on or off
+    occ, n4 = run(True, batch=True, occ=True)
+    assert n4 == dict({k: 0 for k in calls}, scn_occ_bounds=1, scn_occ_chain=1, scn_batch_build_occ=1)
+    occ2, n5 = run(False, batch=True, occ="auto")
+    assert n5 == n4
     assert [r[0] for r in ref[0::2]] == [r[0] for r in got[0::2]] and ref[0][0] > ref[2][0] > ref[10][0] > 0
-    for a, b, d, e in zip(ref, again, got, one):
-        for x, y, z, u in zip(a, b, d, e):
+    for a, b, d, e, f, g in zip(ref, again, got, one, occ, occ2):
+        for x, y, z, u, v, w in zip(a, b, d, e, f, g):
             if torch.is_tensor(x):
-                assert torch.equal(x, y) and torch.equal(x, z) and torch.equal(x, u)
+                assert torch.equal(x, y) and torch.equal(x, z) and torch.equal(x, u) and torch.equal(x, v) and torch.equal(x, w)
             elif isinstance(x, list):  # the lists of a rulebook (the rows behind counts[k] are unwritten memory)
-                assert len(x) == len(y) == len(z) == len(u)
-                assert all(np.array_equal(i, j) and np.array_equal(i, k) and np.array_equal(i, v) for i, j, k, v in zip(x, y, z, u))
+                assert len(x) == len(y) == len(z) == len(u) == len(v) == len(w)
+                assert all(np.array_equal(i, j) and np.array_equal(i, k) and np.array_equal(i, q) and np.array_equal(i, r) and np.array_equal(i, t)
+                           for i, j, k, q, r, t in zip(x, y, z, u, v, w))
             else:
-                assert x == y == z == u
+                assert x == y == z == u == v == w
     # the error a coordinate outside the key box raises comes from the chain now
     bad = coords.clone()
     bad[5, 1] = 2048
     monkeypatch.setattr(SCN, "GRID_CHAIN", True)
-    for batch in (False, True):
+    for batch, occ_ in ((False, False), (True, False), (True, True)):
         monkeypatch.setattr(SCN, "BATCH_BUILD", batch)
+        monkeypatch.setattr(SCN, "OCC_BUILD", occ_)
         with pytest.raises(RuntimeError, match="key box"):
             SCN.Metadata_3().inputLayer(size, bad, 0, 4, gpu)
+
+
+def _same_walk(a, b):
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            if torch.is_tensor(u):
+                assert torch.equal(u, v)
+            elif isinstance(u, list):
+                assert len(u) == len(v) and all(np.array_equal(i, j) for i, j in zip(u, v))
+            else:
+                assert u == v
+
+
+@pytest.mark.parametrize("case", ["word_edges", "odd_origin_three_samples", "ncols3_float", "long_segment", "sparse_far_apart"])
+def test_occupancy_build_against_the_sort_build(gpu, monkeypatch, case):
+    """scn_batch_build_occ (round 6: ranks from population counts over bitmaps of the bounding box) against the per-scale sort +
+    hash build that test_rulebooks_bit_exact holds against the oracle: every grid, rulebook, tile-base table and the input
+    layer's order / site_of_row / site_start, bit for bit -- on clouds made to hit what the bitmaps could get wrong: sites at
+    both ends of the 32-voxel words, a box whose origin is not aligned to the coarsest scale, sample indices that do not start at
+    0, three-column and float coordinates, a voxel with more rows than the segment sort takes (the host's repair), and a cloud
+    whose box is mostly empty."""
+    from occuseg_amd import SCN
+    rng = np.random.default_rng(11)
+    levels, dtype, ncols = 4, torch.int64, 4
+    if case == "word_edges":
+        # dense slabs around x = 31 | 32 and 63 | 64 (relative to an origin of 8 * k): every row has neighbours across a word edge
+        x = np.concatenate([np.arange(24, 40), np.arange(56, 72)]) + 160
+        g = np.stack(np.meshgrid(x, np.arange(100, 112), np.arange(40, 52), np.arange(2), indexing="ij"), -1).reshape(-1, 4)
+        c = g[rng.random(len(g)) < 0.7]
+    elif case == "odd_origin_three_samples":
+        c = np.concatenate([rng.integers(0, 90, size=(30000, 3)) + np.array([37, 1001, 515]), rng.integers(2, 5, size=(30000, 1))], 1)
+    elif case == "ncols3_float":
+        c = (rng.integers(0, 60, size=(20000, 3)) + 5).astype(np.float32) + 0.25
+        dtype, ncols = torch.float32, 3
+    elif case == "long_segment":
+        c = np.concatenate([rng.integers(0, 40, size=(8000, 3)) + 3, rng.integers(0, 2, size=(8000, 1))], 1)
+        c[rng.permutation(8000)[:300]] = np.array([17, 9, 30, 1])     # 300 rows in one voxel (> SCN_OCC_SEGMENT_MAX = 64)
+        c[rng.permutation(8000)[:64]] = np.array([5, 5, 5, 0])        # <= 64: sorted on the device
+    else:
+        c = np.concatenate([rng.integers(0, 1000, size=(3000, 3)), rng.integers(0, 2, size=(3000, 1))], 1)
+    coords = torch.from_numpy(np.ascontiguousarray(c)).to(dtype)
+    size = torch.tensor([4096 + 16 * (1 + ["word_edges", "odd_origin_three_samples", "ncols3_float", "long_segment",
+                                            "sparse_far_apart"].index(case))] * 3, dtype=torch.int64)
+    monkeypatch.setattr(SCN, "GRID_CHAIN", False)
+
+    def run(occ):
+        monkeypatch.setattr(SCN, "OCC_BUILD", occ)
+        m = SCN.Metadata_3()
+        m.inputLayer(size, coords, 0, 4, gpu)
+        return _walk_levels(m, size, levels), m
+
+    SCN._PLANS.pop(tuple(int(v) for v in size), None)
+    ref, _ = run(False)          # no plan yet: per-scale builds
+    ref2, _ = run(False)         # plan replayed, per-scale builds
+    before = dict(SCN.OCC_STATS)
+    got, m = run(True)
+    assert SCN.OCC_STATS["built"] == before["built"] + 1
+    assert SCN.OCC_STATS["order_repaired"] == before["order_repaired"] + (1 if case == "long_segment" else 0)
+    _same_walk(ref, ref2)
+    _same_walk(ref, got)
+    # a grid built from bitmaps has no hash map until something asks for one
+    g0 = m.grids[tuple(int(v) for v in size)]
+    assert g0.hash_keys is None and m._hash(g0).hash_keys is not None
+    auto, _ = run("auto")
+    _same_walk(ref, auto)
+    if case == "sparse_far_apart":  # 3,000 points in a 1000^3 box: "auto" leaves it to the sort
+        assert SCN.OCC_STATS["too_large"] == before["too_large"] + 1 and SCN.OCC_STATS["built"] == before["built"] + 1
+    else:
+        assert SCN.OCC_STATS["built"] == before["built"] + 2
+
+
+def test_occupancy_chain_abi(gpu):
+    """scn_occ_bounds / scn_occ_plan / scn_occ_chain by themselves: bounds and site counts of coords >> l against numpy, the
+    high halves of the words = running population counts, duplicates, sample indices from 3, 1 to 12 scales"""
+    import ctypes
+    from occuseg_amd import SCN, _lib
+    from occuseg_amd.SCN import ptr, stream, check
+    lib = SCN._lib_()
+    rng = np.random.default_rng(6)
+    for P, span, ncols, levels, dt in ((1, 8, 3, 1, np.int32), (5000, 40, 4, 12, np.int64), (200000, 300, 4, 6, np.int32)):
+        c = (rng.integers(0, span, size=(P, ncols)) + 7).astype(dt)
+        if ncols == 4:
+            c[:, 3] = rng.integers(3, 6, size=P)
+        t = torch.from_numpy(c).to(gpu)
+        mm = (ctypes.c_int32 * 8)()
+        scratch = torch.empty(16, dtype=torch.int32, device=gpu)
+        check(lib.scn_occ_bounds(ptr(t), 0 if dt == np.int32 else 1, ncols, P, ptr(scratch), mm, stream()))
+        want = list(c[:, :3].min(0)) + [c[:, 3].min() if ncols == 4 else 0] + list(c[:, :3].max(0)) + [c[:, 3].max() if ncols == 4 else 0]
+        assert list(mm) == [int(v) for v in want]
+        box = _lib.OccBox()
+        check(lib.scn_occ_plan(mm, levels, ctypes.byref(box)))
+        assert box.bytes > 0 and all(box.origin[a] % (1 << (levels - 1)) == 0 and box.origin[a] <= mm[a] for a in range(3))
+        buf = torch.zeros(box.bytes, dtype=torch.uint8, device=gpu)
+        n = (ctypes.c_int32 * levels)()
+        check(lib.scn_occ_chain(ptr(t), 0 if dt == np.int32 else 1, ncols, P, ctypes.byref(box), ptr(buf), box.bytes, n, stream()))
+        for l in range(levels):
+            cc = c.copy()
+            cc[:, :3] >>= l
+            assert n[l] == len(np.unique(cc, axis=0)), (P, l)
+        W = int(box.woff[levels])
+        words = buf[box.off_words:box.off_words + 8 * W].view(torch.int64).cpu().numpy().astype(np.uint64)
+        bits = (words & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        pop = np.array([bin(int(b)).count("1") for b in bits], np.int64)
+        assert np.array_equal((words >> np.uint64(32)).astype(np.int64), np.concatenate([[0], np.cumsum(pop)[:-1]]))
+        assert pop.sum() == sum(n)
+    # a box that does not fit: bytes = 0, no error
+    mm = (ctypes.c_int32 * 8)(0, 0, 0, 0, 1023, 2047, 1023, 63)
+    box = _lib.OccBox()
+    check(lib.scn_occ_plan(mm, 6, ctypes.byref(box)))
+    assert box.bytes == 0
 
 
 def test_grid_chain_counts_abi(gpu):

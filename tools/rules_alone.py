@@ -49,8 +49,8 @@ def main():
         torch.cuda.synchronize()
         ms.append((e0.elapsed_time(e1), (t1 - t0) * 1e3))
     ms = ms[2:]
-    print("rule build alone, GRID_CHAIN=%s: %.3f ms per batch (events; min %.3f), host issue time %.3f ms, %d rulebooks, "
-          "sites %s" % (SCN.GRID_CHAIN, sum(m[0] for m in ms) / len(ms), min(m[0] for m in ms),
+    print("rule build alone, GRID_CHAIN=%s OCC_BUILD=%s (built %d): %.3f ms per batch (events; min %.3f), host issue time %.3f ms, %d rulebooks, "
+          "sites %s" % (SCN.GRID_CHAIN, SCN.OCC_BUILD, SCN.OCC_STATS["built"], sum(m[0] for m in ms) / len(ms), min(m[0] for m in ms),
                         sum(m[1] for m in ms) / len(ms), len(plan), [g.n for g in md.grids.values()]))
 
 
