@@ -475,11 +475,12 @@ class Metadata_3(object):
         _PLANS[key] = self._plan
         if PREBUILD and old_plan:
             pending = []
+            from_batch = {id(rb) for _, rb in batch_small[1][2]} if batch_small is not None else ()
             for req in old_plan:
                 try:
                     if req[0] == "sub":
                         rb = self.getSubmanifoldRuleBook(req[1], req[2], _defer=True)
-                        if rb.total_pairs is None:  # (known already: a rulebook of the batch build, read back with `small`)
+                        if rb.total_pairs is None and id(rb) not in from_batch:  # (a rulebook of the batch build: read back with `small`)
                             pending.append(rb)
                     else:
                         self.getRuleBook(req[1], req[2], req[3], req[4], _defer=True)

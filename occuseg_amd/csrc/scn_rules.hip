@@ -61,9 +61,8 @@ __global__ void __launch_bounds__(256) k_mark_first(const uint64_t *keys, int64_
 }
 
 // exclusive scan of each row of data[rows][n] in place; totals[row] = row sum
-__global__ void __launch_bounds__(1024) k_excl_scan_rows(int *data, int n, int *totals) {
+__device__ __forceinline__ void excl_scan_row(int *__restrict__ d, int n, int *__restrict__ total) {
   __shared__ int wsum[16];
-  int *d = data + (int64_t)blockIdx.x * n;
   const int lane = lane_id(), w = threadIdx.x >> 6;
   int carry = 0;
   for (int base = 0; base < n; base += 1024) {
@@ -88,7 +87,10 @@ __global__ void __launch_bounds__(1024) k_excl_scan_rows(int *data, int n, int *
     carry += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(1024) k_excl_scan_rows(int *data, int n, int *totals) {
+  excl_scan_row(data + (int64_t)blockIdx.x * n, n, totals + blockIdx.x);
 }
 
 __global__ void __launch_bounds__(256)
@@ -306,12 +308,12 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// pass 2: order-preserving compaction of (in, out) pairs into rules[k]
+// pass 2: order-preserving compaction of (in, out) pairs into rules[k]  (block `bi` of `nblk` over the N sites of one scale)
 template <int K>
-__global__ void __launch_bounds__(256)
-    k_rules_fill(const int32_t *nbr, int64_t N, const int *blk_base, int nblk, int2 *rules) {
+__device__ __forceinline__ void rules_fill_body(const int32_t *__restrict__ nbr, int64_t N, const int *__restrict__ blk_base, int nblk,
+                                                int2 *__restrict__ rules, int bi) {
   __shared__ int wcnt[4][K];
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t o = (int64_t)bi * 256 + threadIdx.x;
   const bool valid = o < N;
   const int lane = lane_id(), w = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -328,19 +330,23 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (in_k[k] >= 0) {
-      int base = blk_base[(int64_t)k * nblk + blockIdx.x];
+      int base = blk_base[(int64_t)k * nblk + bi];
       for (int j = 0; j < w; ++j) base += wcnt[j][k];
       rules[(int64_t)k * N + base + rk[k]] = make_int2(in_k[k], (int)o);
     }
   }
 }
+template <int K>
+__global__ void __launch_bounds__(256)
+    k_rules_fill(const int32_t *nbr, int64_t N, const int *blk_base, int nblk, int2 *rules) {
+  rules_fill_body<K>(nbr, N, blk_base, nblk, rules, (int)blockIdx.x);
+}
 
 // ---------------------------------------------------- strided 2/2 rules ---
 // k = ((x&1)*2 + (y&1))*2 + (z&1): sparseconvnet/SCN/CUDA/SubmanifoldRules_cuda.cu:549-554
-__global__ void __launch_bounds__(256)
-    k_str_count(const int4 *coords, int64_t N, int *blk_cnt, int nblk) {
+__device__ __forceinline__ void str_count_body(const int4 *__restrict__ coords, int64_t N, int *__restrict__ blk_cnt, int nblk, int bi) {
   __shared__ int wcnt[4][8];
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t f = (int64_t)bi * 256 + threadIdx.x;
   const int lane = lane_id(), w = threadIdx.x >> 6;
   int koff = -1;
   if (f < N) {
@@ -355,22 +361,27 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   if (threadIdx.x < 8) {
     const int k = threadIdx.x;
-    blk_cnt[(int64_t)k * nblk + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+    blk_cnt[(int64_t)k * nblk + bi] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
   }
 }
-
 __global__ void __launch_bounds__(256)
-    k_str_fill(const int4 *coords, int64_t N, const int32_t *coarse_of_fine, const int *blk_base,
-               int nblk, int2 *rules) {
+    k_str_count(const int4 *coords, int64_t N, int *blk_cnt, int nblk) {
+  str_count_body(coords, N, blk_cnt, nblk, (int)blockIdx.x);
+}
+
+// `coarse(f, c)` = the coarse site of fine site f at coordinates c
+template <typename Coarse>
+__device__ __forceinline__ void str_fill_body(const int4 *__restrict__ coords, int64_t N, Coarse coarse_of, const int *__restrict__ blk_base,
+                                              int nblk, int2 *__restrict__ rules, int bi) {
   __shared__ int wcnt[4][8];
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t f = (int64_t)bi * 256 + threadIdx.x;
   const int lane = lane_id(), w = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   int koff = -1, coarse = -1;
   if (f < N) {
     const int4 c = coords[f];
     koff = ((c.x & 1) * 2 + (c.y & 1)) * 2 + (c.z & 1);
-    coarse = coarse_of_fine[f];
+    coarse = coarse_of(f, c);
   }
   int my_rank = 0;
 #pragma unroll
@@ -381,10 +392,15 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   if (koff >= 0) {
-    int base = blk_base[(int64_t)koff * nblk + blockIdx.x];
+    int base = blk_base[(int64_t)koff * nblk + bi];
     for (int j = 0; j < w; ++j) base += wcnt[j][koff];
     rules[(int64_t)koff * N + base + my_rank] = make_int2((int)f, coarse);
   }
+}
+__global__ void __launch_bounds__(256)
+    k_str_fill(const int4 *coords, int64_t N, const int32_t *coarse_of_fine, const int *blk_base,
+               int nblk, int2 *rules) {
+  str_fill_body(coords, N, [&](int64_t f, const int4 &) { return coarse_of_fine[f]; }, blk_base, nblk, rules, (int)blockIdx.x);
 }
 
 // Pass prefix of the 128-row output tiles of one output column (scn_conv_forward's tile_passes): k_conv_tile4 walks the pairs
@@ -533,9 +549,8 @@ __global__ void __launch_bounds__(1024)
 }
 
 // ------------------------------------------------------------ tile bases ---
-__global__ void k_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
-                             int out_col, int n_gran, int32_t *bases) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tile_bases_body(const int32_t *__restrict__ rules, const int32_t *__restrict__ counts, int K, int64_t stride,
+                                                int out_col, int n_gran, int32_t *__restrict__ bases, int64_t t) {
   const int64_t total = (int64_t)K * (n_gran + 1);
   if (t >= total) return;
   const int k = (int)(t / (n_gran + 1));
@@ -548,6 +563,10 @@ __global__ void k_tile_bases(const int32_t *rules, const int32_t *counts, int K,
     if (col[(int64_t)mid * 2] < target) lo = mid + 1; else hi = mid;
   }
   bases[t] = lo;
+}
+__global__ void k_tile_bases(const int32_t *rules, const int32_t *counts, int K, int64_t stride,
+                             int out_col, int n_gran, int32_t *bases) {
+  tile_bases_body(rules, counts, K, stride, out_col, n_gran, bases, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ------------------------------------------------------ input rule table ---
@@ -585,19 +604,39 @@ struct OccDev {
   int32_t nx[SCN_BATCH_MAX_LEVELS], ny[SCN_BATCH_MAX_LEVELS], nz[SCN_BATCH_MAX_LEVELS], wx[SCN_BATCH_MAX_LEVELS];
   int64_t woff[SCN_BATCH_MAX_LEVELS + 1];
 };
-struct OccOut {  // where k_occ_sites writes: byte offsets into the arena
-  int64_t coords[SCN_BATCH_MAX_LEVELS], keys[SCN_BATCH_MAX_LEVELS];
+// What the multi-scale launches of scn_batch_build_occ read (byte OCC_HDR_BATCH of the buffer; offsets are bytes into the arena)
+struct BatchDev {
+  int32_t L, pad;
+  int32_t N[SCN_BATCH_MAX_LEVELS];
+  int32_t blk0[SCN_BATCH_MAX_LEVELS + 1];                               // first 256-site block of every scale in those launches
+  int32_t sub_counts[SCN_BATCH_MAX_LEVELS], str_counts[SCN_BATCH_MAX_LEVELS];  // list lengths: index into `small` (-1: not built)
+  int64_t coords[SCN_BATCH_MAX_LEVELS], keys[SCN_BATCH_MAX_LEVELS], sub_rules[SCN_BATCH_MAX_LEVELS], str_rules[SCN_BATCH_MAX_LEVELS];
+  int64_t nbr[SCN_BATCH_MAX_LEVELS], sub_blk[SCN_BATCH_MAX_LEVELS], str_blk[SCN_BATCH_MAX_LEVELS];  // (scratch)
+  int64_t small;
 };
-constexpr int OCC_HDR_OUT = 512;      // byte offset of OccOut in the buffer
+struct TileDesc {
+  int64_t rules, bases, stride, first;  // (first: the launch's first thread of this table)
+  int32_t counts, K, out_col, n_gran;
+};
+struct TileDescs {
+  int32_t n, pad;
+  int64_t threads;
+  TileDesc d[3 * SCN_BATCH_MAX_LEVELS];
+};
+constexpr int OCC_HDR_BATCH = 512, OCC_HDR_TILES = 1536, OCC_HDR_BYTES = 4096;
 constexpr int OCC_INFO_START = 0;     // info[0 .. levels]: occupied voxels in front of every scale's first word ([levels] = all)
 constexpr int OCC_INFO_OVERFLOW = 32;  // info[32]: != 0 = a voxel with more than SCN_OCC_SEGMENT_MAX input rows
-static_assert(sizeof(OccDev) <= OCC_HDR_OUT && sizeof(OccOut) <= 512, "occupancy header");
+static_assert(sizeof(OccDev) <= OCC_HDR_BATCH && OCC_HDR_BATCH + sizeof(BatchDev) <= OCC_HDR_TILES &&
+                  OCC_HDR_TILES + sizeof(TileDescs) <= OCC_HDR_BYTES, "occupancy header");
 
-__global__ void k_occ_header(OccDev d, OccDev *dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = d;
+template <typename T>
+__global__ void k_put(T v, T *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
 }
-__global__ void k_occ_out(OccOut d, OccOut *dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = d;
+__device__ __forceinline__ int ml_level(const BatchDev *__restrict__ b, int blk) {
+  int l = 0;
+  while (l + 1 < b->L && blk >= b->blk0[l + 1]) ++l;
+  return l;
 }
 
 // mm[0..3] = max of (-x, -y, -z, -b), mm[4..7] = max of (x, y, z, b), mm[8] |= 1 for a coordinate outside the key box; all nine
@@ -620,6 +659,9 @@ __global__ void __launch_bounds__(256) k_occ_bounds(const void *coords_, int nco
       hi[a] = max(hi[a], v[a]);
     }
   }
+  // one atomic per value and BLOCK (a few hundred blocks: per wave of a grid that covers the rows, 65,000 atomics on eight
+  // addresses took 0.7 ms)
+  __shared__ int red[4][9];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -628,11 +670,19 @@ __global__ void __launch_bounds__(256) k_occ_bounds(const void *coords_, int nco
       hi[a] = max(hi[a], __shfl_down(hi[a], off));
     }
     if (lane_id() == 0) {
-      if (lo[a] != INT_MIN) atomicMax(mm + a, lo[a]);
-      if (hi[a] != INT_MIN) atomicMax(mm + 4 + a, hi[a]);
+      red[threadIdx.x >> 6][a] = lo[a];
+      red[threadIdx.x >> 6][4 + a] = hi[a];
     }
   }
-  if (__ballot(bad) != 0 && lane_id() == 0) atomicOr(mm + 8, 1);
+  const bool any_bad = __ballot(bad) != 0;
+  if (lane_id() == 0) red[threadIdx.x >> 6][8] = any_bad ? 1 : 0;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int v = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+    if (v != INT_MIN) atomicMax(mm + threadIdx.x, v);
+  } else if (threadIdx.x == 8 && (red[0][8] | red[1][8] | red[2][8] | red[3][8])) {
+    atomicOr(mm + 8, 1);
+  }
 }
 
 __device__ __forceinline__ int64_t occ_word_index(const OccDev *__restrict__ d, int l, int rx, int ry, int rz, int rb) {
@@ -660,8 +710,10 @@ __global__ void __launch_bounds__(256) k_occ_set(const void *coords_, int ncols,
     if (live) {
       const int64_t w = occ_word_index(d, l, rx >> l, ry >> l, rz >> l, rb);
       const uint32_t bit = 1u << ((rx >> l) & 31);
-      const uint32_t old = atomicOr(w32 + 2 * w, bit);  // (little endian: the low half of word w)
-      if (old & bit) live = false;
+      // (little endian: the low half of word w.  A plain look first: bits are only ever set, so a set bit seen here is set -- most
+      //  rows find their coarse voxels taken -- and a stale "not set" only costs the atomic)
+      if (w32[2 * w] & bit) live = false;
+      else if (atomicOr(w32 + 2 * w, bit) & bit) live = false;
     }
     if (__ballot(live) == 0) break;  // (wave-uniform)
   }
@@ -728,7 +780,7 @@ __global__ void __launch_bounds__(256) k_occ_base(const uint64_t *__restrict__ b
 __global__ void __launch_bounds__(256) k_occ_sites(const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words, int64_t W,
                                                    const int *__restrict__ info, char *__restrict__ arena) {
   const OccDev *__restrict__ d = (const OccDev *)buf;
-  const OccOut *__restrict__ out = (const OccOut *)((const char *)buf + OCC_HDR_OUT);
+  const BatchDev *__restrict__ out = (const BatchDev *)((const char *)buf + OCC_HDR_BATCH);
   const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (w >= W) return;
   const uint64_t word = words[w];
@@ -737,7 +789,7 @@ __global__ void __launch_bounds__(256) k_occ_sites(const uint64_t *__restrict__ 
   int l = 0;
   const int levels = d->levels;
   while (l + 1 < levels && w >= d->woff[l + 1]) ++l;
-  if (out->coords[l] < 0) return;  // (a scale the plan does not reach)
+  if (l >= out->L) return;  // (a scale the plan does not reach)
   const int64_t wi = w - d->woff[l];
   const int wx = d->wx[l], ny = d->ny[l], nz = d->nz[l];
   const int xw = (int)(wi % wx);
@@ -840,17 +892,24 @@ __global__ void k_occ_small(const int *__restrict__ info, int levels, int32_t *_
   small[2 * l + 1] = (l == 0 && info[OCC_INFO_OVERFLOW]) ? 2 : 0;
 }
 
-// the 27 neighbours of every site of scale l from the bitmap: one word per (y + dy, z + dz) row holds x - 1, x, x + 1 (two words
-// when the site sits at a word's edge), and their ranks are consecutive.  Output as k_sub_probe.
+// the 27 neighbours of every site of every scale from the bitmaps: one word per (y + dy, z + dz) row holds x - 1, x, x + 1 (two
+// words when the site sits at a word's edge), and their ranks are consecutive.  Output as k_sub_probe.  One launch for all scales.
 __global__ void __launch_bounds__(256)
-    k_sub_probe_occ(const int4 *__restrict__ coords, int64_t N, const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words,
-                    const int *__restrict__ info, int l, int32_t *__restrict__ nbr, int *__restrict__ blk_cnt, int nblk) {
+    k_sub_probe_occ(const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words, const int *__restrict__ info, char *__restrict__ arena) {
   __shared__ int wcnt[4][27];
   const OccDev *__restrict__ d = (const OccDev *)buf;
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const BatchDev *__restrict__ bd = (const BatchDev *)((const char *)buf + OCC_HDR_BATCH);
+  const int l = ml_level(bd, (int)blockIdx.x);
+  if (bd->sub_counts[l] < 0) return;
+  const int bi = (int)blockIdx.x - bd->blk0[l], nblk = bd->blk0[l + 1] - bd->blk0[l];
+  const int64_t N = bd->N[l];
+  const int4 *__restrict__ coords = (const int4 *)(arena + bd->coords[l]);
+  int32_t *__restrict__ nbr = (int32_t *)(arena + bd->nbr[l]);
+  int *__restrict__ blk_cnt = (int *)(arena + bd->sub_blk[l]);
+  const int64_t o = (int64_t)bi * 256 + threadIdx.x;
   const bool valid = o < N;
   const int lane = lane_id(), w = threadIdx.x >> 6;
-  const int nx = d->nx[l], ny = d->ny[l], nz = d->nz[l], wx = d->wx[l], ls = info[OCC_INFO_START + l];
+  const int ny = d->ny[l], nz = d->nz[l], wx = d->wx[l], ls = info[OCC_INFO_START + l];
   const uint64_t *__restrict__ lw = words + d->woff[l];
   int rx = 0, ry = 0, rz = 0, rb = 0;
   if (valid) {
@@ -893,25 +952,63 @@ __global__ void __launch_bounds__(256)
       if (lane == 0) wcnt[w][k] = __popcll(m);
     }
   }
-  (void)nx;
   __syncthreads();
   if (threadIdx.x < 27) {
     const int k = threadIdx.x;
-    blk_cnt[(int64_t)k * nblk + blockIdx.x] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
+    blk_cnt[(int64_t)k * nblk + bi] = wcnt[0][k] + wcnt[1][k] + wcnt[2][k] + wcnt[3][k];
   }
 }
 
-// the coarse site of every site of scale l (its voxel halved, looked up at scale l + 1)
-__global__ void __launch_bounds__(256)
-    k_occ_coarse_of_fine(const int4 *__restrict__ coords, int64_t N, const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words,
-                         const int *__restrict__ info, int l, int32_t *__restrict__ coarse_of_fine) {
+// the other per-scale launches of a batch, one launch each for all scales
+__global__ void __launch_bounds__(256) k_str_count_ml(const uint64_t *__restrict__ buf, char *__restrict__ arena) {
+  const BatchDev *__restrict__ bd = (const BatchDev *)((const char *)buf + OCC_HDR_BATCH);
+  const int l = ml_level(bd, (int)blockIdx.x);
+  if (bd->str_counts[l] < 0) return;
+  str_count_body((const int4 *)(arena + bd->coords[l]), bd->N[l], (int *)(arena + bd->str_blk[l]), bd->blk0[l + 1] - bd->blk0[l],
+                 (int)blockIdx.x - bd->blk0[l]);
+}
+// rows (blocks) scale x 35: 27 lists of the submanifold rulebook, 8 of the strided one
+__global__ void __launch_bounds__(1024) k_scan_ml(const uint64_t *__restrict__ buf, char *__restrict__ arena) {
+  const BatchDev *__restrict__ bd = (const BatchDev *)((const char *)buf + OCC_HDR_BATCH);
+  const int l = (int)blockIdx.x / 35, j = (int)blockIdx.x % 35, nblk = bd->blk0[l + 1] - bd->blk0[l];
+  int32_t *small = (int32_t *)(arena + bd->small);
+  if (j < 27) {
+    if (bd->sub_counts[l] >= 0) excl_scan_row((int *)(arena + bd->sub_blk[l]) + (int64_t)j * nblk, nblk, small + bd->sub_counts[l] + j);
+  } else if (bd->str_counts[l] >= 0) {
+    excl_scan_row((int *)(arena + bd->str_blk[l]) + (int64_t)(j - 27) * nblk, nblk, small + bd->str_counts[l] + j - 27);
+  }
+}
+__global__ void __launch_bounds__(256) k_rules_fill_ml(const uint64_t *__restrict__ buf, char *__restrict__ arena) {
+  const BatchDev *__restrict__ bd = (const BatchDev *)((const char *)buf + OCC_HDR_BATCH);
+  const int l = ml_level(bd, (int)blockIdx.x);
+  if (bd->sub_counts[l] < 0) return;
+  rules_fill_body<27>((const int32_t *)(arena + bd->nbr[l]), bd->N[l], (const int *)(arena + bd->sub_blk[l]), bd->blk0[l + 1] - bd->blk0[l],
+                      (int2 *)(arena + bd->sub_rules[l]), (int)blockIdx.x - bd->blk0[l]);
+}
+__global__ void __launch_bounds__(256) k_str_fill_ml(const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words,
+                                                     const int *__restrict__ info, char *__restrict__ arena) {
   const OccDev *__restrict__ d = (const OccDev *)buf;
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (f >= N) return;
-  const int4 c = coords[f];
+  const BatchDev *__restrict__ bd = (const BatchDev *)((const char *)buf + OCC_HDR_BATCH);
+  const int l = ml_level(bd, (int)blockIdx.x);
+  if (bd->str_counts[l] < 0) return;
   const int l1 = l + 1;
-  coarse_of_fine[f] = occ_rank(d, words, info, l1, (c.x >> 1) - (d->ox >> l1), (c.y >> 1) - (d->oy >> l1), (c.z >> 1) - (d->oz >> l1),
-                               c.w - d->ob);
+  // the coarse site of a site: its voxel halved, looked up at the next scale
+  auto coarse = [&](int64_t, const int4 &c) {
+    return occ_rank(d, words, info, l1, (c.x >> 1) - (d->ox >> l1), (c.y >> 1) - (d->oy >> l1), (c.z >> 1) - (d->oz >> l1), c.w - d->ob);
+  };
+  str_fill_body((const int4 *)(arena + bd->coords[l]), bd->N[l], coarse, (const int *)(arena + bd->str_blk[l]), bd->blk0[l + 1] - bd->blk0[l],
+                (int2 *)(arena + bd->str_rules[l]), (int)blockIdx.x - bd->blk0[l]);
+}
+__global__ void __launch_bounds__(256) k_tile_bases_ml(const uint64_t *__restrict__ buf, char *__restrict__ arena) {
+  const BatchDev *__restrict__ bd = (const BatchDev *)((const char *)buf + OCC_HDR_BATCH);
+  const TileDescs *__restrict__ td = (const TileDescs *)((const char *)buf + OCC_HDR_TILES);
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= td->threads) return;
+  int i = 0;
+  while (i + 1 < td->n && t >= td->d[i + 1].first) ++i;
+  const TileDesc &q = td->d[i];
+  tile_bases_body((const int32_t *)(arena + q.rules), (const int32_t *)(arena + bd->small) + q.counts, q.K, q.stride, q.out_col, q.n_gran,
+                  (int32_t *)(arena + q.bases), t - q.first);
 }
 
 static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
@@ -1288,15 +1385,17 @@ static int batch_layout(const scn_batch_plan *pl, scn_batch_layout *lo) {
       lo->sub_rules[l] = take((size_t)27 * N * 8);
       lo->sub_bases[l] = take((size_t)27 * (n_gran + 1) * 4);
       const size_t r = align256((size_t)27 * N * 4) + align256(scn_rules_temp_bytes(N, 27));
-      if (r > sc_rules) sc_rules = r;
+      if (occ) sc_rules += r;  // (every scale's neighbour table and block counts at once: one launch for all scales)
+      else if (r > sc_rules) sc_rules = r;
     }
     if (pl->strided[l]) {
       const int64_t n_gran_c = (pl->N[l + 1] + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE;
       lo->str_rules[l] = take((size_t)8 * N * 8);
       lo->str_bases_fine[l] = take((size_t)8 * (n_gran + 1) * 4);
       lo->str_bases_coarse[l] = take((size_t)8 * (n_gran_c + 1) * 4);
-      const size_t r = (occ ? align256((size_t)N * 4) : 0) + align256(scn_rules_temp_bytes(N, 8));  // (occ: + the coarse site of every site)
-      if (r > sc_rules) sc_rules = r;
+      const size_t r = align256(scn_rules_temp_bytes(N, 8));
+      if (occ) sc_rules += r;
+      else if (r > sc_rules) sc_rules = r;
     }
   }
   lo->scratch = (int64_t)off;
@@ -1383,7 +1482,7 @@ int scn_occ_bounds(const void *coords, int coords_dtype, int ncols, int64_t P, i
   SCN_REQUIRE(coords_dtype >= 0 && coords_dtype <= 2, "scn_occ_bounds: coords_dtype must be 0 (int32), 1 (int64) or 2 (float32)");
   SCN_REQUIRE(scratch_dev != nullptr && minmax_host != nullptr, "scn_occ_bounds: NULL argument");
   SCN_CHECK_HIP(hipMemsetAsync(scratch_dev, 0x80, 36, stream));
-  const int g = grid_for(P, 256, 2048);
+  const int g = grid_for(P, 256, 512);
   if (coords_dtype == 1) k_occ_bounds<1><<<g, 256, 0, stream>>>(coords, ncols, P, scratch_dev);
   else if (coords_dtype == 0) k_occ_bounds<0><<<g, 256, 0, stream>>>(coords, ncols, P, scratch_dev);
   else k_occ_bounds<2><<<g, 256, 0, stream>>>(coords, ncols, P, scratch_dev);
@@ -1423,9 +1522,9 @@ int scn_occ_plan(const int32_t *mm, int levels, scn_occ_box *box) {
   }
   box->woff[levels] = W;
   box->blocks = (W + 1023) / 1024;
-  box->off_info = 1024;
-  box->off_blk = 2048;
-  box->off_words = (int64_t)align256((size_t)2048 + (size_t)(box->blocks + 1) * 4);
+  box->off_info = OCC_HDR_BYTES;
+  box->off_blk = OCC_HDR_BYTES + 1024;
+  box->off_words = (int64_t)align256((size_t)box->off_blk + (size_t)(box->blocks + 1) * 4);
   box->bytes = box->off_words + box->blocks * 1024 * 8;
   return 0;
 }
@@ -1454,7 +1553,7 @@ int scn_occ_chain(const void *coords, int coords_dtype, int ncols, int64_t P, co
   int *info = (int *)(B + box->off_info), *blk = (int *)(B + box->off_blk);
   // (the counters and everything behind them: the block sums are written before they are read, but one memset is one launch)
   SCN_CHECK_HIP(hipMemsetAsync(B + box->off_info, 0, (size_t)(box->bytes - box->off_info), stream));
-  k_occ_header<<<1, 64, 0, stream>>>(occ_dev(box), (OccDev *)B);
+  k_put<OccDev><<<1, 64, 0, stream>>>(occ_dev(box), (OccDev *)B);
   SCN_CHECK_LAUNCH();
   const int nblk = (int)((P + 255) / 256);
   if (coords_dtype == 1) k_occ_set<1><<<nblk, 256, 0, stream>>>(coords, ncols, P, buf, words);
@@ -1495,22 +1594,65 @@ int scn_batch_build_occ(const void *coords, const scn_batch_plan *pl, const scn_
   const int L = pl->levels;
   const int64_t P = pl->P, N0 = pl->N[0];
   int32_t *small = (int32_t *)(A + lo.small);
-  // ---- sites of every scale
-  OccOut out;
-  for (int l = 0; l < SCN_BATCH_MAX_LEVELS; ++l) out.coords[l] = out.keys[l] = -1;
-  for (int l = 0; l < L; ++l) { out.coords[l] = lo.coords[l]; out.keys[l] = lo.keys[l]; }
-  k_occ_out<<<1, 64, 0, stream>>>(out, (OccOut *)(B + OCC_HDR_OUT));
-  SCN_CHECK_LAUNCH();
-  const int64_t W = box->woff[box->levels];
-  k_occ_sites<<<(int)((W + 255) / 256), 256, 0, stream>>>(buf, words, W, info, A);
-  SCN_CHECK_LAUNCH();
-  // ---- input layer: site_of_row, site_start, order
+  // ---- what the multi-scale launches read: sizes, block ranges, where everything lies
   char *S = A + lo.scratch;
   int32_t *slot = (int32_t *)S; S += align256((size_t)P * 4);
   int *cnt = (int *)S; S += align256((size_t)(N0 + 1) * 4);
   const int nb0 = (int)((N0 + 1 + 255) / 256);
   int *blk = (int *)S; S += align256((size_t)(nb0 + 1) * 4);
-  char *SR = S;
+  BatchDev bd;
+  TileDescs td;
+  memset(&bd, 0, sizeof(bd));
+  memset(&td, 0, sizeof(td));
+  bd.L = L;
+  bd.small = lo.small;
+  int64_t nblocks = 0, threads = 0;
+  bool any_sub = false, any_str = false;
+  auto tile = [&](int64_t rules, int64_t bases, int counts, int K, int64_t stride, int out_col, int64_t n_out) {
+    TileDesc &q = td.d[td.n++];
+    q.rules = rules; q.bases = bases; q.stride = stride; q.first = threads;
+    q.counts = counts; q.K = K; q.out_col = out_col;
+    q.n_gran = (int)((n_out + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+    threads += (int64_t)K * (q.n_gran + 1);
+  };
+  for (int l = 0; l < SCN_BATCH_MAX_LEVELS; ++l) bd.sub_counts[l] = bd.str_counts[l] = -1;
+  for (int l = 0; l < L; ++l) {
+    const int64_t N = pl->N[l];
+    const int64_t nblk = (N + 255) / 256;
+    bd.N[l] = (int32_t)N;
+    bd.blk0[l] = (int32_t)nblocks;
+    nblocks += nblk;
+    bd.coords[l] = lo.coords[l];
+    bd.keys[l] = lo.keys[l];
+    if (pl->sub[l]) {
+      any_sub = true;
+      bd.sub_counts[l] = 2 * L + 27 * l;
+      bd.sub_rules[l] = lo.sub_rules[l];
+      bd.nbr[l] = S - A; S += align256((size_t)27 * N * 4);
+      bd.sub_blk[l] = S - A; S += align256((size_t)27 * nblk * 4);
+      tile(lo.sub_rules[l], lo.sub_bases[l], bd.sub_counts[l], 27, N, 1, N);
+    }
+    if (pl->strided[l]) {
+      any_str = true;
+      bd.str_counts[l] = 2 * L + 27 * L + 8 * l;
+      bd.str_rules[l] = lo.str_rules[l];
+      bd.str_blk[l] = S - A; S += align256((size_t)8 * nblk * 4);
+      tile(lo.str_rules[l], lo.str_bases_coarse[l], bd.str_counts[l], 8, N, 1, pl->N[l + 1]);
+      tile(lo.str_rules[l], lo.str_bases_fine[l], bd.str_counts[l], 8, N, 0, N);
+    }
+  }
+  for (int l = L; l <= SCN_BATCH_MAX_LEVELS; ++l) bd.blk0[l] = (int32_t)nblocks;
+  td.threads = threads;
+  SCN_REQUIRE((size_t)(S - A) <= (size_t)lo.total && nblocks < (int64_t)1 << 31, "scn_batch_build_occ: scratch layout");
+  k_put<BatchDev><<<1, 64, 0, stream>>>(bd, (BatchDev *)(B + OCC_HDR_BATCH));
+  SCN_CHECK_LAUNCH();
+  k_put<TileDescs><<<1, 64, 0, stream>>>(td, (TileDescs *)(B + OCC_HDR_TILES));
+  SCN_CHECK_LAUNCH();
+  // ---- sites of every scale
+  const int64_t W = box->woff[box->levels];
+  k_occ_sites<<<(int)((W + 255) / 256), 256, 0, stream>>>(buf, words, W, info, A);
+  SCN_CHECK_LAUNCH();
+  // ---- input layer: site_of_row, site_start, order
   int32_t *site_of_row = (int32_t *)(A + lo.site_of_row), *site_start = (int32_t *)(A + lo.site_start), *order = (int32_t *)(A + lo.order);
   SCN_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)(N0 + 1) * 4, stream));
   const int nbp = (int)((P + 255) / 256);
@@ -1530,36 +1672,28 @@ int scn_batch_build_occ(const void *coords, const scn_batch_plan *pl, const scn_
   SCN_CHECK_LAUNCH();
   k_occ_small<<<1, 64, 0, stream>>>(info, L, small);
   SCN_CHECK_LAUNCH();
-  // ---- rulebooks
-  for (int l = 0; l < L; ++l) {
-    const int64_t N = pl->N[l];
-    const int4 *cl = (const int4 *)(A + lo.coords[l]);
-    if (pl->strided[l]) {
-      const int64_t Nc = pl->N[l + 1];
-      int32_t *cof = (int32_t *)SR;
-      void *rt = SR + align256((size_t)N * 4);
-      k_occ_coarse_of_fine<<<(int)((N + 255) / 256), 256, 0, stream>>>(cl, N, buf, words, info, l, cof);
-      SCN_CHECK_LAUNCH();
-      int32_t *rules = (int32_t *)(A + lo.str_rules[l]);
-      int32_t *counts = small + 2 * L + 27 * L + 8 * l;
-      if (int rc = scn_strided_rules((const int32_t *)cl, N, cof, rules, counts, rt, scn_rules_temp_bytes(N, 8), stream_)) return rc;
-      if (int rc = scn_tile_bases(rules, counts, 8, N, 1, Nc, (int32_t *)(A + lo.str_bases_coarse[l]), stream_)) return rc;
-      if (int rc = scn_tile_bases(rules, counts, 8, N, 0, N, (int32_t *)(A + lo.str_bases_fine[l]), stream_)) return rc;
-    }
-    if (pl->sub[l]) {
-      int32_t *nbr = (int32_t *)SR;
-      int *blk_cnt = (int *)(SR + align256((size_t)27 * N * 4));
-      int32_t *rules = (int32_t *)(A + lo.sub_rules[l]);
-      int32_t *counts = small + 2 * L + 27 * l;
-      const int nblk = (int)((N + 255) / 256);
-      k_sub_probe_occ<<<nblk, 256, 0, stream>>>(cl, N, buf, words, info, l, nbr, blk_cnt, nblk);
-      SCN_CHECK_LAUNCH();
-      k_excl_scan_rows<<<27, 1024, 0, stream>>>(blk_cnt, nblk, counts);
-      SCN_CHECK_LAUNCH();
-      k_rules_fill<27><<<nblk, 256, 0, stream>>>(nbr, N, blk_cnt, nblk, (int2 *)rules);
-      SCN_CHECK_LAUNCH();
-      if (int rc = scn_tile_bases(rules, counts, 27, N, 1, N, (int32_t *)(A + lo.sub_bases[l]), stream_)) return rc;
-    }
+  // ---- rulebooks of every scale: six launches
+  if (any_sub) {
+    k_sub_probe_occ<<<(int)nblocks, 256, 0, stream>>>(buf, words, info, A);
+    SCN_CHECK_LAUNCH();
+  }
+  if (any_str) {
+    k_str_count_ml<<<(int)nblocks, 256, 0, stream>>>(buf, A);
+    SCN_CHECK_LAUNCH();
+  }
+  k_scan_ml<<<L * 35, 1024, 0, stream>>>(buf, A);
+  SCN_CHECK_LAUNCH();
+  if (any_sub) {
+    k_rules_fill_ml<<<(int)nblocks, 256, 0, stream>>>(buf, A);
+    SCN_CHECK_LAUNCH();
+  }
+  if (any_str) {
+    k_str_fill_ml<<<(int)nblocks, 256, 0, stream>>>(buf, words, info, A);
+    SCN_CHECK_LAUNCH();
+  }
+  if (threads > 0) {
+    k_tile_bases_ml<<<(int)((threads + 255) / 256), 256, 0, stream>>>(buf, A);
+    SCN_CHECK_LAUNCH();
   }
   return 0;
 }

@@ -66,7 +66,7 @@ def test_occupancy_box_plan_is_host_arithmetic():
         assert list(box.n[l]) == n and box.wx[l] == (n[0] + 31) // 32 and box.woff[l] == W
         W += 3 * n[2] * n[1] * box.wx[l]
     assert box.woff[4] == W and box.blocks == (W + 1023) // 1024
-    assert box.off_info == 1024 and box.off_blk == 2048 and box.off_words % 256 == 0 and box.off_words >= 2048 + 4 * (box.blocks + 1)
+    assert box.off_info == 4096 and box.off_blk == 5120 and box.off_words % 256 == 0 and box.off_words >= box.off_blk + 4 * (box.blocks + 1)
     assert box.bytes == box.off_words + box.blocks * 1024 * 8
     big = (ctypes.c_int32 * 8)(0, 0, 0, 0, 1023, 2047, 1023, 7)
     assert lib.scn_occ_plan(big, 6, ctypes.byref(box)) == 0 and box.bytes == 0
