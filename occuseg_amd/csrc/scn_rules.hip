@@ -309,9 +309,11 @@ __global__ void __launch_bounds__(256)
 }
 
 // pass 2: order-preserving compaction of (in, out) pairs into rules[k]  (block `bi` of `nblk` over the N sites of one scale)
+// `bases` (may be NULL): the tile-base table of the OUTPUT column (scn_tile_bases), which this pass knows anyway -- the first pair of
+// list k with output site >= 32 g is the pair output site 32 g writes, or would write
 template <int K>
 __device__ __forceinline__ void rules_fill_body(const int32_t *__restrict__ nbr, int64_t N, const int *__restrict__ blk_base, int nblk,
-                                                int2 *__restrict__ rules, int bi) {
+                                                int2 *__restrict__ rules, int bi, int32_t *__restrict__ bases = nullptr) {
   __shared__ int wcnt[4][K];
   const int64_t o = (int64_t)bi * 256 + threadIdx.x;
   const bool valid = o < N;
@@ -327,12 +329,18 @@ __device__ __forceinline__ void rules_fill_body(const int32_t *__restrict__ nbr,
     if (lane == 0) wcnt[w][k] = __popcll(m);
   }
   __syncthreads();
+  const bool edge = bases != nullptr && valid && ((o & (SCN_TILE_GRANULE - 1)) == 0 || o == N - 1);
+  const int n_gran = (int)((N + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (in_k[k] >= 0) {
+    if (in_k[k] >= 0 || edge) {
       int base = blk_base[(int64_t)k * nblk + bi];
       for (int j = 0; j < w; ++j) base += wcnt[j][k];
-      rules[(int64_t)k * N + base + rk[k]] = make_int2(in_k[k], (int)o);
+      if (in_k[k] >= 0) rules[(int64_t)k * N + base + rk[k]] = make_int2(in_k[k], (int)o);
+      if (edge) {
+        if ((o & (SCN_TILE_GRANULE - 1)) == 0) bases[(int64_t)k * (n_gran + 1) + o / SCN_TILE_GRANULE] = base + rk[k];
+        if (o == N - 1) bases[(int64_t)k * (n_gran + 1) + n_gran] = base + rk[k] + (in_k[k] >= 0 ? 1 : 0);
+      }
     }
   }
 }
@@ -370,9 +378,10 @@ __global__ void __launch_bounds__(256)
 }
 
 // `coarse(f, c)` = the coarse site of fine site f at coordinates c
+// `bases_fine` (may be NULL): the tile-base table of column 0 (the fine site, ascending in every list)
 template <typename Coarse>
 __device__ __forceinline__ void str_fill_body(const int4 *__restrict__ coords, int64_t N, Coarse coarse_of, const int *__restrict__ blk_base,
-                                              int nblk, int2 *__restrict__ rules, int bi) {
+                                              int nblk, int2 *__restrict__ rules, int bi, int32_t *__restrict__ bases_fine = nullptr) {
   __shared__ int wcnt[4][8];
   const int64_t f = (int64_t)bi * 256 + threadIdx.x;
   const int lane = lane_id(), w = threadIdx.x >> 6;
@@ -384,10 +393,12 @@ __device__ __forceinline__ void str_fill_body(const int4 *__restrict__ coords, i
     coarse = coarse_of(f, c);
   }
   int my_rank = 0;
+  int rk[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const unsigned long long m = __ballot(koff == k);
-    if (koff == k) my_rank = __popcll(m & lt);
+    rk[k] = __popcll(m & lt);
+    if (koff == k) my_rank = rk[k];
     if (lane == 0) wcnt[w][k] = __popcll(m);
   }
   __syncthreads();
@@ -395,6 +406,16 @@ __device__ __forceinline__ void str_fill_body(const int4 *__restrict__ coords, i
     int base = blk_base[(int64_t)koff * nblk + bi];
     for (int j = 0; j < w; ++j) base += wcnt[j][koff];
     rules[(int64_t)koff * N + base + my_rank] = make_int2((int)f, coarse);
+  }
+  if (bases_fine != nullptr && f < N && ((f & (SCN_TILE_GRANULE - 1)) == 0 || f == N - 1)) {
+    const int n_gran = (int)((N + SCN_TILE_GRANULE - 1) / SCN_TILE_GRANULE);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int base = blk_base[(int64_t)k * nblk + bi];
+      for (int j = 0; j < w; ++j) base += wcnt[j][k];
+      if ((f & (SCN_TILE_GRANULE - 1)) == 0) bases_fine[(int64_t)k * (n_gran + 1) + f / SCN_TILE_GRANULE] = base + rk[k];
+      if (f == N - 1) bases_fine[(int64_t)k * (n_gran + 1) + n_gran] = base + rk[k] + (koff == k ? 1 : 0);
+    }
   }
 }
 __global__ void __launch_bounds__(256)
@@ -612,6 +633,7 @@ struct BatchDev {
   int32_t sub_counts[SCN_BATCH_MAX_LEVELS], str_counts[SCN_BATCH_MAX_LEVELS];  // list lengths: index into `small` (-1: not built)
   int64_t coords[SCN_BATCH_MAX_LEVELS], keys[SCN_BATCH_MAX_LEVELS], sub_rules[SCN_BATCH_MAX_LEVELS], str_rules[SCN_BATCH_MAX_LEVELS];
   int64_t nbr[SCN_BATCH_MAX_LEVELS], sub_blk[SCN_BATCH_MAX_LEVELS], str_blk[SCN_BATCH_MAX_LEVELS];  // (scratch)
+  int64_t sub_bases[SCN_BATCH_MAX_LEVELS], str_bases_fine[SCN_BATCH_MAX_LEVELS];  // tile-base tables the fill launches write themselves
   int64_t small;
 };
 struct TileDesc {
@@ -623,7 +645,7 @@ struct TileDescs {
   int64_t threads;
   TileDesc d[3 * SCN_BATCH_MAX_LEVELS];
 };
-constexpr int OCC_HDR_BATCH = 512, OCC_HDR_TILES = 1536, OCC_HDR_BYTES = 4096;
+constexpr int OCC_HDR_BATCH = 512, OCC_HDR_TILES = 2048, OCC_HDR_BYTES = 4096;
 constexpr int OCC_INFO_START = 0;     // info[0 .. levels]: occupied voxels in front of every scale's first word ([levels] = all)
 constexpr int OCC_INFO_OVERFLOW = 32;  // info[32]: != 0 = a voxel with more than SCN_OCC_SEGMENT_MAX input rows
 static_assert(sizeof(OccDev) <= OCC_HDR_BATCH && OCC_HDR_BATCH + sizeof(BatchDev) <= OCC_HDR_TILES &&
@@ -689,34 +711,54 @@ __device__ __forceinline__ int64_t occ_word_index(const OccDev *__restrict__ d, 
   return d->woff[l] + (((int64_t)rb * d->nz[l] + rz) * d->ny[l] + ry) * d->wx[l] + (rx >> 5);
 }
 
-// Bits of every scale: row p sets its bit at scale 0, 1, ... and stops at the first scale where the bit was set already (whoever
-// set it goes on): P + N_0 + N_1 + ... atomics in all.
+// Bits of scale 0: one atomic OR per input row, nothing returned (fire and forget).  [Round 6, first form: every row walked the
+// scales with RETURNING atomics and stopped where its bit was taken -- 130 us for 1.1 M rows, 260 with a look before the atomic.]
 template <int DT>
 __global__ void __launch_bounds__(256) k_occ_set(const void *coords_, int ncols, int64_t P, const uint64_t *__restrict__ buf, uint64_t *words) {
   const OccDev *__restrict__ d = (const OccDev *)buf;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  bool live = p < P;
-  int rx = 0, ry = 0, rz = 0, rb = 0;
-  if (live) {
-    int64_t x, y, z, b;
-    read_coords<DT>(coords_, p, ncols, x, y, z, b);
-    rx = (int)x - d->ox; ry = (int)y - d->oy; rz = (int)z - d->oz; rb = (int)b - d->ob;
-    // (scn_occ_bounds has seen every row: inside the box.  Anything else -- a coords tensor changed in between -- is dropped.)
-    live = rx >= 0 && rx < d->nx[0] && ry >= 0 && ry < d->ny[0] && rz >= 0 && rz < d->nz[0] && rb >= 0 && rb < d->nb;
-  }
+  if (p >= P) return;
+  int64_t x, y, z, b;
+  read_coords<DT>(coords_, p, ncols, x, y, z, b);
+  const int rx = (int)x - d->ox, ry = (int)y - d->oy, rz = (int)z - d->oz, rb = (int)b - d->ob;
+  // (scn_occ_bounds has seen every row: inside the box.  Anything else -- a coords tensor changed in between -- is dropped.)
+  if (rx < 0 || rx >= d->nx[0] || ry < 0 || ry >= d->ny[0] || rz < 0 || rz >= d->nz[0] || rb < 0 || rb >= d->nb) return;
   uint32_t *w32 = (uint32_t *)words;
-  const int levels = d->levels;
-  for (int l = 0; l < levels; ++l) {
-    if (live) {
-      const int64_t w = occ_word_index(d, l, rx >> l, ry >> l, rz >> l, rb);
-      const uint32_t bit = 1u << ((rx >> l) & 31);
-      // (little endian: the low half of word w.  A plain look first: bits are only ever set, so a set bit seen here is set -- most
-      //  rows find their coarse voxels taken -- and a stale "not set" only costs the atomic)
-      if (w32[2 * w] & bit) live = false;
-      else if (atomicOr(w32 + 2 * w, bit) & bit) live = false;
+  atomicOr(w32 + 2 * occ_word_index(d, 0, rx, ry, rz, rb), 1u << (rx & 31));  // (little endian: the low half of the word)
+}
+
+// Bits of scale l + 1 from scale l: a coarse voxel is occupied when one of its 2 x 2 x 2 voxels is.  One thread per coarse word = 32
+// coarse voxels of an x row = two words of each of four rows of scale l: OR them, OR neighbouring bits, keep the even ones.
+__global__ void __launch_bounds__(256) k_occ_coarsen(const uint64_t *__restrict__ buf, uint64_t *__restrict__ words, int l) {
+  const OccDev *__restrict__ d = (const OccDev *)buf;
+  const int l1 = l + 1;
+  const int wxc = d->wx[l1], nyc = d->ny[l1], nzc = d->nz[l1], wxf = d->wx[l], nyf = d->ny[l], nzf = d->nz[l];
+  const int64_t Wc = d->woff[l1 + 1] - d->woff[l1];
+  const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (wi >= Wc) return;
+  const int xw = (int)(wi % wxc);
+  const int64_t row = wi / wxc;
+  const int yc = (int)(row % nyc), zc = (int)((row / nyc) % nzc), rb = (int)(row / ((int64_t)nyc * nzc));
+  const uint64_t *__restrict__ fw = words + d->woff[l];
+  uint64_t f = 0;
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int yf = 2 * yc + dy, zf = 2 * zc + dz;
+      if (yf < nyf && zf < nzf) {
+        const uint64_t *r = fw + (((int64_t)rb * nzf + zf) * nyf + yf) * wxf;
+        f |= (uint64_t)(uint32_t)r[2 * xw];
+        if (2 * xw + 1 < wxf) f |= (uint64_t)(uint32_t)r[2 * xw + 1] << 32;
+      }
     }
-    if (__ballot(live) == 0) break;  // (wave-uniform)
-  }
+  uint64_t t = (f | (f >> 1)) & 0x5555555555555555ull;
+  t = (t | (t >> 1)) & 0x3333333333333333ull;
+  t = (t | (t >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  t = (t | (t >> 4)) & 0x00FF00FF00FF00FFull;
+  t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
+  t = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
+  if (t) words[d->woff[l1] + wi] = t;  // (the buffer was cleared)
 }
 
 // population counts of 1024-word blocks (thread t: words 4 t .. 4 t + 3)
@@ -983,7 +1025,7 @@ __global__ void __launch_bounds__(256) k_rules_fill_ml(const uint64_t *__restric
   const int l = ml_level(bd, (int)blockIdx.x);
   if (bd->sub_counts[l] < 0) return;
   rules_fill_body<27>((const int32_t *)(arena + bd->nbr[l]), bd->N[l], (const int *)(arena + bd->sub_blk[l]), bd->blk0[l + 1] - bd->blk0[l],
-                      (int2 *)(arena + bd->sub_rules[l]), (int)blockIdx.x - bd->blk0[l]);
+                      (int2 *)(arena + bd->sub_rules[l]), (int)blockIdx.x - bd->blk0[l], (int32_t *)(arena + bd->sub_bases[l]));
 }
 __global__ void __launch_bounds__(256) k_str_fill_ml(const uint64_t *__restrict__ buf, const uint64_t *__restrict__ words,
                                                      const int *__restrict__ info, char *__restrict__ arena) {
@@ -997,7 +1039,7 @@ __global__ void __launch_bounds__(256) k_str_fill_ml(const uint64_t *__restrict_
     return occ_rank(d, words, info, l1, (c.x >> 1) - (d->ox >> l1), (c.y >> 1) - (d->oy >> l1), (c.z >> 1) - (d->oz >> l1), c.w - d->ob);
   };
   str_fill_body((const int4 *)(arena + bd->coords[l]), bd->N[l], coarse, (const int *)(arena + bd->str_blk[l]), bd->blk0[l + 1] - bd->blk0[l],
-                (int2 *)(arena + bd->str_rules[l]), (int)blockIdx.x - bd->blk0[l]);
+                (int2 *)(arena + bd->str_rules[l]), (int)blockIdx.x - bd->blk0[l], (int32_t *)(arena + bd->str_bases_fine[l]));
 }
 __global__ void __launch_bounds__(256) k_tile_bases_ml(const uint64_t *__restrict__ buf, char *__restrict__ arena) {
   const BatchDev *__restrict__ bd = (const BatchDev *)((const char *)buf + OCC_HDR_BATCH);
@@ -1560,6 +1602,11 @@ int scn_occ_chain(const void *coords, int coords_dtype, int ncols, int64_t P, co
   else if (coords_dtype == 0) k_occ_set<0><<<nblk, 256, 0, stream>>>(coords, ncols, P, buf, words);
   else k_occ_set<2><<<nblk, 256, 0, stream>>>(coords, ncols, P, buf, words);
   SCN_CHECK_LAUNCH();
+  for (int l = 0; l + 1 < box->levels; ++l) {
+    const int64_t Wc = box->woff[l + 2] - box->woff[l + 1];
+    k_occ_coarsen<<<(int)((Wc + 255) / 256), 256, 0, stream>>>(buf, words, l);
+    SCN_CHECK_LAUNCH();
+  }
   k_occ_count<<<(int)box->blocks, 256, 0, stream>>>(words, blk);
   SCN_CHECK_LAUNCH();
   k_excl_scan_rows<<<1, 1024, 0, stream>>>(blk, (int)box->blocks, info + OCC_INFO_START + box->levels);
@@ -1630,15 +1677,15 @@ int scn_batch_build_occ(const void *coords, const scn_batch_plan *pl, const scn_
       bd.sub_rules[l] = lo.sub_rules[l];
       bd.nbr[l] = S - A; S += align256((size_t)27 * N * 4);
       bd.sub_blk[l] = S - A; S += align256((size_t)27 * nblk * 4);
-      tile(lo.sub_rules[l], lo.sub_bases[l], bd.sub_counts[l], 27, N, 1, N);
+      bd.sub_bases[l] = lo.sub_bases[l];  // (written by the fill launch)
     }
     if (pl->strided[l]) {
       any_str = true;
       bd.str_counts[l] = 2 * L + 27 * L + 8 * l;
       bd.str_rules[l] = lo.str_rules[l];
       bd.str_blk[l] = S - A; S += align256((size_t)8 * nblk * 4);
+      bd.str_bases_fine[l] = lo.str_bases_fine[l];  // (written by the fill launch; the coarse column's needs the search)
       tile(lo.str_rules[l], lo.str_bases_coarse[l], bd.str_counts[l], 8, N, 1, pl->N[l + 1]);
-      tile(lo.str_rules[l], lo.str_bases_fine[l], bd.str_counts[l], 8, N, 0, N);
     }
   }
   for (int l = L; l <= SCN_BATCH_MAX_LEVELS; ++l) bd.blk0[l] = (int32_t)nblocks;
@@ -1672,7 +1719,7 @@ int scn_batch_build_occ(const void *coords, const scn_batch_plan *pl, const scn_
   SCN_CHECK_LAUNCH();
   k_occ_small<<<1, 64, 0, stream>>>(info, L, small);
   SCN_CHECK_LAUNCH();
-  // ---- rulebooks of every scale: six launches
+  // ---- rulebooks of every scale: six launches (the fills write the tile-base tables of their sorted column themselves)
   if (any_sub) {
     k_sub_probe_occ<<<(int)nblocks, 256, 0, stream>>>(buf, words, info, A);
     SCN_CHECK_LAUNCH();
