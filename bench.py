@@ -297,6 +297,15 @@ def other_configs(scn, dev, which=("cfg2", "cfg5a", "cfg5b")):
         rb = md.getSubmanifoldRuleBook(size, f3)
         n = md.getNActive(size)
         R = rb.total_pairs
+        # ... and the whole batch as an InputLayer call builds it from its second batch on (the plan the call above recorded: this
+        # scale's grid + its rulebook; bounds, occupancy bitmaps, sites, neighbours, lists, tile bases and both read-backs)
+        cdev = torch.from_numpy(c).to(dev)
+        plan = list(SCN._PLANS[(4096,) * 3])
+
+        def batch_build():
+            SCN._PLANS[(4096,) * 3] = list(plan)  # (what a forward pass would have recorded again)
+            SCN.Metadata_3().inputLayer(size, cdev, 0, 4, dev)
+        t_batch = _timeit(batch_build, 3, 1)
         x = torch.randn(n, 128, device=dev)
         w = torch.randn(27, 128, 128, device=dev) * 0.02
         dy = torch.randn(n, 128, device=dev)
@@ -310,7 +319,7 @@ def other_configs(scn, dev, which=("cfg2", "cfg5a", "cfg5b")):
         flops = 2.0 * R * 128 * 128
         fb = 4.0 * (R * 128 + n * 128) + 8.0 * R + 4.0 * 27 * 128 * 128
         wb = 4.0 * R * 256 + 8.0 * R + 4.0 * 27 * 128 * 128
-        res[name] = {"active_voxels": n, "nu": R / n, "rulebook_build_ms": t_rules,
+        res[name] = {"active_voxels": n, "nu": R / n, "rulebook_build_ms": t_rules, "grid_and_rulebook_batch_build_ms": t_batch,
                      "fwd_ms": t_f, "fwd_TFLOPs": flops / t_f / 1e9, "fwd_mfma_frac": flops / t_f / 1e9 / F32_MFMA_PEAK_TFLOPS,
                      "fwd_algo_GBs": fb / t_f / 1e6,
                      "dinput_ms": t_di, "dinput_TFLOPs": flops / t_di / 1e9,

@@ -530,13 +530,13 @@ class Metadata_3(object):
             if req[0] != "sub" and req[1] == sizes[-1] and req[3] == (2, 2, 2) and req[4] == (2, 2, 2):
                 sizes.append(req[2])
         self._occ = None
-        if len(sizes) < 2 or len(sizes) > _GRID_CHAIN_MAX:
+        if not old_plan or len(sizes) > _GRID_CHAIN_MAX:
             return None, sizes
         lib = _lib_()
         P = c.size(0)
         if P <= 0 or P >= (1 << 30):  # (scn_grid_chain_counts takes fewer points than scn_grid_build: per-scale read-backs then)
             return None, sizes
-        if occ:
+        if occ:  # (also for a plan of ONE scale -- a network without strided convolutions --, which the hash-set chain leaves alone)
             mm = (ctypes.c_int32 * 8)()
             scratch = torch.empty(16, dtype=torch.int32, device=c.device)
             check(lib.scn_occ_bounds(ptr(c), _COORD_DTYPES[c.dtype], c.size(1), P, ptr(scratch), mm, stream()))
@@ -555,7 +555,7 @@ class Metadata_3(object):
                     return self._chain_counts
                 return fetch_occ, sizes
             OCC_STATS["too_large"] += 1
-        if not hashed:
+        if not hashed or len(sizes) < 2:
             return None, sizes
         tb = lib.scn_grid_chain_temp_bytes(P, len(sizes))
         if tb == 0:

@@ -276,14 +276,15 @@ def _same_walk(a, b):
                 assert u == v
 
 
-@pytest.mark.parametrize("case", ["word_edges", "odd_origin_three_samples", "ncols3_float", "long_segment", "sparse_far_apart"])
+@pytest.mark.parametrize("case", ["word_edges", "odd_origin_three_samples", "ncols3_float", "long_segment", "sparse_far_apart",
+                                  "single_scale"])
 def test_occupancy_build_against_the_sort_build(gpu, monkeypatch, case):
     """scn_batch_build_occ (round 6: ranks from population counts over bitmaps of the bounding box) against the per-scale sort +
     hash build that test_rulebooks_bit_exact holds against the oracle: every grid, rulebook, tile-base table and the input
     layer's order / site_of_row / site_start, bit for bit -- on clouds made to hit what the bitmaps could get wrong: sites at
     both ends of the 32-voxel words, a box whose origin is not aligned to the coarsest scale, sample indices that do not start at
     0, three-column and float coordinates, a voxel with more rows than the segment sort takes (the host's repair), and a cloud
-    whose box is mostly empty."""
+    whose box is mostly empty; a plan of one scale (a network without strided convolutions)."""
     from occuseg_amd import SCN
     rng = np.random.default_rng(11)
     levels, dtype, ncols = 4, torch.int64, 4
@@ -301,11 +302,14 @@ def test_occupancy_build_against_the_sort_build(gpu, monkeypatch, case):
         c = np.concatenate([rng.integers(0, 40, size=(8000, 3)) + 3, rng.integers(0, 2, size=(8000, 1))], 1)
         c[rng.permutation(8000)[:300]] = np.array([17, 9, 30, 1])     # 300 rows in one voxel (> SCN_OCC_SEGMENT_MAX = 64)
         c[rng.permutation(8000)[:64]] = np.array([5, 5, 5, 0])        # <= 64: sorted on the device
+    elif case == "single_scale":
+        c = np.concatenate([rng.integers(0, 70, size=(40000, 3)) + 11, rng.integers(0, 3, size=(40000, 1))], 1)
+        levels = 1
     else:
         c = np.concatenate([rng.integers(0, 1000, size=(3000, 3)), rng.integers(0, 2, size=(3000, 1))], 1)
     coords = torch.from_numpy(np.ascontiguousarray(c)).to(dtype)
     size = torch.tensor([4096 + 16 * (1 + ["word_edges", "odd_origin_three_samples", "ncols3_float", "long_segment",
-                                            "sparse_far_apart"].index(case))] * 3, dtype=torch.int64)
+                                            "sparse_far_apart", "single_scale"].index(case))] * 3, dtype=torch.int64)
     monkeypatch.setattr(SCN, "GRID_CHAIN", False)
 
     def run(occ):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 evidence: ONE run on one box with the final sources -- rocprofv3 statistics of the bench command, the two PMC traffic
 # passes (profiles/r06_traffic.json), clock + MFMA-pipe occupancy inside the step, the bench lines (the default one carries
-# parity_fullsize, configs, h2d, cpu_baseline), the assembly loop's A/B and ablations, determinism, scratch.
+# parity_fullsize, configs, h2d, cpu_baseline), the assembly loop's A/B and ablations, determinism, scratch, the rule build (sort + hash against occupancy bitmaps: alone, beside a step, by kernel, in the serving loop).
 set -u
 E=gpurun_out/evidence_r6
 mkdir -p $E
@@ -22,7 +22,13 @@ python3 tools/bench_conv.py --levels 0,1,2 --variants 4 --asm 0,1,2,3,4,5,6,9 > 
 python3 tools/ab_step.py tune28=0,1 > $E/ab_asm_loop_step.txt 2>&1
 python3 tools/determinism_full.py > $E/determinism.txt 2>&1
 python3 tools/check_scratch.py > $E/check_scratch.txt 2>&1
-for c in 1 0; do SCN_BATCH_BUILD=$c python3 tools/rules_alone.py 20; done > $E/rules_alone.txt 2>&1
+for o in 0 1 0 1; do SCN_OCC_BUILD=$o python3 tools/rules_alone.py 20 2>&1 | grep "rule build"; done > $E/rules_alone.txt 2>&1
+for o in 0 1 0 1; do echo "SCN_OCC_BUILD=$o"; SCN_OCC_BUILD=$o python3 tools/rules_cost_in_step.py 2>/dev/null | head -3; done > $E/rules_cost_in_step.txt 2>&1
+SCN_OCC_BUILD=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $E/rules_occ -- python3 tools/rules_alone.py 10 > /dev/null 2> $E/rules_occ.err
+cp $(find $E/rules_occ -name "*kernel_stats.csv" | head -1) $E/rules_occ_kernel_stats.csv
+SCN_OCC_BUILD=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $E/rules_sort -- python3 tools/rules_alone.py 10 > /dev/null 2> $E/rules_sort.err
+cp $(find $E/rules_sort -name "*kernel_stats.csv" | head -1) $E/rules_sort_kernel_stats.csv
+for o in 0 1; do echo "SCN_OCC_BUILD=$o"; CFG2_PREFETCH=1 SCN_OCC_BUILD=$o python3 tools/cfg2_iters.py 2>/dev/null | tail -6; done > $E/cfg2_serving_loop.txt 2>&1
 find $E -name "*.db" -delete
 find $E -name "*kernel_trace.csv" -delete
 find $E -name "*counter_collection.csv" -delete
