@@ -705,6 +705,7 @@ def main():
             SCN._PREFETCHED.clear()  # really build: do not adopt what the last step prefetched
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             alone = []
+            built0 = SCN.OCC_STATS["built"]
             plan_key = (4096, 4096, 4096)
             plan = list(SCN._PLANS_USED.get(plan_key, []))  # the rulebook requests of one forward pass of this network
             chain, SCN.GRID_CHAIN = SCN.GRID_CHAIN, False  # (as prefetch_input builds it in training: a read-back per scale)
@@ -722,8 +723,11 @@ def main():
             kernels["rules"]["alone_rulebooks_built"] = len(plan)
             kernels["rules"]["alone_algo_GBs"] = kernels["rules"]["algo_bytes_per_step"] / min(alone) / 1e6
             kernels["rules"]["alone_hbm_frac"] = kernels["rules"]["alone_algo_GBs"] / HBM_PEAK_GBS
-            kernels["rules"]["note"] = ("ms_per_step: on the side stream, overlapped with and slowed by the step's "
-                                        "kernels; alone_*: the same build on an idle GPU, incl. its ~7 host syncs")
+            kernels["rules"]["alone_path"] = "occupancy bitmaps" if SCN.OCC_STATS["built"] > built0 else "sort + hash"
+            kernels["rules"]["note"] = ("ms_per_step / algo_bytes: the per-scale sort + hash build of the PROFILED extra step (events "
+                                        "around every piece keep it off the one-call batch build), on the side stream, overlapped with "
+                                        "and slowed by the step's kernels; alone_*: the batch's grids and rulebooks as an InputLayer call "
+                                        "builds them from the second batch on (alone_path), on an idle GPU, incl. its two read-backs")
         mm = [k for k in agg if k.startswith(("conv_", "dw_"))]
         dom = max(mm, key=lambda k: agg[k][3]) if mm else None
         traffic = counted.get(dom or "")
