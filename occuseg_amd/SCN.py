@@ -134,6 +134,7 @@ BATCH_BUILD = os.environ.get("SCN_BATCH_BUILD", "1") != "0"
 _OB = os.environ.get("SCN_OCC_BUILD", "auto")
 OCC_BUILD = True if _OB == "1" else False if _OB == "0" else "auto"
 OCC_WORDS_PER_ROW = 64
+OCC_FIRST_BATCH = os.environ.get("SCN_OCC_FIRST_BATCH", "1") != "0"  # see Metadata_3.inputLayer ("speculative")
 OCC_STATS = {"built": 0, "too_large": 0, "order_repaired": 0}  # since import (tests, tools)
 DEFER_PREFETCH_READBACK = os.environ.get("SCN_DEFER_PREFETCH_READBACK", "1") != "0"
 _PINNED = []  # pinned host buffers of the deferred read-backs (allocating one costs a millisecond: kept and re-used)
@@ -445,12 +446,29 @@ class Metadata_3(object):
         c = coords.to(device, non_blocking=True).contiguous()
         P = c.size(0)
         old_plan = _PLANS.get(key, [])
+        batchable = (BATCH_BUILD and normals is None and not KEEP_NBR and not (PROFILE is not None and "rules" in PROFILE_KINDS))
+        speculative = False
+        if not old_plan and PREBUILD and OCC_BUILD and OCC_FIRST_BATCH and batchable:
+            # the FIRST batch on this input size: no forward pass has said yet which rulebooks it wants.  From bitmaps every grid and
+            # rulebook a UNet could ask for (3x3x3 at every scale, 2/2 between scales, while the size halves) costs a fraction of
+            # building the ones it does ask for by sort + hash, one at a time; what the ops then do not ask for is dropped with
+            # this batch (the plan of the next one is what they DID ask for).  A box too large for that falls through to the old way.
+            old_plan, sz = [], key
+            while len(old_plan) < 2 * _lib.BATCH_MAX_LEVELS - 1:
+                old_plan.append(("sub", sz, (3, 3, 3)))
+                if any(v % 2 or v < 4 for v in sz) or len(old_plan) >= 2 * _lib.BATCH_MAX_LEVELS - 1:
+                    break
+                nxt = tuple(v // 2 for v in sz)
+                old_plan.append(("conv", sz, nxt, (2, 2, 2), (2, 2, 2)))
+                sz = nxt
+            speculative = True
         # auto: inside a forward pass, and in a prefetch issued under torch.no_grad() (a serving loop: the same host thread
         # issues the forward pass, nothing hides a read-back); not in a prefetch beside a backward pass
         chain = GRID_CHAIN if GRID_CHAIN != "auto" else (not in_prefetch or not torch.is_grad_enabled())
-        batchable = (BATCH_BUILD and normals is None and not KEEP_NBR and not (PROFILE is not None and "rules" in PROFILE_KINDS))
         fetch, sizes = self._chain(c, key, old_plan if PREBUILD and (chain or (OCC_BUILD and batchable)) else [],
-                                   occ=OCC_BUILD if batchable else False, hashed=chain)
+                                   occ=OCC_BUILD if batchable else False, hashed=chain and not speculative)
+        if speculative and fetch is None:
+            old_plan = []  # (nothing was built ahead: the ops build what they ask for)
         self.input_mode = int(mode)
         self.input_P = P
         batch_small = None

@@ -23,12 +23,27 @@ def _cases():
     yield "scene-2x8k", c
 
 
+@pytest.mark.parametrize("path", ["sort_hash", "bitmaps"])
 @pytest.mark.parametrize("name,coords", list(_cases()), ids=[n for n, _ in _cases()])
-def test_rulebooks_bit_exact(gpu, name, coords, monkeypatch):
+def test_rulebooks_bit_exact(gpu, name, coords, monkeypatch, path):
+    """every grid, the input rules and the rulebooks of four scales against the oracle -- built one at a time by sort + hash as
+    the ops ask (with the probe table kept), and from occupancy bitmaps (round 6: the first batch on an input size builds
+    everything a UNet could ask for ahead, scn_batch_build_occ)"""
     from occuseg_amd import SCN
     from oracle import rules as R
-    monkeypatch.setattr(SCN, "KEEP_NBR", True)  # the probe table is dropped after the build unless a test asks
+    if path == "sort_hash":
+        monkeypatch.setattr(SCN, "KEEP_NBR", True)  # the probe table is dropped after the build unless a test asks
+    else:
+        monkeypatch.setattr(SCN, "OCC_BUILD", True)
+        SCN._PLANS.clear()
+    before = dict(SCN.OCC_STATS)
     m, size = build_metadata(coords, gpu)
+    if path == "sort_hash":
+        assert SCN.OCC_STATS == before
+    elif name == "edges+dups":  # sites in the corners of the key box, two samples: beyond SCN_OCC_MAX_WORDS, left to the sort
+        assert SCN.OCC_STATS["too_large"] == before["too_large"] + 1 and SCN.OCC_STATS["built"] == before["built"]
+    else:
+        assert SCN.OCC_STATS["built"] == before["built"] + 1
     grid, header, table, site_of_point = R.input_layer_rules(coords)
     # site order and coordinates
     loc = m.getSpatialLocations(size).numpy()
@@ -47,7 +62,11 @@ def test_rulebooks_bit_exact(gpu, name, coords, monkeypatch):
         got = rb.host_lists()
         for k in range(27):
             assert np.array_equal(got[k], want[k]), (name, level, k)
-        assert np.array_equal(rb.nbr.cpu().numpy().T, nbr)
+        if path == "sort_hash":
+            assert np.array_equal(rb.nbr.cpu().numpy().T, nbr)
+        bases = rb.bases[1].cpu().numpy()
+        for k in range(27):
+            assert np.array_equal(bases[k], np.searchsorted(want[k][:, 1], np.arange(bases.shape[1]) * 32, side="left"))
         if int(size[0]) % 2 or grid.n == 0:
             break
         out_size = size // 2
@@ -277,12 +296,12 @@ def _same_walk(a, b):
 
 
 @pytest.mark.parametrize("case", ["word_edges", "odd_origin_three_samples", "ncols3_float", "long_segment", "sparse_far_apart",
-                                  "single_scale"])
+                                  "single_scale", "key_box_corners"])
 def test_occupancy_build_against_the_sort_build(gpu, monkeypatch, case):
     """scn_batch_build_occ (round 6: ranks from population counts over bitmaps of the bounding box) against the per-scale sort +
     hash build that test_rulebooks_bit_exact holds against the oracle: every grid, rulebook, tile-base table and the input
     layer's order / site_of_row / site_start, bit for bit -- on clouds made to hit what the bitmaps could get wrong: sites at
-    both ends of the 32-voxel words, a box whose origin is not aligned to the coarsest scale, sample indices that do not start at
+    both ends of the 32-voxel words, sites in the corners of the key box (neighbours beyond its faces), a box whose origin is not aligned to the coarsest scale, sample indices that do not start at
     0, three-column and float coordinates, a voxel with more rows than the segment sort takes (the host's repair), and a cloud
     whose box is mostly empty; a plan of one scale (a network without strided convolutions)."""
     from occuseg_amd import SCN
@@ -305,11 +324,14 @@ def test_occupancy_build_against_the_sort_build(gpu, monkeypatch, case):
     elif case == "single_scale":
         c = np.concatenate([rng.integers(0, 70, size=(40000, 3)) + 11, rng.integers(0, 3, size=(40000, 1))], 1)
         levels = 1
+    elif case == "key_box_corners":  # the whole key box as the bounding box (one sample: 77 M words), neighbours beyond its faces
+        c = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [1023, 2047, 1023, 0], [1022, 2047, 1023, 0],
+                      [1023, 2046, 1022, 0], [1022, 2046, 1022, 0], [5, 5, 5, 0], [5, 5, 5, 0], [31, 5, 5, 0], [32, 5, 5, 0]], np.int64)
     else:
         c = np.concatenate([rng.integers(0, 1000, size=(3000, 3)), rng.integers(0, 2, size=(3000, 1))], 1)
     coords = torch.from_numpy(np.ascontiguousarray(c)).to(dtype)
     size = torch.tensor([4096 + 16 * (1 + ["word_edges", "odd_origin_three_samples", "ncols3_float", "long_segment",
-                                            "sparse_far_apart", "single_scale"].index(case))] * 3, dtype=torch.int64)
+                                            "sparse_far_apart", "single_scale", "key_box_corners"].index(case))] * 3, dtype=torch.int64)
     monkeypatch.setattr(SCN, "GRID_CHAIN", False)
 
     def run(occ):
@@ -332,7 +354,7 @@ def test_occupancy_build_against_the_sort_build(gpu, monkeypatch, case):
     assert g0.hash_keys is None and m._hash(g0).hash_keys is not None
     auto, _ = run("auto")
     _same_walk(ref, auto)
-    if case == "sparse_far_apart":  # 3,000 points in a 1000^3 box: "auto" leaves it to the sort
+    if case in ("sparse_far_apart", "key_box_corners"):  # 3,000 points in a 1000^3 box (12 in the key box): "auto" leaves it to the sort
         assert SCN.OCC_STATS["too_large"] == before["too_large"] + 1 and SCN.OCC_STATS["built"] == before["built"] + 1
     else:
         assert SCN.OCC_STATS["built"] == before["built"] + 2

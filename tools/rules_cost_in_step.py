@@ -82,6 +82,7 @@ def load_part(part, coords):
     with torch.cuda.stream(side):
         plans = dict(SCN._PLANS)
         SCN._PLANS.clear()  # (no replay: build exactly what is asked below)
+        SCN.OCC_FIRST_BATCH = False  # (... piece by piece, by sort + hash)
         md = SCN.Metadata_3()
         md.inputLayer(size, coords, 0, 4, dev, _in_prefetch=True)  # grid of scale 0 (sort of the points)
         if part in ("grids", "all"):
