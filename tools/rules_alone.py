@@ -49,9 +49,15 @@ def main():
         torch.cuda.synchronize()
         ms.append((e0.elapsed_time(e1), (t1 - t0) * 1e3))
     ms = ms[2:]
-    print("rule build alone, GRID_CHAIN=%s OCC_BUILD=%s (built %d): %.3f ms per batch (events; min %.3f), host issue time %.3f ms, %d rulebooks, "
-          "sites %s" % (SCN.GRID_CHAIN, SCN.OCC_BUILD, SCN.OCC_STATS["built"], sum(m[0] for m in ms) / len(ms), min(m[0] for m in ms),
-                        sum(m[1] for m in ms) / len(ms), len(plan), [g.n for g in md.grids.values()]))
+    if os.environ.get("RULES_ALONE_ALL"):
+        print("all (ms):", " ".join("%.2f" % m[0] for m in ms))
+    ev = sorted(m[0] for m in ms)
+    # (median: a generational collection of Python's garbage collector -- 35-40 ms in a process that has imported torch -- lands in
+    #  one of some twenty iterations, wherever the allocation counts put it)
+    print("rule build alone, GRID_CHAIN=%s OCC_BUILD=%s (built %d): %.3f ms per batch (events: median; min %.3f, max %.3f), host issue "
+          "time %.3f ms (median), %d rulebooks, sites %s" % (
+              SCN.GRID_CHAIN, SCN.OCC_BUILD, SCN.OCC_STATS["built"], ev[len(ev) // 2], ev[0], ev[-1],
+              sorted(m[1] for m in ms)[len(ms) // 2], len(plan), [md.grids[k].n for k in sorted(md.grids, reverse=True)][:6]))
 
 
 if __name__ == "__main__":
