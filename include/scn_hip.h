@@ -211,7 +211,10 @@ int scn_batch_build(const void *coords, const scn_batch_plan *plan_host, void *a
  *                    site count of every scale after ONE synchronisation (scn_occ_fetch reads them later)
  *   scn_batch_build_occ   as scn_batch_build with a layout from a plan whose flags bit 0 is set; `small` [2 l + 1] bit 1 of scale
  *                    0 set = a voxel holds more than SCN_OCC_SEGMENT_MAX input rows: `order` is NOT sorted inside such sites (the
- *                    caller sorts (site_of_row, row) itself or builds the batch with scn_batch_build) */
+ *                    caller sorts (site_of_row, row) itself or builds the batch with scn_batch_build).  scratch = NULL: the arena
+ *                    holds layout.total bytes, results and scratch; else the arena holds the results (layout.scratch bytes) and
+ *                    `scratch` layout.total - layout.scratch bytes that may be freed once the stream has passed the call (the
+ *                    neighbour tables of all scales: ~110 bytes per site) */
 #define SCN_OCC_MAX_WORDS ((int64_t)1 << 27)
 #define SCN_OCC_SEGMENT_MAX 64
 typedef struct {
@@ -230,7 +233,7 @@ int scn_occ_chain(const void *coords, int coords_dtype, int ncols, int64_t P, co
                   int32_t *n_sites_host, void *stream);
 int scn_occ_fetch(const void *occ, const scn_occ_box *box, int32_t *n_sites_host, void *stream);
 int scn_batch_build_occ(const void *coords, const scn_batch_plan *plan_host, const scn_occ_box *box, void *occ, void *arena,
-                        size_t arena_bytes, void *stream);
+                        size_t arena_bytes, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ------------------------------------------------------- gather-mm-scatter ---
  * out[o,:] = (bias) + sum_k sum_{pairs of list k} in[pair.in_col,:] . Wk

@@ -608,13 +608,21 @@ class Metadata_3(object):
         lo = _lib.BatchLayout()
         plan.flags = 1 if self._occ is not None else 0
         check(lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)))
-        arena = torch.empty(lo.total, dtype=torch.uint8, device=dev)
         if self._occ is not None:
+            # results and scratch apart: the results live as long as the batch, the scratch (the neighbour tables of all scales, the
+            # input rows' arrival numbers: ~110 bytes per site) and the bitmaps go back to the allocator behind this call -- it is
+            # stream-ordered, and the stream has the launches that use them (round-5 advisor: one allocation kept the scratch alive
+            # with the batch, twice over while a prefetched batch waits)
             box, buf = self._occ
-            check(lib.scn_batch_build_occ(ptr(c), ctypes.byref(plan), ctypes.byref(box), ptr(buf), ptr(arena), lo.total, stream()))
-            self._occ = None  # (the bitmaps are scratch of the build; the stream has the launches that read them)
+            arena = torch.empty(lo.scratch, dtype=torch.uint8, device=dev)
+            scratch = torch.empty(lo.total - lo.scratch, dtype=torch.uint8, device=dev)
+            check(lib.scn_batch_build_occ(ptr(c), ctypes.byref(plan), ctypes.byref(box), ptr(buf), ptr(arena), lo.scratch,
+                                          ptr(scratch), lo.total - lo.scratch, stream()))
+            self._occ = None
+            del scratch, buf
             OCC_STATS["built"] += 1
         else:
+            arena = torch.empty(lo.total, dtype=torch.uint8, device=dev)
             check(lib.scn_batch_build(ptr(c), ctypes.byref(plan), ptr(arena), lo.total, stream()))
         a32, a64 = arena.view(torch.int32), arena.view(torch.int64)
 

@@ -39,7 +39,7 @@ SIGNATURES = {
     "scn_occ_plan": (c_int, [ctypes.POINTER(c_int32), c_int, _P]),
     "scn_occ_chain": (c_int, [_P, c_int, c_int, c_int64, _P, _P, c_size_t, ctypes.POINTER(c_int32), _P]),
     "scn_occ_fetch": (c_int, [_P, _P, ctypes.POINTER(c_int32), _P]),
-    "scn_batch_build_occ": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P]),
+    "scn_batch_build_occ": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P, c_size_t, _P]),
     "scn_tile_passes_bytes": (c_size_t, [c_int64]),
     "scn_tile_passes": (c_int, [_P, c_int, c_int64, _P, _P]),
     "scn_conv_wpack_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -619,7 +619,7 @@ __global__ void k_input_table(const int32_t *order, const int32_t *site_start, i
 
 // ------------------------------------------------ occupancy bitmaps (round 6) ---
 // include/scn_hip.h, "the same batch from OCCUPANCY BITMAPS".  The table the kernels read lies at byte 0 of the buffer (written by
-// k_occ_header from its by-value argument: no host-to-device copy whose source could go out of scope), the counters behind it.
+// k_put from its by-value argument: no host-to-device copy whose source could go out of scope), the counters behind it.
 struct OccDev {
   int32_t levels, nb, ox, oy, oz, ob, pad0, pad1;
   int32_t nx[SCN_BATCH_MAX_LEVELS], ny[SCN_BATCH_MAX_LEVELS], nz[SCN_BATCH_MAX_LEVELS], wx[SCN_BATCH_MAX_LEVELS];
@@ -1628,12 +1628,16 @@ int scn_occ_fetch(const void *occ, const scn_occ_box *box, int32_t *n_sites_host
 }
 
 int scn_batch_build_occ(const void *coords, const scn_batch_plan *pl, const scn_occ_box *box, void *occ, void *arena,
-                        size_t arena_bytes, void *stream_) {
+                        size_t arena_bytes, void *scratch, size_t scratch_bytes, void *stream_) {
   hipStream_t stream = as_stream(stream_);
   scn_batch_layout lo;
   SCN_REQUIRE(pl != nullptr && (pl->flags & 1), "scn_batch_build_occ: the plan's flags bit 0 must be set");
   if (int rc = batch_layout(pl, &lo)) return rc;
-  SCN_REQUIRE(coords != nullptr && arena != nullptr && arena_bytes >= (size_t)lo.total, "scn_batch_build_occ: arena smaller than scn_batch_layout_query says");
+  // the scratch behind the results (one allocation of layout.total bytes), or an allocation of its own that the caller drops
+  // after the call while the results live as long as the batch
+  SCN_REQUIRE(coords != nullptr && arena != nullptr && arena_bytes >= (size_t)(scratch != nullptr ? lo.scratch : lo.total),
+              "scn_batch_build_occ: arena smaller than scn_batch_layout_query says");
+  SCN_REQUIRE(scratch == nullptr || scratch_bytes >= (size_t)(lo.total - lo.scratch), "scn_batch_build_occ: scratch smaller than layout.total - layout.scratch");
   SCN_REQUIRE(box != nullptr && box->bytes > 0 && occ != nullptr && box->levels >= pl->levels, "scn_batch_build_occ: the box must cover the plan's scales");
   char *A = (char *)arena, *B = (char *)occ;
   const uint64_t *buf = (const uint64_t *)B, *words = (const uint64_t *)(B + box->off_words);
@@ -1642,7 +1646,7 @@ int scn_batch_build_occ(const void *coords, const scn_batch_plan *pl, const scn_
   const int64_t P = pl->P, N0 = pl->N[0];
   int32_t *small = (int32_t *)(A + lo.small);
   // ---- what the multi-scale launches read: sizes, block ranges, where everything lies
-  char *S = A + lo.scratch;
+  char *S = scratch != nullptr ? (char *)scratch : A + lo.scratch, *const S0 = S;  // (offsets below are relative to the arena either way)
   int32_t *slot = (int32_t *)S; S += align256((size_t)P * 4);
   int *cnt = (int *)S; S += align256((size_t)(N0 + 1) * 4);
   const int nb0 = (int)((N0 + 1 + 255) / 256);
@@ -1690,7 +1694,7 @@ int scn_batch_build_occ(const void *coords, const scn_batch_plan *pl, const scn_
   }
   for (int l = L; l <= SCN_BATCH_MAX_LEVELS; ++l) bd.blk0[l] = (int32_t)nblocks;
   td.threads = threads;
-  SCN_REQUIRE((size_t)(S - A) <= (size_t)lo.total && nblocks < (int64_t)1 << 31, "scn_batch_build_occ: scratch layout");
+  SCN_REQUIRE((size_t)(S - S0) <= (size_t)(lo.total - lo.scratch) && nblocks < (int64_t)1 << 31, "scn_batch_build_occ: scratch layout");
   k_put<BatchDev><<<1, 64, 0, stream>>>(bd, (BatchDev *)(B + OCC_HDR_BATCH));
   SCN_CHECK_LAUNCH();
   k_put<TileDescs><<<1, 64, 0, stream>>>(td, (TileDescs *)(B + OCC_HDR_TILES));
