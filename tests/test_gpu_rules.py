@@ -466,3 +466,77 @@ def test_batch_layout_query(gpu):
     plan.N[1] = 17000
     plan.strided[2] = 1
     assert lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)) != 0
+
+
+def test_prefetched_bitmap_build_repairs_a_long_segment_at_adoption(gpu, monkeypatch):
+    """a batch built ahead on the side stream under no_grad leaves its read-back to the InputLayer call that adopts it
+    (SCN.DEFER_PREFETCH_READBACK): the "a voxel holds more than 64 rows" flag of scn_batch_build_occ arrives there too, and the
+    host's sort of (site, row) runs before anything reads `order` -- the adopted arrays equal the sort build's"""
+    from occuseg_amd import SCN
+    rng = np.random.default_rng(3)
+    c = np.concatenate([rng.integers(0, 50, size=(12000, 3)) + 4, rng.integers(0, 2, size=(12000, 1))], 1)
+    c[rng.permutation(12000)[:200]] = np.array([20, 21, 22, 1])
+    coords = torch.from_numpy(np.ascontiguousarray(c)).to(gpu)
+    size = torch.tensor([4096 + 16 * 11] * 3, dtype=torch.int64)
+    key = tuple(int(v) for v in size)
+    monkeypatch.setattr(SCN, "GRID_CHAIN", False)
+    monkeypatch.setattr(SCN, "OCC_BUILD", False)
+    SCN._PLANS.pop(key, None)
+    m0 = SCN.Metadata_3()
+    m0.inputLayer(size, coords, 0, 4, gpu)
+    ref = _walk_levels(m0, size, 3)          # (records the plan)
+    monkeypatch.setattr(SCN, "OCC_BUILD", True)
+    before = dict(SCN.OCC_STATS)
+    with torch.no_grad():
+        SCN.prefetch_input(size, coords, 4, gpu)
+        pre = SCN._PREFETCHED[id(coords)][2]
+        assert pre._deferred is not None and SCN.OCC_STATS["order_repaired"] == before["order_repaired"]  # (not read back yet)
+        m = SCN.Metadata_3()
+        m.inputLayer(size, coords, 0, 4, gpu)
+    assert SCN.OCC_STATS["built"] == before["built"] + 1 and SCN.OCC_STATS["order_repaired"] == before["order_repaired"] + 1
+    _same_walk(ref, _walk_levels(m, size, 3))
+
+
+def test_batch_build_occ_with_and_without_a_scratch_of_its_own(gpu):
+    """scn_batch_build_occ's two forms -- results and scratch in one arena of layout.total bytes (scratch = NULL), or the scratch as an
+    allocation the caller drops behind the call -- leave the same results, byte for byte"""
+    import ctypes
+    from occuseg_amd import SCN, _lib, scenes
+    from occuseg_amd.SCN import ptr, stream, check
+    lib = SCN._lib_()
+    c, _ = scenes.batch([1000, 1001], target_sites=8000)
+    t = torch.from_numpy(np.ascontiguousarray(c)).to(gpu)
+    P, L = t.size(0), 3
+    mm = (ctypes.c_int32 * 8)()
+    check(lib.scn_occ_bounds(ptr(t), 1, 4, P, ptr(torch.empty(16, dtype=torch.int32, device=gpu)), mm, stream()))
+    box = _lib.OccBox()
+    check(lib.scn_occ_plan(mm, L, ctypes.byref(box)))
+    results = []
+    for own_scratch in (False, True):
+        buf = torch.empty(box.bytes, dtype=torch.uint8, device=gpu)
+        n = (ctypes.c_int32 * L)()
+        check(lib.scn_occ_chain(ptr(t), 1, 4, P, ctypes.byref(box), ptr(buf), box.bytes, n, stream()))
+        plan = _lib.BatchPlan()
+        plan.levels, plan.coords_dtype, plan.ncols, plan.P, plan.flags = L, 1, 4, P, 1
+        for l in range(L):
+            plan.N[l], plan.sub[l], plan.strided[l] = n[l], 1, 1 if l + 1 < L else 0
+        lo = _lib.BatchLayout()
+        check(lib.scn_batch_layout_query(ctypes.byref(plan), ctypes.byref(lo)))
+        if own_scratch:
+            arena = torch.full((lo.scratch,), 0xA5, dtype=torch.uint8, device=gpu)
+            scratch = torch.empty(lo.total - lo.scratch, dtype=torch.uint8, device=gpu)
+            check(lib.scn_batch_build_occ(ptr(t), ctypes.byref(plan), ctypes.byref(box), ptr(buf), ptr(arena), lo.scratch, ptr(scratch),
+                                          lo.total - lo.scratch, stream()))
+            # a scratch that is too small is refused
+            assert lib.scn_batch_build_occ(ptr(t), ctypes.byref(plan), ctypes.byref(box), ptr(buf), ptr(arena), lo.scratch, ptr(scratch),
+                                           lo.total - lo.scratch - 1, stream()) != 0
+        else:
+            arena = torch.full((lo.total,), 0xA5, dtype=torch.uint8, device=gpu)
+            check(lib.scn_batch_build_occ(ptr(t), ctypes.byref(plan), ctypes.byref(box), ptr(buf), ptr(arena), lo.total, None, 0, stream()))
+            assert lib.scn_batch_build_occ(ptr(t), ctypes.byref(plan), ctypes.byref(box), ptr(buf), ptr(arena), lo.scratch, None, 0,
+                                           stream()) != 0
+        results.append((arena[:lo.scratch].cpu(), [int(v) for v in n]))
+    (a, na), (b, nb) = results
+    assert na == nb
+    # every byte the build writes is the same (rows behind a list's length and alignment gaps keep the 0xA5 fill in both)
+    assert torch.equal(a, b)
