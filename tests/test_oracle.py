@@ -370,3 +370,45 @@ def test_bench_parity_fullsize_machinery_on_cpu():
     dev["grads"][7] = (name, shape, bad)
     res = bench.compare_passes(dev, got, order, 0, 1)
     assert not res["ok"] and res["worst_tensor"].startswith(name) and "tensor 8 of" in res["worst_tensor"]
+
+
+@pytest.mark.parametrize("name", ["dense", "sparse", "bernoulli", "word-edges"])
+def test_occupancy_bitmap_algorithm_reproduces_the_reference_ranks(name):
+    """WHY scn_batch_build_occ (round 6) agrees with the reference's sort + hash, on the CPU: oracle/occupancy.py restates the
+    bitmap algorithm of csrc/scn_rules.hip in numpy (same box as scn_occ_plan -- compared field by field with the C function --,
+    32 bits + a running count per word, the same index arithmetic) and reproduces what oracle/rules.py restates from the
+    reference: site order, the site of every input row, the 27-neighbour table, the coarse grids and the fine -> coarse map of
+    two coarsenings"""
+    import ctypes
+    from occuseg_amd import _lib, scenes
+    from oracle import occupancy as O, rules as R
+    coords = {"dense": lambda: random_points(0, 300, 2, 7),
+              "sparse": lambda: random_points(1, 200, 3, 30, origin=10),
+              "bernoulli": lambda: scenes.bernoulli_grid(12, 0.3, 3) + np.array([5, 1001, 37]),
+              "word-edges": lambda: np.array([[x, y, 3, b] for b in (0, 1) for x in (30, 31, 32, 33, 62, 63, 64, 65, 96) for y in (7, 8)]
+                                             + [[31, 8, 3, 1]], np.int64)}[name]()
+    levels = 3
+    occ = O.Occupancy(coords, levels)
+    # the box: the same numbers as the C function
+    c4 = coords if coords.shape[1] == 4 else np.concatenate([coords, np.zeros((len(coords), 1), np.int64)], 1)
+    mm = (ctypes.c_int32 * 8)(*[int(v) for v in list(c4.min(0)) + list(c4.max(0))])
+    box = _lib.OccBox()
+    assert _lib.load().scn_occ_plan(mm, levels, ctypes.byref(box)) == 0
+    assert list(box.origin) == [int(v) for v in occ.box.origin] and box.nb == occ.box.nb
+    assert [list(box.n[l]) for l in range(levels)] == occ.box.n and list(box.wx)[:levels] == occ.box.wx
+    assert list(box.woff)[:levels + 1] == occ.box.woff
+    # scale 0: sites, rows, neighbours
+    grid, header, table, site_of_point = R.input_layer_rules(coords)
+    assert np.array_equal(occ.sites(0), grid.coords) and occ.n_sites[0] == grid.n
+    assert np.array_equal(occ.site_of_row(), site_of_point)
+    for l in range(levels):
+        _, nbr = R.submanifold_rules(grid)
+        assert np.array_equal(occ.neighbours(l), nbr), (name, l)
+        if l + 1 < levels:
+            coarse, rules, child = R.strided_rules(grid)
+            assert np.array_equal(occ.sites(l + 1), coarse.coords) and occ.n_sites[l + 1] == coarse.n
+            want = np.full(grid.n, -1, np.int64)
+            for k in range(8):
+                want[rules[k][:, 0]] = rules[k][:, 1]
+            assert np.array_equal(occ.coarse_of_fine(l), want)
+            grid = coarse
