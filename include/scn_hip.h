@@ -10,8 +10,9 @@
  *   - features are contiguous fp32 [rows, planes]; indices are int32 (`Int`,
  *     sparseconvnet/SCN/Metadata/32bits.h:11);
  *   - `stream` is a hipStream_t passed as void*; nothing runs on another stream;
- *   - the only entry points that synchronise the stream are the two whose
- *     result size is data dependent (scn_grid_build, scn_input_rules_max_active);
+ *   - the only entry points that synchronise the stream are those whose
+ *     result sizes the next allocation (scn_grid_build, scn_input_rules_max_active,
+ *     scn_grid_chain_counts / _fetch, scn_occ_bounds, scn_occ_chain / scn_occ_fetch);
  *   - no entry point allocates device memory: callers pass workspaces whose
  *     sizes are given by the *_bytes query functions;
  *   - return value 0 = ok, otherwise an error code; scn_last_error() holds text.
