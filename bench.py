@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
+import gc
 import hashlib
 import json
 import os
@@ -530,6 +531,12 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sites_done = 0
     first = counter[0]
+    # Python's generational garbage collector walks every container object of the process when its oldest generation comes due: 35-40
+    # ms in a process that has imported torch (profiles/r06_rules_alone.txt: one iteration in twenty of a 0.45 ms loop), at a moment the
+    # allocation counts pick.  What a long-running training or serving loop does after its warm-up: collect once, then move what is
+    # alive out of the collector's sight -- the timed steps allocate and free as before, nothing of the step is skipped.
+    gc.collect()
+    gc.freeze()
     barrier()
     wpack_before = dict(SCN.WPACK_STATS)
     t0 = time.perf_counter()
@@ -783,6 +790,9 @@ def main():
                        "weight_repack": "every (weight, orientation) pair re-laid out once per step in one launch "
                                         "(SCN weight epochs): %d multi-tensor launches, %d single ones in the timed region"
                                         % (wpack_after["batch"] - wpack_before["batch"], wpack_after["single"] - wpack_before["single"]),
+                       "python_gc": "gc.collect() + gc.freeze() behind the warm-up, before the timed region (a generational collection "
+                                    "takes 35-40 ms in this process wherever the allocation counts put it)",
+                       "rule_build": ("occupancy bitmaps (scn_batch_build_occ)" if SCN.OCC_STATS["built"] else "sort + hash"),
                        "source_hash": source_hash()},
             "roofline": roof, "kernels": kernels, "peaks_measured": peaks,
         }
