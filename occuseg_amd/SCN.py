@@ -446,7 +446,11 @@ class Metadata_3(object):
         c = coords.to(device, non_blocking=True).contiguous()
         P = c.size(0)
         old_plan = _PLANS.get(key, [])
-        batchable = (BATCH_BUILD and normals is None and not KEEP_NBR and not (PROFILE is not None and "rules" in PROFILE_KINDS))
+        # (normals: the batch build leaves the input scale's 3x3x3 rulebook -- the one they re-sort, remap_rules_with_normal -- to
+        #  getSubmanifoldRuleBook below; where they would guide STRIDED rules too, nothing is built ahead and the op says what the
+        #  reference's path for that is worth, see getRuleBook)
+        batchable = (BATCH_BUILD and (normals is None or key[0] < self.normal_guide_scale) and not KEEP_NBR
+                     and not (PROFILE is not None and "rules" in PROFILE_KINDS))
         speculative = False
         if not old_plan and PREBUILD and OCC_BUILD and OCC_FIRST_BATCH and batchable:
             # the FIRST batch on this input size: no forward pass has said yet which rulebooks it wants.  From bitmaps every grid and
@@ -474,7 +478,7 @@ class Metadata_3(object):
         batch_small = None
         if fetch is not None and batchable:
             # every grid and rulebook of the chain queued by ONE call into one arena (scn_batch_build)
-            batch_small = self._batch_build(c, sizes, fetch(), old_plan)
+            batch_small = self._batch_build(c, sizes, fetch(), old_plan, skip_sub=(key,) if normals is not None else ())
             g = self.grids[key]
         else:
             g, order, site_of_row, site_start = self._build_grid(c, _COORD_DTYPES[c.dtype], c.size(1), 0, P,
@@ -487,7 +491,7 @@ class Metadata_3(object):
             pn = normals.to(device=device, dtype=torch.float32).contiguous()
             sn = torch.empty((g.n, 3), dtype=torch.float32, device=c.device)
             ori = torch.empty(g.n, dtype=torch.int32, device=c.device)
-            check(_lib_().scn_site_normals(ptr(pn), ptr(order), ptr(site_start), g.n, ptr(sn), ptr(ori), stream()))
+            check(_lib_().scn_site_normals(ptr(pn), ptr(self.input_order), ptr(self.input_site_start), g.n, ptr(sn), ptr(ori), stream()))
             self.normals[key] = (sn, ori)
         self._plan = []          # requests made by the ops of THIS forward pass (stale ones drop out)
         _PLANS[key] = self._plan
@@ -591,7 +595,7 @@ class Metadata_3(object):
             return self._chain_counts
         return fetch, sizes
 
-    def _batch_build(self, c, sizes, counts, old_plan):
+    def _batch_build(self, c, sizes, counts, old_plan, skip_sub=()):
         """scn_batch_build: the grids of the chain `sizes` (site counts known: `counts`), the 2/2 rulebooks between them and the
         submanifold rulebooks the previous forward pass asked for, queued by one call into one arena; every array the ops read
         is a view into it.  Returns (the `small` block to read back, what _batch_finish needs)."""
@@ -603,7 +607,7 @@ class Metadata_3(object):
         want_sub = {req[1] for req in old_plan if req[0] == "sub" and req[2] == (3, 3, 3)}
         for l, sz in enumerate(sizes):
             plan.N[l] = counts[sz]
-            plan.sub[l] = 1 if sz in want_sub else 0
+            plan.sub[l] = 1 if sz in want_sub and sz not in skip_sub else 0
             plan.strided[l] = 1 if l + 1 < L else 0
         lo = _lib.BatchLayout()
         plan.flags = 1 if self._occ is not None else 0

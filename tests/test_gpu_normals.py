@@ -20,11 +20,17 @@ def _case(seed, n=4000, batch=2, extent=24):
     return coords, normals
 
 
+@pytest.mark.parametrize("path", ["sort_hash", "bitmaps"])
 @pytest.mark.parametrize("seed", [0, 1])
-def test_normal_guided_rulebook_bit_exact(gpu, seed):
+def test_normal_guided_rulebook_bit_exact(gpu, seed, path, monkeypatch):
+    """(`bitmaps`, round 6: a normal-guided batch is built from occupancy bitmaps too -- all of it but the input scale's 3x3x3
+    rulebook, which the normals re-sort and getSubmanifoldRuleBook builds from the hash map it makes for that)"""
     from occuseg_amd import SCN
     from oracle import rules as R
     coords, normals = _case(seed)
+    monkeypatch.setattr(SCN, "OCC_BUILD", path == "bitmaps")
+    SCN._PLANS.clear()
+    built = SCN.OCC_STATS["built"]
     grid, _, table, _ = R.input_layer_rules(coords)
     want_sn = R.site_normals(normals, table)
     want_ori = R.oriented_filter(want_sn)
@@ -33,6 +39,7 @@ def test_normal_guided_rulebook_bit_exact(gpu, seed):
     m = SCN.Metadata_3()
     size = torch.tensor([4096] * 3)
     m.inputLayer(size, torch.from_numpy(coords), 0, 4, gpu, normals=torch.from_numpy(normals).to(gpu))
+    assert SCN.OCC_STATS["built"] == built + (1 if path == "bitmaps" else 0)
     sn, ori = m.normals[(4096, 4096, 4096)]
     assert np.array_equal(ori.cpu().numpy().astype(np.int64), want_ori)
     assert set(np.unique(want_ori)) == {0, 2, 4}
