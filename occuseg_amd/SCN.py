@@ -135,6 +135,7 @@ _OB = os.environ.get("SCN_OCC_BUILD", "auto")
 OCC_BUILD = True if _OB == "1" else False if _OB == "0" else "auto"
 OCC_WORDS_PER_ROW = 64
 OCC_FIRST_BATCH = os.environ.get("SCN_OCC_FIRST_BATCH", "1") != "0"  # see Metadata_3.inputLayer ("speculative")
+OCC_FIRST_BATCH_LEVELS = 8
 OCC_STATS = {"built": 0, "too_large": 0, "order_repaired": 0}  # since import (tests, tools)
 DEFER_PREFETCH_READBACK = os.environ.get("SCN_DEFER_PREFETCH_READBACK", "1") != "0"
 _PINNED = []  # pinned host buffers of the deferred read-backs (allocating one costs a millisecond: kept and re-used)
@@ -457,10 +458,12 @@ class Metadata_3(object):
             # rulebook a UNet could ask for (3x3x3 at every scale, 2/2 between scales, while the size halves) costs a fraction of
             # building the ones it does ask for by sort + hash, one at a time; what the ops then do not ask for is dropped with
             # this batch (the plan of the next one is what they DID ask for).  A box too large for that falls through to the old way.
+            # (OCC_FIRST_BATCH_LEVELS scales: the box's origin is aligned to 2^(scales - 1) -- with all twelve a cloud far from
+            #  the origin would get a box that starts at 0; a network deeper than that builds its coarsest grids as it asks)
             old_plan, sz = [], key
-            while len(old_plan) < 2 * _lib.BATCH_MAX_LEVELS - 1:
+            while len(old_plan) < 2 * OCC_FIRST_BATCH_LEVELS - 1:
                 old_plan.append(("sub", sz, (3, 3, 3)))
-                if any(v % 2 or v < 4 for v in sz) or len(old_plan) >= 2 * _lib.BATCH_MAX_LEVELS - 1:
+                if any(v % 2 or v < 4 for v in sz) or len(old_plan) >= 2 * OCC_FIRST_BATCH_LEVELS - 1:
                     break
                 nxt = tuple(v // 2 for v in sz)
                 old_plan.append(("conv", sz, nxt, (2, 2, 2), (2, 2, 2)))
